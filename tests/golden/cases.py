@@ -1,0 +1,84 @@
+"""Shared, reference-free definitions of the golden test cases: deterministic
+inputs, the linear output functionals used for backward, summaries.  Imported by
+make_golden.py (build container) and by the tests (everywhere)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from detweights import det_tensor
+
+NLSPN_CFG = dict(prop_kernel=3, prop_time=18, affinity='TGASS', affinity_gamma=0.5,
+                 conf_prop=True, preserve_input=False)
+
+STEP_HP = dict(B=2, H=60, W=76, lr=2e-3, beta1=0.5, beta2=0.999, lambda_A=100.0, lambda_B=100.0, lambda_L1=100.0)
+
+
+def _smooth(t, k=9):
+    c = t.shape[1]
+    w = torch.ones(c, 1, k, k) / (k * k)
+    return F.conv2d(F.pad(t, (k // 2,) * 4, mode='replicate'), w, groups=c)
+
+
+def synth_depth(seed, key, B, H, W):
+    """NYUv2-like metric depth (mean 2.84 m, std 0.99 m, clipped), normalised (m-5)/5;
+    raw depth = gt with rectangular holes set to 0 m -> -1.0."""
+    m = (2.84 + 3.0 * _smooth(det_tensor(seed, key + '.m', (B, 1, H, W)))).clamp(0.713, 9.995)
+    gt = (m - 5.0) / 5.0
+    raw = gt.clone()
+    r = det_tensor(seed, key + '.holes', (B, 6, 4), 'rand')
+    for b in range(B):
+        for y0, x0, hh, ww in r[b].tolist():
+            ys, xs = int(y0 * H * 0.8), int(x0 * W * 0.8)
+            raw[b, :, ys:ys + max(2, int(hh * H * 0.35)), xs:xs + max(2, int(ww * W * 0.35))] = -1.0
+    mask = m > 1e-4
+    return gt, raw, mask
+
+
+def unit_normals(seed, key, B, H, W):
+    return F.normalize(_smooth(det_tensor(seed, key, (B, 3, H, W)), 5) + 0.05 * det_tensor(seed, key + '.n', (B, 3, H, W)), dim=1)
+
+
+def gen_inputs(tag, B, H, W):
+    rgb = det_tensor(1, tag + '.rgb', (B, 3, H, W), 'rand') * 2 - 1
+    _, raw, _ = synth_depth(1, tag + '.depth', B, H, W)
+    return rgb, raw, unit_normals(1, tag + '.normal', B, H, W)
+
+
+def out_weights(tag, key, shape):
+    """Fixed random cotangent so that backward exercises every output."""
+    return det_tensor(7, f'{tag}.{key}', tuple(shape))
+
+
+def grad_summary(net):
+    names, rows = [], []
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            g = p.grad.double()
+            rows.append([float(g.sum()), float(g.norm())])
+    return names, np.array(rows)
+
+
+def step_batch(it, B, H, W):
+    gt, raw, mask = synth_depth(20 + it, 'step.depth', B, H, W)
+    data = dict(rgb=det_tensor(20 + it, 'step.rgb', (B, 3, H, W), 'rand') * 2 - 1,
+                gt_depth=gt, raw_depth=raw, depth_masks=mask,
+                gt_normal=unit_normals(20 + it, 'step.gtn', B, H, W),
+                labels=torch.zeros(B, H, W, dtype=torch.long),
+                normal_masks=torch.ones(B, 1, H, W))
+    return data, unit_normals(20 + it, 'step.nA', B, H, W), unit_normals(20 + it, 'step.nfA', B, H, W)
+
+
+def pepper_mask(seed, shape):
+    """The mask upstream's addPepperNoise would draw after random.seed(seed) /
+    np.random.seed(seed) (helper.py:384-402): returns None (no noise this call) or
+    an int array in {0,1,2} of shape (B,1,H,W)."""
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    if not random.uniform(0, 1) < 0.9:
+        return None
+    b, c, h, w = shape
+    snr = 0.98
+    pct = 1 - snr
+    return np.random.choice((0, 1, 2), size=(b, 1, h, w), p=[snr, pct / 2., pct / 2.])

@@ -1,0 +1,208 @@
+"""Generate the committed golden fixtures from the upstream reference.
+
+Run in the BUILD CONTAINER only (needs /root/reference):
+    python tests/golden/make_golden.py [--only NAME]
+Outputs tests/golden/*.npz.  Inputs and weights are regenerated deterministically
+by tests (detweights.py), so fixtures hold expected outputs / gradients /
+checksums only.
+"""
+import argparse
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_harness as rh                                   # noqa: E402
+from detweights import det_state_dict, det_tensor          # noqa: E402
+from cases import NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP   # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f'wrote {path}  ({os.path.getsize(path) / 1e6:.2f} MB)')
+
+
+def run_module(net, inputs, tag, out_keys=None, full_grads=()):
+    """forward (train + eval), then backward of a fixed linear functional of the outputs."""
+    res = {}
+    net.eval()
+    with torch.no_grad():
+        o = net(*inputs)
+    o = o if isinstance(o, dict) else {'out': o}
+    for k, v in o.items():
+        res[f'eval.{k}'] = v
+    net.train()
+    ins = [t.clone().requires_grad_(t.is_floating_point()) for t in inputs]
+    o = net(*ins)
+    o = o if isinstance(o, dict) else {'out': o}
+    loss = 0
+    for k, v in o.items():
+        res[f'train.{k}'] = v
+        loss = loss + (v * out_weights(tag, k, v.shape)).sum()
+    loss.backward()
+    for i, t in enumerate(ins):
+        if t.grad is not None:
+            res[f'grad_in.{i}'] = t.grad
+    names, summ = grad_summary(net)
+    res['grad_names'] = np.array(names)
+    res['grad_summary'] = summ
+    for k in full_grads:
+        res[f'grad.{k}'] = dict(net.named_parameters())[k].grad
+    bufs = {k: v for k, v in net.state_dict().items() if k.endswith('running_mean') or k.endswith('running_var')}
+    res['buf_names'] = np.array(list(bufs))
+    res['buf_summary'] = np.array([[float(v.sum()), float(v.norm())] for v in bufs.values()])
+    return res
+
+
+def g_a2b(nlspn, B, H, W, name, full=True):
+    RG, _, _, _ = rh.ref_classes()
+    net = RG(pretrained_on_imagenet=False, use_nlspn_refine=nlspn, nlspn_configs=NLSPN_CFG)
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    rgb, depth, normal = gen_inputs('g_a2b', B, H, W)
+    fg = ('rgb_branch_en1.0.bias', 'rgb_conf_dec0.0.weight', 'fuse_layer1.style.linear.bias',
+          'rgb_branch_encoder_decoder.en6.1.weight', 'depth_branch_en1_depth.0.weight',
+          'id_dec0.0.weight', 'depth_branch_encoder_decoder.de2.1.bias')
+    if nlspn:
+        fg += ('nlspn_refine_module.prop_layer.conv_offset_aff.weight', 'nlspn_refine_module.prop_layer.aff_scale_const')
+    res = run_module(net, (rgb, depth, normal), name, full_grads=fg)
+    if not full:   # big case: keep train-mode outputs + summaries only
+        res = {k: v for k, v in res.items() if not k.startswith('eval.') or k == 'eval.pred_depth'}
+    save(name, **res)
+
+
+def g_b2a(B, H, W, name):
+    _, RB, _, _ = rh.ref_classes()
+    net = RB(1, 3, 64, 'IN2d')
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    x = gen_inputs('g_b2a', B, H, W)[1]
+    save(name, **run_module(net, (x,), name, full_grads=('model.1.bias', 'model.6.weight', 'model.23.weight', 'model.18.weight')))
+
+
+def disc(cin, B, H, W, name):
+    _, _, PD, _ = rh.ref_classes()
+    net = PD(cin, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    x = det_tensor(3, f'disc{cin}', (B, cin, H, W))
+    save(name, **run_module(net, (x,), name, full_grads=('model.0.conv.bias', 'model.4.conv.weight', 'model.1.bn2d.weight')))
+
+
+def wadain():
+    rh.install()
+    from lib.models.generator.rdf_generator.model_utils import AdaptiveInstanceNorm
+    res = {}
+    for i, (c, h, w) in enumerate([(512, 5, 7), (768, 6, 9), (384, 9, 8), (192, 12, 10)], 1):
+        m = AdaptiveInstanceNorm(c, c)
+        m.load_state_dict(det_state_dict(m.state_dict(), i))
+        x = det_tensor(4, f'wadain_x{i}', (2, c, h, w)).requires_grad_(True)
+        s = det_tensor(4, f'wadain_s{i}', (2, c, h, w)).requires_grad_(True)
+        y = m(x, s)
+        (y * out_weights('wadain', str(i), y.shape)).sum().backward()
+        res.update({f'y{i}': y, f'gx{i}': x.grad, f'gs{i}': s.grad,
+                    f'gw_corner{i}': m.style.linear.weight_orig.grad[:32, :32].clone(),
+                    f'gw_summary{i}': np.array([float(m.style.linear.weight_orig.grad.double().sum()),
+                                                float(m.style.linear.weight_orig.grad.double().norm())]),
+                    f'gb{i}': m.style.linear.bias.grad})
+    save('wadain', **res)
+
+
+def losses():
+    _, _, _, gl = rh.ref_classes()
+    res = {}
+    p = det_tensor(5, 'p', (2, 1, 26, 36)).requires_grad_(True)
+    for mode in ('lsgan',):
+        crit = gl.GANLoss(mode)
+        for real in (True, False):
+            v = crit(p, real)
+            g, = torch.autograd.grad(v, p)
+            res[f'gan.{mode}.{int(real)}'] = v
+            res[f'gan.{mode}.{int(real)}.grad'] = g
+    for C in (1, 3):
+        a = det_tensor(5, f'a{C}', (2, C, 20, 24)).requires_grad_(True)
+        b = det_tensor(5, f'b{C}', (2, C, 20, 24))
+        m = (det_tensor(5, 'm', (2, 1, 20, 24), 'rand') > 0.3)
+        w = m / (m.sum() + 1e-6)
+        for nm, fn in (('l1', gl.L1_loss), ('l2', gl.L2_loss)):
+            for wn, ww in (('w', w), ('u', None)):
+                v = fn(a, b, weight=ww)
+                g, = torch.autograd.grad(v, a)
+                res[f'{nm}.{C}.{wn}'] = v
+                res[f'{nm}.{C}.{wn}.grad'] = g
+    save('losses', **res)
+
+
+class _Node(dict):
+    __getattr__ = dict.__getitem__
+
+
+def step_trace(nsteps=2):
+    """Run upstream RDFCGAN.optimize_parameters itself (NNET / PSPNet replaced by
+    constant stand-ins) and record the loss dict + weight / BN-buffer checksums."""
+    rh.install()
+    from lib.models.rdfc_gan import RDFCGAN
+    from lib.models.generator.normal_net.NNET import NNET
+    hp = STEP_HP
+    model_cfg = _Node(
+        G_A2B=dict(type='RDFGenerator', pretrained_on_imagenet=False),
+        G_B2A=dict(type='ResnetGenerator', input_channels=1, output_channels=3, ngf=64, norm_layer='IN2d'),
+        D_A=dict(type='PatchGANDiscriminator', in_channels=1, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'),
+        D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'))
+    args = _Node(local_rank=0, model=model_cfg, lr=hp['lr'], beta1=hp['beta1'], beta2=hp['beta2'], weight_decay=0.0,
+                 gan_loss_type='lsgan', scheduler='linear', epoch=0, decay_epoch=100, n_epochs=150,
+                 lambda_A=hp['lambda_A'], lambda_B=hp['lambda_B'], lambda_L1=hp['lambda_L1'], optimizer='adam')
+    m = RDFCGAN(device=torch.device('cpu'), distributed=False, args=args, is_train=True,
+                out_height=hp['H'], out_width=hp['W'])
+    for key, net in (('G_A2B', m.G_A2B), ('G_B2A', m.G_B2A), ('disc_A', m.disc_A), ('disc_B', m.disc_B)):
+        net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    m.train()
+    res = {}
+    for it in range(nsteps):
+        data, normal_A, normal_fA = step_batch(it, hp['B'], hp['H'], hp['W'])
+        pad = torch.zeros(hp['B'], 1, hp['H'], hp['W'])
+        NNET.queue[:] = [torch.cat([normal_A, pad], 1), torch.cat([normal_fA, pad], 1), torch.cat([normal_fA, pad], 1)]
+        random.seed(100 + it)
+        np.random.seed(100 + it)
+        m.set_input(data)
+        ls = m.optimize_parameters()
+        keys = sorted(k for k in ls if not any(s in k for s in ('label', 'normal', 'floor', 'wall', 'ceiling')))
+        res[f'loss_names.{it}'] = np.array(keys)
+        res[f'loss_values.{it}'] = np.array([ls[k] for k in keys], dtype=np.float64)
+        extra = sum(ls[k] for k in ls if any(s in k for s in ('label', 'normal', 'floor', 'wall', 'ceiling')))
+        res[f'loss_extra.{it}'] = np.float64(extra)
+        for key, net in (('G_A2B', m.G_A2B), ('G_B2A', m.G_B2A), ('disc_A', m.disc_A), ('disc_B', m.disc_B)):
+            sd = net.state_dict()
+            names = [k for k in sd if not k.endswith('num_batches_tracked')]
+            res[f'sd_names.{key}'] = np.array(names)
+            res[f'sd_summary.{key}.{it}'] = np.array([[float(sd[k].double().sum()), float(sd[k].double().norm())] for k in names])
+        res[f'fake_B.{it}'] = m.fake_B.detach().clone()
+        res[f'fake_A.{it}'] = m.fake_A.detach().clone()
+    save('step_trace', **res)
+
+
+JOBS = {
+    'g_a2b_small': lambda: g_a2b(False, 2, 60, 76, 'g_a2b_small'),
+    'g_a2b_nlspn_small': lambda: g_a2b(True, 2, 60, 76, 'g_a2b_nlspn_small'),
+    'g_a2b_full_b1': lambda: g_a2b(False, 1, 228, 304, 'g_a2b_full_b1', full=False),
+    'g_b2a_small': lambda: g_b2a(2, 60, 76, 'g_b2a_small'),
+    'd_a_small': lambda: disc(1, 2, 60, 76, 'd_a_small'),
+    'd_b_small': lambda: disc(3, 2, 60, 76, 'd_b_small'),
+    'wadain': wadain,
+    'losses': losses,
+    'step_trace': step_trace,
+}
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', nargs='*')
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    for name, job in JOBS.items():
+        if a.only and name not in a.only:
+            continue
+        job()
