@@ -1,0 +1,203 @@
+/*
+ * rdfc_hip.h -- C ABI of librdfc_hip.so: the MI355X (gfx950) kernels behind the
+ * RDFC-GAN generator / discriminator train-step hot path.
+ *
+ * Boundary rules
+ *   - plain C: device pointers, ints, floats, one POD descriptor struct; no torch /
+ *     ATen types.  Every entry point enqueues work on `stream` (a hipStream_t passed
+ *     as void*) and returns immediately; nothing here allocates or synchronises.
+ *   - return value: 0 on success, non-zero on a rejected argument or a failed
+ *     launch; rdfc_last_error() returns the message (upstream only printf'ed launch
+ *     failures: modulated_deform_im2col_cuda.cuh:348-352 -- here they are errors).
+ *   - activations are "pixel-major": element (n, y, x, c) of a feature map lives at
+ *     base[((n*H + y)*W + x) * ld + c], ld >= C (ld > C addresses a channel slice of
+ *     a wider map, which is how channel concatenation is done without a copy pass).
+ *     1-channel maps are therefore bit-identical to upstream's NCHW tensors.
+ *   - dtype: RDFC_F32 (exact-f32 MFMA path, parity mode) or RDFC_BF16 (bf16 storage,
+ *     bf16 MFMA, f32 accumulation).  Statistics, scales, losses, weight gradients
+ *     and optimizer state are always f32.
+ *
+ * Each group below cites the upstream interface it stands in for (paths relative to
+ * RDFC-GAN/).  The python side (rdfc_gan_amd/) binds this file with ctypes; a
+ * maintainer of upstream would bind it the same way.
+ */
+#ifndef RDFC_HIP_H
+#define RDFC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RDFC_F32 = 0, RDFC_BF16 = 1 };
+enum { RDFC_ACT_NONE = 0, RDFC_ACT_RELU = 1, RDFC_ACT_LRELU = 2, RDFC_ACT_TANH = 3, RDFC_ACT_SIGMOID = 4,
+       RDFC_ACT_PRELU = 5 /* slope read from device memory */ };
+
+const char *rdfc_last_error(void);
+int rdfc_version(void);
+
+/* ------------------------------------------------------------------------------
+ * Convolution family (implicit GEMM on MFMA).
+ * Stands in for ATen conv2d / conv_transpose2d fwd+bwd as called by
+ *   lib/models/generator/rdf_generator/encoder_decoder/common.py:29-61 (conv_bn_relu,
+ *   convt_bn_relu), torchvision BasicBlock, lib/models/generator/resnet_generator.py:19-50,
+ *   lib/models/module/conv_norm_act.py:66-75, model_utils.py:39-50 (EqualLinear == 1x1).
+ *
+ * One descriptor describes the *forward* convolution  y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w[Co,Ci,KH,KW]).
+ * ConvTranspose2d is expressed through the same three primitives with the roles of
+ * x and y exchanged (its forward is rdfc_conv2d_dgrad, its input-gradient is
+ * rdfc_conv2d_forward, its weight-gradient is rdfc_conv2d_wgrad with x<->dy).
+ * ------------------------------------------------------------------------------ */
+typedef struct rdfc_conv_desc {
+    int32_t N, Hi, Wi, Ci;      /* input map                                         */
+    int32_t Ho, Wo, Co;         /* output map                                        */
+    int32_t KH, KW;             /* kernel                                            */
+    int32_t sh, sw, ph, pw, dh, dw;
+    int32_t ldx, ldy;           /* pixel strides (elements) of x / y                 */
+    int32_t dtype;              /* RDFC_F32 | RDFC_BF16: storage + MFMA type of x,y,w */
+    int32_t act;                /* epilogue activation applied after bias (forward)  */
+    float   slope;              /* LeakyReLU slope                                   */
+    int32_t out_f32;            /* 1: result stored as f32 regardless of dtype       */
+} rdfc_conv_desc;
+
+/* OIHW f32 master weights -> MFMA operand layouts in `dtype`, multiplied by `scale`
+ * (EqualLR's sqrt(2/fan_in), model_utils.py:11-16; 1.0 elsewhere):
+ *   w_fwd [O][KH*KW][I]   rows of the forward GEMM          (may be NULL)
+ *   w_bwd [I][KH*KW][O]   rows of the input-gradient GEMM   (may be NULL)            */
+int rdfc_pack_weight(const float *w_oihw, void *w_fwd, void *w_bwd, int O, int I, int KH, int KW,
+                     int dtype, float scale, void *stream);
+/* dw_packed f32 [O][KH*KW][I] -> grad_oihw f32 [O][I][KH][KW] = scale * dw_packed (overwrite) */
+int rdfc_unpack_wgrad(const float *dw_packed, float *grad_oihw, int O, int I, int KH, int KW,
+                      float scale, void *stream);
+
+/* y = act(conv(x, w_fwd) + bias).  bias: f32[Co] or NULL. */
+int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias,
+                        void *y, void *stream);
+/* dx[N,Hi,Wi,Ci] = conv^T(dy[N,Ho,Wo,Co], w_bwd); ld of dy = d->ldy, ld of dx = d->ldx.
+ * Also the forward of ConvTranspose2d (then bias/act apply to the result). */
+int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const float *bias,
+                      void *dx, void *stream);
+/* dw_packed f32 [Co][KH*KW][Ci] += sum_pixels dy (x) x   (caller zeroes dw_packed first). */
+int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Layout / data movement.
+ * ------------------------------------------------------------------------------ */
+/* upstream NCHW f32 tensor -> pixel-major `dtype` (and back, f32 out). */
+int rdfc_nchw_to_pm(const float *src, void *dst, int N, int C, int H, int W, int ld, int dtype, void *stream);
+int rdfc_pm_to_nchw(const void *src, float *dst, int N, int C, int H, int W, int ld, int dtype, void *stream);
+/* dst[p, 0:C] (ld_dst) = src[p', 0:C] (ld_src) for the top-left Hd x Wd window of an Hs x Ws map:
+ * the crop of rdf_generator.py:244-260 and the channel-slice copy of torch.cat. accumulate!=0: dst += src. */
+int rdfc_copy_window(const void *src, void *dst, int N, int Hs, int Ws, int Hd, int Wd, int C,
+                     int ld_src, int ld_dst, int dtype, int accumulate, void *stream);
+/* nn.ReflectionPad2d(pad) forward, and its adjoint (fold the border back). resnet_generator.py:19,50,68,84 */
+int rdfc_reflect_pad(const void *src, void *dst, int N, int H, int W, int C, int pad, int dtype, void *stream);
+int rdfc_reflect_pad_adjoint(const void *dpad, void *dsrc, int N, int H, int W, int C, int pad, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Normalisation (+ residual + activation).  Stands in for nn.BatchNorm2d (train and
+ * eval), nn.InstanceNorm2d and the activation that follows them
+ * (common.py:34-39,52-57; torchvision BasicBlock; resnet_generator.py:21-44;
+ *  conv_norm_act.py:117-125).
+ * groups G = 1 (batch norm: statistics over N*H*W) or N (instance norm).
+ * ------------------------------------------------------------------------------ */
+/* pass 1: per-(group, channel) sum and sum of squares -> partial[G][nchunk][2][C] (f32),
+ * nchunk = rdfc_norm_nchunk(P) where P = pixels per group. */
+int rdfc_norm_nchunk(int pixels_per_group);
+int rdfc_norm_stats(const void *x, float *partial, int G, int P, int C, int ld, int dtype, void *stream);
+/* pass 2: mean[G][C], rstd[G][C] (biased variance, eps); optional running-stat update
+ * (momentum, unbiased variance) when run_mean != NULL. */
+int rdfc_norm_finalize(const float *partial, float *mean, float *rstd, int G, int P, int C, float eps,
+                       float *run_mean, float *run_var, float momentum, void *stream);
+/* z = act(gamma*(x-mean)*rstd + beta + res).  gamma/beta f32[C] or NULL (1/0); res may be NULL.
+ * prelu: device pointer to the slope when act == RDFC_ACT_PRELU. */
+int rdfc_norm_apply(const void *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                    const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype,
+                    int act, float slope, const float *prelu, void *stream);
+/* backward pass 1: u recomputed from (x, stats, res); du = dz*act'(u);
+ * partial[G][nchunk][3][C] = sum du, sum du*xhat, sum dz*min(u,0) (PReLU slope grad). */
+int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                         const float *beta, const void *res, float *partial, int G, int P, int C,
+                         int lddz, int ldx, int ldr, int dtype, int act, float slope, const float *prelu,
+                         void *stream);
+/* sums[G][3][C] from the partials (fixed order => deterministic). */
+int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, void *stream);
+/* backward pass 2: dx = gamma*rstd*(du - S1/P - xhat*S2/P) (training) or gamma*rstd*du (frozen stats);
+ * dres (may be NULL) = du. */
+int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                        const float *beta, const void *res, const float *sums, void *dx, void *dres,
+                        int G, int P, int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype,
+                        int act, float slope, const float *prelu, int frozen_stats, void *stream);
+
+/* W-AdaIN (model_utils.py:72-90): out = gb[:, 0:C] * IN(x) + gb[:, C:2C], gb = per-pixel style affine. */
+int rdfc_adain_apply(const void *x, const float *mean, const float *rstd, const void *gb, void *out,
+                     int N, int P, int C, int ldx, int ldgb, int ldo, int dtype, void *stream);
+int rdfc_adain_bwd_reduce(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb,
+                          float *partial, int N, int P, int C, int lddo, int ldx, int ldgb, int dtype, void *stream);
+int rdfc_adain_bwd_apply(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb,
+                         const float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx,
+                         int ldgb, int lddx, int lddgb, int dtype, void *stream);
+
+/* per-channel sum over all pixels (bias gradient): out[C] = sum_p x[p, c].  partial: [nchunk][C] scratch. */
+int rdfc_channel_sum(const void *x, float *partial, float *out, int P, int C, int ld, int dtype, void *stream);
+
+/* elementwise activation backward for conv epilogues without a norm:
+ * dx = dy * act'(y) given the *output* y (relu / lrelu / tanh / sigmoid). */
+int rdfc_act_bwd(const void *dy, const void *y, void *dx, int P, int C, int lddy, int ldy, int lddx,
+                 int dtype, int y_is_f32, int act, float slope, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Generator output head (rdf_generator.py:400-406): clamp, 2-way softmax of the
+ * confidences, confidence-weighted sum.  All maps 1-channel f32, n elements.
+ * ------------------------------------------------------------------------------ */
+int rdfc_fusion_head(const float *d1, const float *c1, const float *d2_in, const float *c2,
+                     float *d2_clamped, float *pred, int n, void *stream);
+int rdfc_fusion_head_bwd(const float *d1, const float *c1, const float *d2_in, const float *c2,
+                         const float *g_pred, const float *g_d2c, float *g_d1, float *g_c1, float *g_d2, float *g_c2,
+                         int n, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Per-pixel weighted loss reductions (lib/losses/gan_loss.py: L1_loss :6-22,
+ * L2_loss :25-42, mse_loss :104-120 as used by GANLoss :194-206).
+ *   loss = sum_i w_i * |p_i - t_i|^k ,  grad_i = scale * w_i * d|.|^k/dp
+ * pred f32 [N][C][HW] (upstream NCHW), target: tensor or constant, weight: [N][1][HW]
+ * broadcast over C, or uniform 1/(numel + 1e-6).
+ * ------------------------------------------------------------------------------ */
+int rdfc_loss_nchunk(int numel);
+int rdfc_weighted_loss(const float *pred, const float *target, float target_const, const float *weight,
+                       float uniform_w, int N, int C, int HW, int kind /*1=L1, 2=L2*/,
+                       float *partial, float *loss_out, float *grad /* may be NULL */, float grad_scale,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Modulated deformable convolution: the ABI underneath upstream's pybind module
+ * `DCN` (deformconv/src/modulated_deform_conv.h:10-87, vision.cpp:5-12).  NCHW f32/f64
+ * upstream; here f32, contiguous.  Kernels: modulated_deform_im2col_cuda.cuh.
+ * The column buffer of upstream is never materialised.
+ * ------------------------------------------------------------------------------ */
+typedef struct rdfc_mdconv_desc {
+    int32_t B, C, H, W, Co, KH, KW, sh, sw, ph, pw, dh, dw, group, dgroup;
+} rdfc_mdconv_desc;
+int rdfc_mdconv_forward(const rdfc_mdconv_desc *d, const float *input, const float *offset, const float *mask,
+                        const float *weight, const float *bias, float *output, void *stream);
+/* any of the five gradient outputs may be NULL; non-NULL ones are overwritten
+ * (grad_input is zeroed inside and accumulated with atomics like upstream). */
+int rdfc_mdconv_backward(const rdfc_mdconv_desc *d, const float *input, const float *offset, const float *mask,
+                         const float *weight, const float *grad_out, float *grad_input, float *grad_offset,
+                         float *grad_mask, float *grad_weight, float *grad_bias, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Optimizer: torch.optim.Adam semantics (rdfc_gan.py:135-140) over one flat f32 buffer.
+ * ------------------------------------------------------------------------------ */
+int rdfc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                   float lr, float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+
+/* addPepperNoise (helper.py:384-402) given the host-drawn mask (0 keep, 1 -> +1, 2 -> -1), in place. */
+int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, int HW, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDFC_HIP_H */

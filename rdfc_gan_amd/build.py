@@ -1,0 +1,55 @@
+"""Ahead-of-time build of librdfc_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m rdfc_gan_amd.build [--force]
+
+Objects go to rdfc_gan_amd/csrc/build/, the library to rdfc_gan_amd/librdfc_hip.so
+(in-tree so it travels to the GPU box; git-ignored so history stays source-only).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'build')
+LIB = os.path.join(HERE, 'librdfc_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-value',
+         '-Wno-pass-failed']
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hdrs.append(os.path.join(os.path.dirname(HERE), 'include', 'rdfc_hip.h'))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, hdr_mtime, force):
+    obj = os.path.join(OBJ, src[:-4] + '.o')
+    spath = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(spath), hdr_mtime):
+        return obj, False
+    subprocess.check_call([HIPCC] + FLAGS + ['-c', spath, '-o', obj])
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr = _deps_mtime()
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
+        res = list(ex.map(lambda s: _compile(s, hdr, force), _sources()))
+    objs = [o for o, _ in res]
+    if force or any(ch for _, ch in res) or not os.path.exists(LIB):
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+        if verbose:
+            print(f'[rdfc_gan_amd.build] linked {LIB}')
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

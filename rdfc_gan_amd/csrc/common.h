@@ -1,0 +1,111 @@
+// common.h -- shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/rdfc_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- error plumbing -----------------------------------------------------------
+void rdfc_set_error(const char *fmt, ...);
+#define RDFC_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            rdfc_set_error(__VA_ARGS__);   \
+            return 1;                      \
+        }                                  \
+    } while (0)
+#define RDFC_LAUNCH_CHECK(name)                                                   \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            rdfc_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return 2;                                                             \
+        }                                                                         \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- element traits -------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;   // elements per 16-byte access
+    __device__ static float ld(const float *p) { return *p; }
+    __device__ static void st(float *p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ static float ld(const bf16_t *p) { return (float)*p; }
+    __device__ static void st(bf16_t *p, float v) { *p = (bf16_t)v; }
+};
+
+// 16-byte vector of T <-> floats
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    f32x4 v;
+    __device__ void load(const float *p) { v = *reinterpret_cast<const f32x4 *>(p); }
+    __device__ void store(float *p) const { *reinterpret_cast<f32x4 *>(p) = v; }
+    __device__ void zero() { v = f32x4{0, 0, 0, 0}; }
+    __device__ float get(int i) const { return v[i]; }
+    __device__ void set(int i, float f) { v[i] = f; }
+};
+template <> struct Vec16<bf16_t> {
+    bf16x8 v;
+    __device__ void load(const bf16_t *p) { v = *reinterpret_cast<const bf16x8 *>(p); }
+    __device__ void store(bf16_t *p) const { *reinterpret_cast<bf16x8 *>(p) = v; }
+    __device__ void zero() {
+        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.0f;
+    }
+    __device__ float get(int i) const { return (float)v[i]; }
+    __device__ void set(int i, float f) { v[i] = (bf16_t)f; }
+};
+
+// ---- activations ------------------------------------------------------------------
+__device__ inline float act_fwd(float u, int act, float slope) {
+    switch (act) {
+        case RDFC_ACT_RELU: return u > 0.f ? u : 0.f;
+        case RDFC_ACT_LRELU:
+        case RDFC_ACT_PRELU: return u > 0.f ? u : u * slope;
+        case RDFC_ACT_TANH: return tanhf(u);
+        case RDFC_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
+        default: return u;
+    }
+}
+// derivative given the pre-activation u
+__device__ inline float act_grad_pre(float u, int act, float slope) {
+    switch (act) {
+        case RDFC_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case RDFC_ACT_LRELU:
+        case RDFC_ACT_PRELU: return u > 0.f ? 1.f : slope;
+        case RDFC_ACT_TANH: { float t = tanhf(u); return 1.f - t * t; }
+        case RDFC_ACT_SIGMOID: { float s = 1.f / (1.f + expf(-u)); return s * (1.f - s); }
+        default: return 1.f;
+    }
+}
+// derivative given the output y = act(u)
+__device__ inline float act_grad_out(float y, int act, float slope) {
+    switch (act) {
+        case RDFC_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case RDFC_ACT_LRELU:
+        case RDFC_ACT_PRELU: return y > 0.f ? 1.f : slope;
+        case RDFC_ACT_TANH: return 1.f - y * y;
+        case RDFC_ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
+// ---- wave / block reductions ---------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}

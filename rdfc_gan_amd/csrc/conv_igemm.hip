@@ -1,0 +1,365 @@
+// conv_igemm.hip -- implicit-GEMM convolution on MFMA (gfx950), forward and
+// input-gradient ("transposed gather") in one kernel.
+//
+//   D[co][pixel] = sum_k  Wrow[co][k] * Xg[pixel][k],   k = tap * Cin + ci
+//
+// MFMA rows = output channels (A operand = packed weights, k-contiguous rows),
+// MFMA cols = output pixels  (B operand = gathered activations; pixel-major maps
+// make the 8 (bf16) / 1 (f32) k-values a lane needs contiguous in memory).
+// Accumulator lane map (16x16 tile): col = lane&15 (pixel), row = 4*(lane>>4)+r (channel),
+// so every lane owns 4 consecutive output channels of one pixel -> one 8/16-byte store.
+//
+// Transposed mode (conv input-gradient, ConvTranspose2d forward): output pixels are
+// enumerated per stride-parity class (blockIdx.z); within a class the set of taps
+// that hit an integer source position is the same for every pixel, so the k-loop
+// only walks those taps -- no zero-filled MFMA work for stride 2.
+//
+// Staging: global -> registers -> LDS, double buffered (loads for step i+1 are in
+// flight during the MFMAs of step i); LDS rows padded by 16 B against bank conflicts.
+#include "common.h"
+
+namespace {
+
+struct IgemmParams {
+    int N, Hin, Win, Cin, Hout, Wout, Cout;
+    int KH, KW, sh, sw, ph, pw, dh, dw;
+    int ld_in, ld_out;
+    int transposed;
+    int act;
+    float slope;
+    int out_f32;
+    int Krow;   // packed weight row length = KH*KW*Cin
+};
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+constexpr int MAXTAPS = 64;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // one v_mfma_f32_16x16x32_bf16 covers BK
+    template <int MT, int NT>
+    __device__ static void step(const bf16_t *As, const bf16_t *Bs, int ldk, int arow, int brow, int lane,
+                                f32x4 (&acc)[MT][NT]) {
+        bf16x8 a[MT], b[NT];
+        const int r = lane & 15, kq = (lane >> 4) * 8;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(&As[(arow + 16 * i + r) * ldk + kq]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(&Bs[(brow + 16 * j + r) * ldk + kq]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // exact-f32 v_mfma_f32_16x16x4_f32, 8 k-substeps per BK
+    template <int MT, int NT>
+    __device__ static void step(const float *As, const float *Bs, int ldk, int arow, int brow, int lane,
+                                f32x4 (&acc)[MT][NT]) {
+        const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = As[(arow + 16 * i + r) * ldk + 4 * kk + kq];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = Bs[(brow + 16 * j + r) * ldk + 4 * kk + kq];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+template <typename T, int TCO, int TPX, int WCO, bool VECLOAD>
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p, const T *__restrict__ x,
+                                                         const T *__restrict__ w, const float *__restrict__ bias,
+                                                         void *__restrict__ yout) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int CPR = BK / VEC;                 // 16-byte chunks per tile row
+    constexpr int LDK = BK + VEC;                 // padded row (elements)
+    constexpr int WPX = 4 / WCO;
+    constexpr int WTCO = TCO / WCO, WTPX = TPX / WPX;
+    constexpr int MT = WTCO / 16, NT = WTPX / 16;
+    static_assert(MT >= 1 && NT >= 1, "tile");
+    constexpr int NB_V = (TPX * CPR + NTHREADS - 1) / NTHREADS;   // vector loads / thread (pixels)
+    constexpr int NA_V = (TCO * CPR + NTHREADS - 1) / NTHREADS;   // vector loads / thread (weights)
+    constexpr int NB_S = TPX / 8, NA_S = TCO / 8;                 // scalar loads / thread
+
+    __shared__ __attribute__((aligned(16))) T As[2][TCO * LDK];
+    __shared__ __attribute__((aligned(16))) T Bs[2][TPX * LDK];
+    __shared__ int pxn[TPX], pxy[TPX], pxx[TPX], pxo[TPX];
+    __shared__ int tap_w[MAXTAPS], tap_dy[MAXTAPS], tap_dx[MAXTAPS];
+    __shared__ int ntaps_s;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.y * TCO;
+
+    // ---- pixel enumeration ------------------------------------------------------------
+    int cy = 0, cx = 0, Ha = p.Hout, Wb = p.Wout;
+    if (p.transposed) {
+        cy = blockIdx.z / p.sw;
+        cx = blockIdx.z % p.sw;
+        Ha = cy < p.Hout ? (p.Hout - cy + p.sh - 1) / p.sh : 0;
+        Wb = cx < p.Wout ? (p.Wout - cx + p.sw - 1) / p.sw : 0;
+    }
+    const int Pc = p.N * Ha * Wb;
+    const int m0 = blockIdx.x * TPX;
+    if (m0 >= Pc) return;
+
+    for (int t = tid; t < TPX; t += NTHREADS) {
+        const int m = m0 + t;
+        int nb = -1, yy = 0, xx = 0, po = -1;
+        if (m < Pc) {
+            const int n = m / (Ha * Wb), r = m - n * (Ha * Wb);
+            const int a = r / Wb, b = r - a * Wb;
+            nb = n * p.Hin * p.Win;
+            if (!p.transposed) {
+                yy = a * p.sh - p.ph;
+                xx = b * p.sw - p.pw;
+                po = m;
+            } else {
+                const int oy = cy + a * p.sh, ox = cx + b * p.sw;
+                yy = (oy + p.ph) / p.sh;          // source row = yy + tap_dy (exact for the class's taps)
+                xx = (ox + p.pw) / p.sw;
+                po = (n * p.Hout + oy) * p.Wout + ox;
+            }
+        }
+        pxn[t] = nb; pxy[t] = yy; pxx[t] = xx; pxo[t] = po;
+    }
+    if (tid == 0) {
+        int nt = 0;
+        const int ry = p.transposed ? (cy + p.ph) % p.sh : 0, rx = p.transposed ? (cx + p.pw) % p.sw : 0;
+        for (int kh = 0; kh < p.KH; ++kh)
+            for (int kw = 0; kw < p.KW; ++kw) {
+                if (!p.transposed) {
+                    tap_w[nt] = kh * p.KW + kw; tap_dy[nt] = kh * p.dh; tap_dx[nt] = kw * p.dw; ++nt;
+                } else {
+                    const int ey = ry - kh * p.dh, ex = rx - kw * p.dw;     // must be multiples of the stride
+                    if (ey % p.sh == 0 && ex % p.sw == 0) {
+                        tap_w[nt] = kh * p.KW + kw; tap_dy[nt] = ey / p.sh; tap_dx[nt] = ex / p.sw; ++nt;
+                    }
+                }
+            }
+        ntaps_s = nt;
+    }
+    __syncthreads();
+    const int ntaps = ntaps_s;
+    const int cch = p.Cin / BK;
+    const int Keff = ntaps * p.Cin;
+    const int nit = VECLOAD ? ntaps * cch : (Keff + BK - 1) / BK;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    // ---- staging registers ---------------------------------------------------------------
+    Vec16<T> rb[VECLOAD ? NB_V : 1], ra[VECLOAD ? NA_V : 1];
+    T sb[VECLOAD ? 1 : NB_S], sa[VECLOAD ? 1 : NA_S];
+
+    auto load_regs = [&](int it) {
+        if constexpr (VECLOAD) {
+            const int ti = it / cch, c0 = (it - ti * cch) * BK;
+            const int tw = tap_w[ti], dy = tap_dy[ti], dx = tap_dx[ti];
+#pragma unroll
+            for (int j = 0; j < NB_V; ++j) {
+                const int e = tid + j * NTHREADS;
+                const int row = e / CPR, ch = e % CPR;
+                rb[j].zero();
+                if (row < TPX) {
+                    const int nb = pxn[row], iy = pxy[row] + dy, ix = pxx[row] + dx;
+                    if (nb >= 0 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
+                        rb[j].load(x + (size_t)(nb + iy * p.Win + ix) * p.ld_in + c0 + ch * VEC);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NA_V; ++j) {
+                const int e = tid + j * NTHREADS;
+                const int row = e / CPR, ch = e % CPR;
+                ra[j].zero();
+                if (row < TCO && co0 + row < p.Cout)
+                    ra[j].load(w + (size_t)(co0 + row) * p.Krow + tw * p.Cin + c0 + ch * VEC);
+            }
+        } else {
+            const int kk = tid & 31, r0 = tid >> 5;
+            const int kg = it * BK + kk;
+            const bool kok = kg < Keff;
+            int tw = 0, dy = 0, dx = 0, ci = 0;
+            if (kok) {
+                const int ti = kg / p.Cin;
+                ci = kg - ti * p.Cin;
+                tw = tap_w[ti]; dy = tap_dy[ti]; dx = tap_dx[ti];
+            }
+#pragma unroll
+            for (int j = 0; j < NB_S; ++j) {
+                const int row = r0 + 8 * j;
+                T v = (T)0.0f;
+                const int nb = pxn[row], iy = pxy[row] + dy, ix = pxx[row] + dx;
+                if (kok && nb >= 0 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
+                    v = x[(size_t)(nb + iy * p.Win + ix) * p.ld_in + ci];
+                sb[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NA_S; ++j) {
+                const int row = r0 + 8 * j;
+                T v = (T)0.0f;
+                if (kok && co0 + row < p.Cout) v = w[(size_t)(co0 + row) * p.Krow + tw * p.Cin + ci];
+                sa[j] = v;
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        if constexpr (VECLOAD) {
+#pragma unroll
+            for (int j = 0; j < NB_V; ++j) {
+                const int e = tid + j * NTHREADS;
+                const int row = e / CPR, ch = e % CPR;
+                if (row < TPX) rb[j].store(&Bs[buf][row * LDK + ch * VEC]);
+            }
+#pragma unroll
+            for (int j = 0; j < NA_V; ++j) {
+                const int e = tid + j * NTHREADS;
+                const int row = e / CPR, ch = e % CPR;
+                if (row < TCO) ra[j].store(&As[buf][row * LDK + ch * VEC]);
+            }
+        } else {
+            const int kk = tid & 31, r0 = tid >> 5;
+#pragma unroll
+            for (int j = 0; j < NB_S; ++j) Bs[buf][(r0 + 8 * j) * LDK + kk] = sb[j];
+#pragma unroll
+            for (int j = 0; j < NA_S; ++j) As[buf][(r0 + 8 * j) * LDK + kk] = sa[j];
+        }
+    };
+
+    const int wr = wave / WPX, wc = wave % WPX;
+    if (nit > 0) {
+        load_regs(0);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nit) load_regs(it + 1);
+        Mma<T>::template step<MT, NT>(As[buf], Bs[buf], LDK, wr * WTCO, wc * WTPX, lane, acc);
+        if (it + 1 < nit) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + activation + store (4 consecutive channels per lane) -----------------
+    const int q4 = (lane >> 4) * 4, pr = lane & 15;
+    const bool vec_ok = (p.ld_out & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int po = pxo[wc * WTPX + 16 * j + pr];
+        if (po < 0) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int co = co0 + wr * WTCO + 16 * i + q4;
+            if (co >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = acc[i][j][r];
+                if (bias != nullptr && co + r < p.Cout) u += bias[co + r];
+                v[r] = act_fwd(u, p.act, p.slope);
+            }
+            const size_t off = (size_t)po * p.ld_out + co;
+            if (p.out_f32 || sizeof(T) == 4) {
+                float *y = reinterpret_cast<float *>(yout) + off;
+                if (vec_ok && co + 3 < p.Cout) {
+                    *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.Cout) y[r] = v[r];
+                }
+            } else {
+                bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
+                if (vec_ok && co + 3 < p.Cout) {
+                    bf16x4 o;
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x4 *>(y) = o;
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int TCO, int TPX, int WCO>
+int launch_cfg(const IgemmParams &p, const void *x, const void *w, const float *bias, void *y, hipStream_t st) {
+    int Pmax, nz = 1;
+    if (!p.transposed) {
+        Pmax = p.N * p.Hout * p.Wout;
+    } else {
+        nz = p.sh * p.sw;
+        Pmax = p.N * ((p.Hout + p.sh - 1) / p.sh) * ((p.Wout + p.sw - 1) / p.sw);
+    }
+    dim3 grid(cdiv(Pmax, TPX), cdiv(p.Cout, TCO), nz);
+    if (p.Cin % BK == 0)
+        hipLaunchKernelGGL((igemm_kernel<T, TCO, TPX, WCO, true>), grid, dim3(NTHREADS), 0, st, p, (const T *)x,
+                           (const T *)w, bias, y);
+    else
+        hipLaunchKernelGGL((igemm_kernel<T, TCO, TPX, WCO, false>), grid, dim3(NTHREADS), 0, st, p, (const T *)x,
+                           (const T *)w, bias, y);
+    return 0;
+}
+
+template <typename T>
+int launch_T(const IgemmParams &p, const void *x, const void *w, const float *bias, void *y, hipStream_t st) {
+    if (p.Cout > 64) return launch_cfg<T, 128, 128, 2>(p, x, w, bias, y, st);
+    if (p.Cout > 32) return launch_cfg<T, 64, 256, 1>(p, x, w, bias, y, st);
+    if (p.Cout > 16) return launch_cfg<T, 32, 256, 1>(p, x, w, bias, y, st);
+    return launch_cfg<T, 16, 256, 1>(p, x, w, bias, y, st);
+}
+
+int check_desc(const rdfc_conv_desc *d, const char *who) {
+    RDFC_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    RDFC_REQUIRE(d->dtype == RDFC_F32 || d->dtype == RDFC_BF16, "%s: bad dtype %d", who, d->dtype);
+    RDFC_REQUIRE(d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->Ci > 0 && d->Ho > 0 && d->Wo > 0 && d->Co > 0,
+                 "%s: non-positive dimension", who);
+    RDFC_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= MAXTAPS, "%s: kernel %dx%d unsupported (max %d taps)", who,
+                 d->KH, d->KW, MAXTAPS);
+    RDFC_REQUIRE(d->sh > 0 && d->sw > 0 && d->dh > 0 && d->dw > 0 && d->ph >= 0 && d->pw >= 0, "%s: bad stride/pad/dilation", who);
+    RDFC_REQUIRE(d->ldx >= d->Ci && d->ldy >= d->Co, "%s: ld smaller than channel count", who);
+    const int vec = d->dtype == RDFC_BF16 ? 8 : 4;
+    RDFC_REQUIRE(d->Ci % BK != 0 || d->ldx % vec == 0, "%s: ldx=%d must be a multiple of %d for vector loads", who, d->ldx, vec);
+    RDFC_REQUIRE(d->Co % BK != 0 || d->ldy % vec == 0, "%s: ldy=%d must be a multiple of %d for vector loads", who, d->ldy, vec);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias,
+                                   void *y, void *stream) {
+    if (int e = check_desc(d, "rdfc_conv2d_forward")) return e;
+    const int ho = (d->Hi + 2 * d->ph - (d->dh * (d->KH - 1) + 1)) / d->sh + 1;
+    const int wo = (d->Wi + 2 * d->pw - (d->dw * (d->KW - 1) + 1)) / d->sw + 1;
+    RDFC_REQUIRE(ho == d->Ho && wo == d->Wo, "rdfc_conv2d_forward: output %dx%d does not match geometry (%dx%d)", d->Ho, d->Wo, ho, wo);
+    IgemmParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
+                  d->ldx, d->ldy, 0, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Ci};
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, w_fwd, bias, y, st);
+    else launch_T<float>(p, x, w_fwd, bias, y, st);
+    RDFC_LAUNCH_CHECK("rdfc_conv2d_forward");
+    return 0;
+}
+
+extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const float *bias,
+                                 void *dx, void *stream) {
+    if (int e = check_desc(d, "rdfc_conv2d_dgrad")) return e;
+    // gather from dy[N,Ho,Wo,Co] (ld = ldy), produce dx[N,Hi,Wi,Ci] (ld = ldx)
+    IgemmParams p{d->N, d->Ho, d->Wo, d->Co, d->Hi, d->Wi, d->Ci, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
+                  d->ldy, d->ldx, 1, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Co};
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, dy, w_bwd, bias, dx, st);
+    else launch_T<float>(p, dy, w_bwd, bias, dx, st);
+    RDFC_LAUNCH_CHECK("rdfc_conv2d_dgrad");
+    return 0;
+}

@@ -1,0 +1,212 @@
+// mdconv.hip -- modulated deformable convolution (DCNv2) forward / backward, the op
+// underneath upstream's `DCN` module (deformconv/src/cuda/modulated_deform_im2col_cuda.cuh,
+// modulated_deform_conv_cuda.cu).  NCHW f32.
+//
+// Upstream materialises a [C*K, B*Ho*Wo] column buffer (im2col), runs a K=9 GEMM on it
+// and permutes the result.  Here the gather, the mask multiply and the tap sum are one
+// kernel: one thread per output pixel, offsets/masks read coalesced along W, nothing
+// written but the output.  HBM-bound: per pixel and tap 2 offsets + 1 mask in, plus the
+// input and output maps once.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+typedef rdfc_mdconv_desc D;
+
+__device__ inline int odim(int in, int pad, int dil, int k, int stride) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
+
+struct Corner {
+    int h0, w0;
+    float lh, lw;
+    bool v00, v01, v10, v11;
+};
+__device__ inline Corner corners(float h, float w, int H, int W) {
+    Corner c;
+    c.h0 = (int)floorf(h);
+    c.w0 = (int)floorf(w);
+    c.lh = h - c.h0;
+    c.lw = w - c.w0;
+    const bool hl = c.h0 >= 0, hh = c.h0 + 1 <= H - 1, wl = c.w0 >= 0, wh = c.w0 + 1 <= W - 1;
+    c.v00 = hl && wl; c.v01 = hl && wh; c.v10 = hh && wl; c.v11 = hh && wh;
+    return c;
+}
+__device__ inline float bilinear(const float *im, int W, const Corner &c) {
+    const float a = c.v00 ? im[c.h0 * W + c.w0] : 0.f, b = c.v01 ? im[c.h0 * W + c.w0 + 1] : 0.f;
+    const float d = c.v10 ? im[(c.h0 + 1) * W + c.w0] : 0.f, e = c.v11 ? im[(c.h0 + 1) * W + c.w0 + 1] : 0.f;
+    const float hh = 1.f - c.lh, hw = 1.f - c.lw;
+    return hh * hw * a + hh * c.lw * b + c.lh * hw * d + c.lh * c.lw * e;
+}
+
+__global__ __launch_bounds__(NT) void fwd_kernel(D s, int Ho, int Wo, const float *__restrict__ in, const float *__restrict__ off,
+                                                 const float *__restrict__ msk, const float *__restrict__ wt,
+                                                 const float *__restrict__ bias, float *__restrict__ out) {
+    const int K = s.KH * s.KW, Cg = s.C / s.group, Cog = s.Co / s.group, Cdg = s.C / s.dgroup;
+    const size_t HWo = (size_t)Ho * Wo, total = (size_t)s.B * s.Co * HWo;
+    for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
+        const int w = (int)(idx % Wo), h = (int)((idx / Wo) % Ho);
+        const int co = (int)((idx / HWo) % s.Co), b = (int)(idx / (HWo * s.Co));
+        const int g = co / Cog;
+        const size_t p = (size_t)h * Wo + w;
+        float acc = bias ? bias[co] : 0.f;
+        for (int cl = 0; cl < Cg; ++cl) {
+            const int c = g * Cg + cl, dgi = c / Cdg;
+            const float *im = in + ((size_t)b * s.C + c) * s.H * s.W;
+            const float *o = off + ((size_t)b * s.dgroup + dgi) * 2 * K * HWo + p;
+            const float *m = msk + ((size_t)b * s.dgroup + dgi) * K * HWo + p;
+            const float *wp = wt + ((size_t)co * Cg + cl) * K;
+            for (int i = 0; i < s.KH; ++i)
+                for (int j = 0; j < s.KW; ++j) {
+                    const int k = i * s.KW + j;
+                    const float hi = h * s.sh - s.ph + i * s.dh + o[(size_t)(2 * k) * HWo];
+                    const float wi = w * s.sw - s.pw + j * s.dw + o[(size_t)(2 * k + 1) * HWo];
+                    if (hi > -1.f && wi > -1.f && hi < s.H && wi < s.W)
+                        acc += wp[k] * m[(size_t)k * HWo] * bilinear(im, s.W, corners(hi, wi, s.H, s.W));
+                }
+        }
+        out[idx] = acc;
+    }
+}
+
+// grad_offset / grad_mask (gather, deterministic) and grad_input (scatter, atomics):
+// one thread per (b, deformable group, tap, h, w).
+__global__ __launch_bounds__(NT) void bwd_kernel(D s, int Ho, int Wo, const float *__restrict__ in, const float *__restrict__ off,
+                                                 const float *__restrict__ msk, const float *__restrict__ wt,
+                                                 const float *__restrict__ go, float *__restrict__ gin, float *__restrict__ goff,
+                                                 float *__restrict__ gmsk) {
+    const int K = s.KH * s.KW, Cg = s.C / s.group, Cog = s.Co / s.group, Cdg = s.C / s.dgroup;
+    const size_t HWo = (size_t)Ho * Wo, total = (size_t)s.B * s.dgroup * K * HWo;
+    for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
+        const int w = (int)(idx % Wo), h = (int)((idx / Wo) % Ho);
+        const int k = (int)((idx / HWo) % K), dgi = (int)((idx / (HWo * K)) % s.dgroup), b = (int)(idx / (HWo * K * s.dgroup));
+        const int i = k / s.KW, j = k % s.KW;
+        const size_t p = (size_t)h * Wo + w;
+        const size_t ob = ((size_t)b * s.dgroup + dgi) * 2 * K * HWo + p, mb = ((size_t)b * s.dgroup + dgi) * K * HWo + p;
+        const float m = msk[mb + (size_t)k * HWo];
+        const float hi = h * s.sh - s.ph + i * s.dh + off[ob + (size_t)(2 * k) * HWo];
+        const float wi = w * s.sw - s.pw + j * s.dw + off[ob + (size_t)(2 * k + 1) * HWo];
+        const bool inside = !(hi <= -1.f || wi <= -1.f || hi >= s.H || wi >= s.W);
+        float g_oh = 0.f, g_ow = 0.f, g_m = 0.f;
+        if (inside) {
+            const Corner c = corners(hi, wi, s.H, s.W);
+            const float hh = 1.f - c.lh, hw = 1.f - c.lw;
+            for (int cd = 0; cd < Cdg; ++cd) {
+                const int ch = dgi * Cdg + cd, g = ch / Cg, cl = ch % Cg;
+                float cg = 0.f;   // column gradient = W^T * grad_out
+                for (int q = 0; q < Cog; ++q) {
+                    const int co = g * Cog + q;
+                    cg += wt[((size_t)co * Cg + cl) * K + k] * go[((size_t)b * s.Co + co) * HWo + p];
+                }
+                const float *im = in + ((size_t)b * s.C + ch) * s.H * s.W;
+                const float a = c.v00 ? im[c.h0 * s.W + c.w0] : 0.f, bb = c.v01 ? im[c.h0 * s.W + c.w0 + 1] : 0.f;
+                const float d = c.v10 ? im[(c.h0 + 1) * s.W + c.w0] : 0.f, e = c.v11 ? im[(c.h0 + 1) * s.W + c.w0 + 1] : 0.f;
+                g_m += cg * (hh * hw * a + hh * c.lw * bb + c.lh * hw * d + c.lh * c.lw * e);
+                g_oh += cg * m * (-hw * a - c.lw * bb + hw * d + c.lw * e);
+                g_ow += cg * m * (-hh * a + hh * bb - c.lh * d + c.lh * e);
+                if (gin) {
+                    float *gi = gin + ((size_t)b * s.C + ch) * s.H * s.W;
+                    const float t = cg * m;
+                    if (c.v00) atomicAdd(gi + c.h0 * s.W + c.w0, hh * hw * t);
+                    if (c.v01) atomicAdd(gi + c.h0 * s.W + c.w0 + 1, hh * c.lw * t);
+                    if (c.v10) atomicAdd(gi + (c.h0 + 1) * s.W + c.w0, c.lh * hw * t);
+                    if (c.v11) atomicAdd(gi + (c.h0 + 1) * s.W + c.w0 + 1, c.lh * c.lw * t);
+                }
+            }
+        }
+        if (goff) {
+            goff[ob + (size_t)(2 * k) * HWo] = g_oh;
+            goff[ob + (size_t)(2 * k + 1) * HWo] = g_ow;
+        }
+        if (gmsk) gmsk[mb + (size_t)k * HWo] = g_m;
+    }
+}
+
+// grad_weight[co][cl][k] (block per element) and grad_bias[co] (extra blocks), block reduction over pixels
+__global__ __launch_bounds__(NT) void wgrad_kernel(D s, int Ho, int Wo, const float *__restrict__ in, const float *__restrict__ off,
+                                                   const float *__restrict__ msk, const float *__restrict__ go,
+                                                   float *__restrict__ gw, float *__restrict__ gb) {
+    const int K = s.KH * s.KW, Cg = s.C / s.group, Cog = s.Co / s.group, Cdg = s.C / s.dgroup;
+    const size_t HWo = (size_t)Ho * Wo, npix = (size_t)s.B * HWo;
+    const int nW = s.Co * Cg * K;
+    const int e = blockIdx.x;
+    float acc = 0.f;
+    if (e < nW) {
+        const int k = e % K, cl = (e / K) % Cg, co = e / (K * Cg);
+        const int i = k / s.KW, j = k % s.KW, g = co / Cog, c = g * Cg + cl, dgi = c / Cdg;
+        for (size_t q = threadIdx.x; q < npix; q += NT) {
+            const int b = (int)(q / HWo);
+            const size_t p = q % HWo;
+            const int h = (int)(p / Wo), w = (int)(p % Wo);
+            const size_t ob = ((size_t)b * s.dgroup + dgi) * 2 * K * HWo + p, mb = ((size_t)b * s.dgroup + dgi) * K * HWo + p;
+            const float hi = h * s.sh - s.ph + i * s.dh + off[ob + (size_t)(2 * k) * HWo];
+            const float wi = w * s.sw - s.pw + j * s.dw + off[ob + (size_t)(2 * k + 1) * HWo];
+            if (hi > -1.f && wi > -1.f && hi < s.H && wi < s.W)
+                acc += go[((size_t)b * s.Co + co) * HWo + p] * msk[mb + (size_t)k * HWo] *
+                       bilinear(in + ((size_t)b * s.C + c) * s.H * s.W, s.W, corners(hi, wi, s.H, s.W));
+        }
+    } else {
+        const int co = e - nW;
+        for (size_t q = threadIdx.x; q < npix; q += NT) acc += go[((size_t)(q / HWo) * s.Co + co) * HWo + q % HWo];
+    }
+    acc = wave_sum(acc);
+    __shared__ float red[NT / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        if (e < nW) { if (gw) gw[e] = t; }
+        else if (gb) gb[e - nW] = t;
+    }
+}
+
+int check(const D *d, const char *who) {
+    RDFC_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    RDFC_REQUIRE(d->B > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->Co > 0 && d->KH > 0 && d->KW > 0, "%s: non-positive size", who);
+    RDFC_REQUIRE(d->group > 0 && d->dgroup > 0 && d->C % d->group == 0 && d->Co % d->group == 0,
+                 "%s: channels(%d) and channels_out(%d) must divide group(%d)", who, d->C, d->Co, d->group);   // cu:62
+    RDFC_REQUIRE(d->C % d->dgroup == 0, "%s: channels(%d) must divide deformable_group(%d)", who, d->C, d->dgroup);
+    RDFC_REQUIRE(d->sh > 0 && d->sw > 0 && d->dh > 0 && d->dw > 0, "%s: bad stride / dilation", who);
+    return 0;
+}
+inline int host_odim(int in, int pad, int dil, int k, int stride) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
+
+}  // namespace
+
+extern "C" int rdfc_mdconv_forward(const rdfc_mdconv_desc *d, const float *input, const float *offset, const float *mask,
+                                   const float *weight, const float *bias, float *output, void *stream) {
+    if (int e = check(d, "rdfc_mdconv_forward")) return e;
+    const int Ho = host_odim(d->H, d->ph, d->dh, d->KH, d->sh), Wo = host_odim(d->W, d->pw, d->dw, d->KW, d->sw);
+    RDFC_REQUIRE(Ho > 0 && Wo > 0, "rdfc_mdconv_forward: empty output");
+    const size_t total = (size_t)d->B * d->Co * Ho * Wo;
+    const int nb = (int)min((size_t)8192, (total + NT - 1) / NT);
+    hipLaunchKernelGGL(fwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, *d, Ho, Wo, input, offset, mask, weight, bias, output);
+    RDFC_LAUNCH_CHECK("rdfc_mdconv_forward");
+    return 0;
+}
+
+extern "C" int rdfc_mdconv_backward(const rdfc_mdconv_desc *d, const float *input, const float *offset, const float *mask,
+                                    const float *weight, const float *grad_out, float *grad_input, float *grad_offset,
+                                    float *grad_mask, float *grad_weight, float *grad_bias, void *stream) {
+    if (int e = check(d, "rdfc_mdconv_backward")) return e;
+    const int Ho = host_odim(d->H, d->ph, d->dh, d->KH, d->sh), Wo = host_odim(d->W, d->pw, d->dw, d->KW, d->sw);
+    RDFC_REQUIRE(Ho > 0 && Wo > 0, "rdfc_mdconv_backward: empty output");
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_input) {
+        if (hipMemsetAsync(grad_input, 0, sizeof(float) * d->B * d->C * d->H * d->W, st) != hipSuccess) {
+            rdfc_set_error("rdfc_mdconv_backward: memset failed");
+            return 2;
+        }
+    }
+    if (grad_input || grad_offset || grad_mask) {
+        const size_t total = (size_t)d->B * d->dgroup * d->KH * d->KW * Ho * Wo;
+        const int nb = (int)min((size_t)8192, (total + NT - 1) / NT);
+        hipLaunchKernelGGL(bwd_kernel, dim3(nb), dim3(NT), 0, st, *d, Ho, Wo, input, offset, mask, weight, grad_out, grad_input,
+                           grad_offset, grad_mask);
+    }
+    if (grad_weight || grad_bias) {
+        const int nW = d->Co * (d->C / d->group) * d->KH * d->KW;
+        hipLaunchKernelGGL(wgrad_kernel, dim3(nW + d->Co), dim3(NT), 0, st, *d, Ho, Wo, input, offset, mask, grad_out, grad_weight, grad_bias);
+    }
+    RDFC_LAUNCH_CHECK("rdfc_mdconv_backward");
+    return 0;
+}

@@ -1,0 +1,521 @@
+// norm.hip -- HBM-bound per-channel kernels on pixel-major maps [G][P][C] (ld):
+// BatchNorm / InstanceNorm statistics, normalise (+residual +activation), their
+// backward, W-AdaIN, per-channel sums.
+//
+// Thread mapping (all kernels): a thread owns one 16-byte channel vector (cv) and
+// walks pixels with stride RPB = 256 / CVT, so per-channel constants live in
+// registers and every access is a full 16-byte coalesced load/store.
+// grid = (pixel chunks, groups, channel slabs of 256 vectors).
+// Reductions are two-stage (per-chunk partials, then a fixed-order finalize in f64):
+// deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int CHUNK = 2048;   // pixels per block
+
+struct Map {       // geometry shared by the kernels
+    int G, P, C;   // groups, pixels per group, channels
+};
+
+template <typename T>
+struct Ctx {
+    static constexpr int VEC = Elem<T>::VEC;
+    int cv, r0, RPB, c0, p_begin, p_end, g, chunk, nchunk;
+    bool active;
+    __device__ Ctx(const Map &m) {
+        const int CV = m.C / VEC;
+        const int slab0 = blockIdx.z * NT;
+        const int CVT = min(CV - slab0, NT);
+        RPB = NT / CVT;
+        const int t = threadIdx.x;
+        active = t < RPB * CVT;
+        cv = slab0 + t % CVT;
+        r0 = t / CVT;
+        c0 = cv * VEC;
+        g = blockIdx.y;
+        chunk = blockIdx.x;
+        nchunk = gridDim.x;
+        p_begin = chunk * CHUNK;
+        p_end = min(p_begin + CHUNK, m.P);
+    }
+};
+
+inline dim3 grid_for(const Map &m, int vec) {
+    return dim3(cdiv(m.P, CHUNK), m.G, cdiv(m.C / vec, NT));
+}
+
+// block-level reduction of K*VEC per-thread sums over the RPB rows, then write partial[g][chunk][k][c]
+template <typename T, int K>
+__device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K][Elem<T>::VEC], float *partial) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float red[K * NT * VEC];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[(k * NT + t) * VEC + v] = cx.active ? s[k][v] : 0.f;
+    __syncthreads();
+    if (cx.active && cx.r0 == 0) {
+        const int CVT = NT / cx.RPB >= 1 ? (NT / cx.RPB) : 1;
+        (void)CVT;
+        const int cvt = t;   // r0 == 0 -> t == cv - slab0
+        const int stride = min(m.C / VEC - (int)blockIdx.z * NT, NT);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float a = 0.f;
+                for (int r = 0; r < cx.RPB; ++r) a += red[(k * NT + r * stride + cvt) * VEC + v];
+                partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + cx.c0 + v] = a;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ x, int ld, float *__restrict__ partial) {
+    constexpr int VEC = Elem<T>::VEC;
+    Ctx<T> cx(m);
+    float s[2][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[0][v] = s[1][v] = 0.f;
+    if (cx.active) {
+        const T *base = x + (size_t)cx.g * m.P * ld + cx.c0;
+        for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+            Vec16<T> a;
+            a.load(base + (size_t)p * ld);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float f = a.get(v);
+                s[0][v] += f;
+                s[1][v] += f * f;
+            }
+        }
+    }
+    block_reduce_store<T, 2>(cx, m, s, partial);
+}
+
+__global__ void stats_finalize_kernel(Map m, int nchunk, const float *__restrict__ partial, float *__restrict__ mean,
+                                      float *__restrict__ rstd, float eps, float *run_mean, float *run_var, float momentum) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m.G * m.C) return;
+    const int g = i / m.C, c = i % m.C;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < nchunk; ++k) {
+        s1 += partial[(((size_t)g * nchunk + k) * 2 + 0) * m.C + c];
+        s2 += partial[(((size_t)g * nchunk + k) * 2 + 1) * m.C + c];
+    }
+    const double mu = s1 / m.P;
+    double var = s2 / m.P - mu * mu;
+    if (var < 0) var = 0;
+    mean[i] = (float)mu;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean != nullptr && g == 0) {   // batch norm (G == 1): nn.BatchNorm2d running statistics
+        const double unb = m.P > 1 ? var * m.P / (m.P - 1) : var;
+        run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+    }
+}
+
+struct ApplyArgs {
+    const float *mean, *rstd, *gamma, *beta, *prelu;
+    int act;
+    float slope;
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *__restrict__ x, const T *__restrict__ res,
+                                                   T *__restrict__ z, int ldx, int ldr, int ldz) {
+    constexpr int VEC = Elem<T>::VEC;
+    Ctx<T> cx(m);
+    if (!cx.active) return;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const int c = cx.c0 + v;
+        const float ga = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
+        const float r = a.rstd[cx.g * m.C + c], mu = a.mean[cx.g * m.C + c];
+        sc[v] = ga * r;
+        sh[v] = be - mu * ga * r;
+    }
+    const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
+    const size_t gb = (size_t)cx.g * m.P;
+    for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+        Vec16<T> xv, rv, o;
+        xv.load(x + (gb + p) * ldx + cx.c0);
+        if (res) rv.load(res + (gb + p) * ldr + cx.c0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float u = sc[v] * xv.get(v) + sh[v];
+            if (res) u += rv.get(v);
+            o.set(v, act_fwd(u, a.act, slope));
+        }
+        o.store(z + (gb + p) * ldz + cx.c0);
+    }
+}
+
+// backward pass 1: sums of du, du*xhat, dz*min(u,0)
+template <typename T>
+__global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
+                                                        const T *__restrict__ res, float *__restrict__ partial, int lddz,
+                                                        int ldx, int ldr) {
+    constexpr int VEC = Elem<T>::VEC;
+    Ctx<T> cx(m);
+    float s[3][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[0][v] = s[1][v] = s[2][v] = 0.f;
+    if (cx.active) {
+        float ga[VEC], be[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int c = cx.c0 + v;
+            ga[v] = a.gamma ? a.gamma[c] : 1.f;
+            be[v] = a.beta ? a.beta[c] : 0.f;
+            rs[v] = a.rstd[cx.g * m.C + c];
+            mu[v] = a.mean[cx.g * m.C + c];
+        }
+        const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
+        const size_t gb = (size_t)cx.g * m.P;
+        for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+            Vec16<T> dv, xv, rv;
+            dv.load(dz + (gb + p) * lddz + cx.c0);
+            xv.load(x + (gb + p) * ldx + cx.c0);
+            if (res) rv.load(res + (gb + p) * ldr + cx.c0);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float xh = (xv.get(v) - mu[v]) * rs[v];
+                float u = ga[v] * xh + be[v];
+                if (res) u += rv.get(v);
+                const float d = dv.get(v);
+                const float du = d * act_grad_pre(u, a.act, slope);
+                s[0][v] += du;
+                s[1][v] += du * xh;
+                s[2][v] += d * fminf(u, 0.f);
+            }
+        }
+    }
+    block_reduce_store<T, 3>(cx, m, s, partial);
+}
+
+__global__ void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial, float *__restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over G*K*C
+    if (i >= G * K * C) return;
+    const int g = i / (K * C), k = (i / C) % K, c = i % C;
+    double s = 0;
+    for (int j = 0; j < nchunk; ++j) s += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
+    sums[i] = (float)s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
+                                                       const T *__restrict__ res, const float *__restrict__ sums,
+                                                       T *__restrict__ dx, T *__restrict__ dres, int lddz, int ldx, int ldr,
+                                                       int lddx, int lddr, int frozen) {
+    constexpr int VEC = Elem<T>::VEC;
+    Ctx<T> cx(m);
+    if (!cx.active) return;
+    float ga[VEC], be[VEC], mu[VEC], rs[VEC], m1[VEC], m2[VEC];
+    const float invP = 1.f / (float)m.P;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const int c = cx.c0 + v;
+        ga[v] = a.gamma ? a.gamma[c] : 1.f;
+        be[v] = a.beta ? a.beta[c] : 0.f;
+        rs[v] = a.rstd[cx.g * m.C + c];
+        mu[v] = a.mean[cx.g * m.C + c];
+        m1[v] = frozen ? 0.f : sums[(cx.g * 3 + 0) * m.C + c] * invP;
+        m2[v] = frozen ? 0.f : sums[(cx.g * 3 + 1) * m.C + c] * invP;
+    }
+    const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
+    const size_t gb = (size_t)cx.g * m.P;
+    for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+        Vec16<T> dv, xv, rv, o, orr;
+        dv.load(dz + (gb + p) * lddz + cx.c0);
+        xv.load(x + (gb + p) * ldx + cx.c0);
+        if (res) rv.load(res + (gb + p) * ldr + cx.c0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float xh = (xv.get(v) - mu[v]) * rs[v];
+            float u = ga[v] * xh + be[v];
+            if (res) u += rv.get(v);
+            const float du = dv.get(v) * act_grad_pre(u, a.act, slope);
+            o.set(v, ga[v] * rs[v] * (du - m1[v] - xh * m2[v]));
+            orr.set(v, du);
+        }
+        o.store(dx + (gb + p) * lddx + cx.c0);
+        if (dres) orr.store(dres + (gb + p) * lddr + cx.c0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// W-AdaIN: out = gamma_p * xhat + beta_p, (gamma_p | beta_p) = gb[p][0:C | C:2C]
+template <typename T>
+__global__ __launch_bounds__(NT) void adain_apply_kernel(Map m, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                         const T *__restrict__ x, const T *__restrict__ gbm, T *__restrict__ out,
+                                                         int ldx, int ldgb, int ldo) {
+    constexpr int VEC = Elem<T>::VEC;
+    Ctx<T> cx(m);
+    if (!cx.active) return;
+    float mu[VEC], rs[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        mu[v] = mean[cx.g * m.C + cx.c0 + v];
+        rs[v] = rstd[cx.g * m.C + cx.c0 + v];
+    }
+    const size_t gb = (size_t)cx.g * m.P;
+    for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+        Vec16<T> xv, gv, bv, o;
+        xv.load(x + (gb + p) * ldx + cx.c0);
+        gv.load(gbm + (gb + p) * ldgb + cx.c0);
+        bv.load(gbm + (gb + p) * ldgb + m.C + cx.c0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.set(v, gv.get(v) * ((xv.get(v) - mu[v]) * rs[v]) + bv.get(v));
+        o.store(out + (gb + p) * ldo + cx.c0);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void adain_bwd_reduce_kernel(Map m, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                              const T *__restrict__ dout, const T *__restrict__ x,
+                                                              const T *__restrict__ gbm, float *__restrict__ partial, int lddo,
+                                                              int ldx, int ldgb) {
+    constexpr int VEC = Elem<T>::VEC;
+    Ctx<T> cx(m);
+    float s[3][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[0][v] = s[1][v] = s[2][v] = 0.f;
+    if (cx.active) {
+        float mu[VEC], rs[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            mu[v] = mean[cx.g * m.C + cx.c0 + v];
+            rs[v] = rstd[cx.g * m.C + cx.c0 + v];
+        }
+        const size_t gb = (size_t)cx.g * m.P;
+        for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+            Vec16<T> dv, xv, gv;
+            dv.load(dout + (gb + p) * lddo + cx.c0);
+            xv.load(x + (gb + p) * ldx + cx.c0);
+            gv.load(gbm + (gb + p) * ldgb + cx.c0);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float xh = (xv.get(v) - mu[v]) * rs[v];
+                const float dxh = dv.get(v) * gv.get(v);
+                s[0][v] += dxh;
+                s[1][v] += dxh * xh;
+            }
+        }
+    }
+    block_reduce_store<T, 3>(cx, m, s, partial);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(Map m, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                             const T *__restrict__ dout, const T *__restrict__ x,
+                                                             const T *__restrict__ gbm, const float *__restrict__ sums,
+                                                             T *__restrict__ dx, T *__restrict__ dgb, int lddo, int ldx, int ldgb,
+                                                             int lddx, int lddgb) {
+    constexpr int VEC = Elem<T>::VEC;
+    Ctx<T> cx(m);
+    if (!cx.active) return;
+    float mu[VEC], rs[VEC], m1[VEC], m2[VEC];
+    const float invP = 1.f / (float)m.P;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const int c = cx.c0 + v;
+        mu[v] = mean[cx.g * m.C + c];
+        rs[v] = rstd[cx.g * m.C + c];
+        m1[v] = sums[(cx.g * 3 + 0) * m.C + c] * invP;
+        m2[v] = sums[(cx.g * 3 + 1) * m.C + c] * invP;
+    }
+    const size_t gb = (size_t)cx.g * m.P;
+    for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+        Vec16<T> dv, xv, gv, o, og, ob;
+        dv.load(dout + (gb + p) * lddo + cx.c0);
+        xv.load(x + (gb + p) * ldx + cx.c0);
+        gv.load(gbm + (gb + p) * ldgb + cx.c0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float xh = (xv.get(v) - mu[v]) * rs[v];
+            const float d = dv.get(v);
+            const float dxh = d * gv.get(v);
+            o.set(v, rs[v] * (dxh - m1[v] - xh * m2[v]));
+            og.set(v, d * xh);
+            ob.set(v, d);
+        }
+        o.store(dx + (gb + p) * lddx + cx.c0);
+        og.store(dgb + (gb + p) * lddgb + cx.c0);
+        ob.store(dgb + (gb + p) * lddgb + m.C + cx.c0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-channel sum for arbitrary C (scalar path: one thread per channel column slice)
+template <typename T>
+__global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, const T *__restrict__ x, float *__restrict__ partial) {
+    // block handles CHUNK pixels; thread t: channel c = t % Cb, row r0 = t / Cb (Cb = min(C,256) slab in blockIdx.z)
+    const int slab0 = blockIdx.z * NT, Cb = min(C - slab0, NT), RPB = NT / Cb;
+    const int t = threadIdx.x, c = slab0 + t % Cb, r0 = t / Cb;
+    const bool active = t < RPB * Cb;
+    float s = 0.f;
+    const int pb = blockIdx.x * CHUNK, pe = min(pb + CHUNK, P);
+    if (active)
+        for (int p = pb + r0; p < pe; p += RPB) s += Elem<T>::ld(x + (size_t)p * ld + c);
+    __shared__ float red[NT];
+    red[t] = active ? s : 0.f;
+    __syncthreads();
+    if (active && r0 == 0) {
+        float a = 0.f;
+        for (int r = 0; r < RPB; ++r) a += red[r * Cb + t];
+        partial[(size_t)blockIdx.x * C + c] = a;
+    }
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(size_t total, int C, int lddy, int ldy, int lddx, int y_f32, int act, float slope,
+                               const T *__restrict__ dy, const void *__restrict__ y, T *__restrict__ dx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i - p * C);
+        const float yv = y_f32 ? reinterpret_cast<const float *>(y)[p * ldy + c] : Elem<T>::ld(reinterpret_cast<const T *>(y) + p * ldy + c);
+        Elem<T>::st(dx + p * lddx + c, Elem<T>::ld(dy + p * lddy + c) * act_grad_out(yv, act, slope));
+    }
+}
+
+int check_map(const char *who, int G, int P, int C, int dtype, std::initializer_list<int> lds) {
+    RDFC_REQUIRE(dtype == RDFC_F32 || dtype == RDFC_BF16, "%s: bad dtype %d", who, dtype);
+    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    RDFC_REQUIRE(G > 0 && P > 0 && C > 0, "%s: non-positive size", who);
+    RDFC_REQUIRE(C % vec == 0, "%s: C=%d must be a multiple of %d", who, C, vec);
+    for (int ld : lds) RDFC_REQUIRE(ld >= C && ld % vec == 0, "%s: ld=%d must be >= C and a multiple of %d", who, ld, vec);
+    return 0;
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, ...)                          \
+    if ((dtype) == RDFC_BF16) { using T = bf16_t; __VA_ARGS__; } \
+    else { using T = float; __VA_ARGS__; }
+
+extern "C" int rdfc_norm_nchunk(int pixels_per_group) { return cdiv(pixels_per_group, CHUNK); }
+
+extern "C" int rdfc_norm_stats(const void *x, float *partial, int G, int P, int C, int ld, int dtype, void *stream) {
+    if (int e = check_map("rdfc_norm_stats", G, P, C, dtype, {ld})) return e;
+    Map m{G, P, C};
+    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld, partial));
+    RDFC_LAUNCH_CHECK("rdfc_norm_stats");
+    return 0;
+}
+
+extern "C" int rdfc_norm_finalize(const float *partial, float *mean, float *rstd, int G, int P, int C, float eps,
+                                  float *run_mean, float *run_var, float momentum, void *stream) {
+    RDFC_REQUIRE(G > 0 && P > 0 && C > 0, "rdfc_norm_finalize: non-positive size");
+    RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_finalize: running statistics need G == 1 (batch norm)");
+    Map m{G, P, C};
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(G * C, 128)), dim3(128), 0, (hipStream_t)stream, m, cdiv(P, CHUNK),
+                       partial, mean, rstd, eps, run_mean, run_var, momentum);
+    RDFC_LAUNCH_CHECK("rdfc_norm_finalize");
+    return 0;
+}
+
+extern "C" int rdfc_norm_apply(const void *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                               const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype,
+                               int act, float slope, const float *prelu, void *stream) {
+    if (int e = check_map("rdfc_norm_apply", G, P, C, dtype, {ldx, ldz})) return e;
+    RDFC_REQUIRE(act != RDFC_ACT_PRELU || prelu != nullptr, "rdfc_norm_apply: PReLU needs the slope pointer");
+    Map m{G, P, C};
+    ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
+    DISPATCH(dtype, hipLaunchKernelGGL(apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
+                                       (const T *)x, (const T *)res, (T *)z, ldx, ldr, ldz));
+    RDFC_LAUNCH_CHECK("rdfc_norm_apply");
+    return 0;
+}
+
+extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                                    const float *beta, const void *res, float *partial, int G, int P, int C, int lddz,
+                                    int ldx, int ldr, int dtype, int act, float slope, const float *prelu, void *stream) {
+    if (int e = check_map("rdfc_norm_bwd_reduce", G, P, C, dtype, {lddz, ldx})) return e;
+    Map m{G, P, C};
+    ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
+    DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
+                                       (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr));
+    RDFC_LAUNCH_CHECK("rdfc_norm_bwd_reduce");
+    return 0;
+}
+
+extern "C" int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, void *stream) {
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(G * 3 * C, 128)), dim3(128), 0, (hipStream_t)stream, G, C, 3,
+                       cdiv(P, CHUNK), partial, sums);
+    RDFC_LAUNCH_CHECK("rdfc_norm_bwd_finalize");
+    return 0;
+}
+
+extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                                   const float *beta, const void *res, const float *sums, void *dx, void *dres, int G, int P,
+                                   int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
+                                   const float *prelu, int frozen_stats, void *stream) {
+    if (int e = check_map("rdfc_norm_bwd_apply", G, P, C, dtype, {lddz, ldx, lddx})) return e;
+    Map m{G, P, C};
+    ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
+    DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
+                                       (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
+                                       lddx, lddr, frozen_stats));
+    RDFC_LAUNCH_CHECK("rdfc_norm_bwd_apply");
+    return 0;
+}
+
+extern "C" int rdfc_adain_apply(const void *x, const float *mean, const float *rstd, const void *gb, void *out, int N, int P,
+                                int C, int ldx, int ldgb, int ldo, int dtype, void *stream) {
+    if (int e = check_map("rdfc_adain_apply", N, P, C, dtype, {ldx, ldo})) return e;
+    RDFC_REQUIRE(ldgb >= 2 * C, "rdfc_adain_apply: ldgb must cover 2C channels");
+    Map m{N, P, C};
+    DISPATCH(dtype, hipLaunchKernelGGL(adain_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, mean,
+                                       rstd, (const T *)x, (const T *)gb, (T *)out, ldx, ldgb, ldo));
+    RDFC_LAUNCH_CHECK("rdfc_adain_apply");
+    return 0;
+}
+
+extern "C" int rdfc_adain_bwd_reduce(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb,
+                                     float *partial, int N, int P, int C, int lddo, int ldx, int ldgb, int dtype, void *stream) {
+    if (int e = check_map("rdfc_adain_bwd_reduce", N, P, C, dtype, {lddo, ldx})) return e;
+    Map m{N, P, C};
+    DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
+                                       mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, partial, lddo, ldx, ldgb));
+    RDFC_LAUNCH_CHECK("rdfc_adain_bwd_reduce");
+    return 0;
+}
+
+extern "C" int rdfc_adain_bwd_apply(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb,
+                                    const float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx, int ldgb,
+                                    int lddx, int lddgb, int dtype, void *stream) {
+    if (int e = check_map("rdfc_adain_bwd_apply", N, P, C, dtype, {lddo, ldx, lddx})) return e;
+    Map m{N, P, C};
+    DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
+                                       mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, sums, (T *)dx, (T *)dgb, lddo,
+                                       ldx, ldgb, lddx, lddgb));
+    RDFC_LAUNCH_CHECK("rdfc_adain_bwd_apply");
+    return 0;
+}
+
+extern "C" int rdfc_channel_sum(const void *x, float *partial, float *out, int P, int C, int ld, int dtype, void *stream) {
+    RDFC_REQUIRE(dtype == RDFC_F32 || dtype == RDFC_BF16, "rdfc_channel_sum: bad dtype");
+    RDFC_REQUIRE(P > 0 && C > 0 && ld >= C, "rdfc_channel_sum: bad size");
+    dim3 grid(cdiv(P, CHUNK), 1, cdiv(C, NT));
+    DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, (const T *)x, partial));
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, 1, C, 1, cdiv(P, CHUNK), partial, out);
+    RDFC_LAUNCH_CHECK("rdfc_channel_sum");
+    return 0;
+}
+
+extern "C" int rdfc_act_bwd(const void *dy, const void *y, void *dx, int P, int C, int lddy, int ldy, int lddx, int dtype,
+                            int y_is_f32, int act, float slope, void *stream) {
+    RDFC_REQUIRE(dtype == RDFC_F32 || dtype == RDFC_BF16, "rdfc_act_bwd: bad dtype");
+    const size_t total = (size_t)P * C;
+    const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+    DISPATCH(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, C, lddy, ldy, lddx,
+                                       y_is_f32, act, slope, (const T *)dy, y, (T *)dx));
+    RDFC_LAUNCH_CHECK("rdfc_act_bwd");
+    return 0;
+}

@@ -1,0 +1,373 @@
+// pointwise.hip -- weight packing, layout changes, window copies, reflection pad,
+// generator output head, weighted loss reductions, Adam, pepper noise.
+// All HBM-bound; one element (or one 16-byte vector) per thread, grid-stride.
+#include "common.h"
+
+#include <stdarg.h>
+
+// ---- error plumbing (shared by every translation unit) --------------------------------
+static thread_local char g_err[512] = "";
+void rdfc_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *rdfc_last_error(void) { return g_err; }
+extern "C" int rdfc_version(void) { return 100; }
+
+namespace {
+
+constexpr int NT = 256;
+inline int nblocks(size_t total, int per = NT) { return (int)min((size_t)4096, (total + per - 1) / per); }
+#define GRID_STRIDE(i, total) \
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (size_t)gridDim.x * blockDim.x)
+
+// ---- weights ------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float *__restrict__ w, T *__restrict__ wf, T *__restrict__ wb, int O, int I, int Tn, float scale) {
+    const size_t total = (size_t)O * I * Tn;
+    GRID_STRIDE(i, total) {   // i indexes the OIHW source: ((o*I + c)*Tn + t)
+        const int t = (int)(i % Tn);
+        const int c = (int)((i / Tn) % I);
+        const int o = (int)(i / ((size_t)Tn * I));
+        const float v = w[i] * scale;
+        if (wf) Elem<T>::st(wf + ((size_t)o * Tn + t) * I + c, v);
+        if (wb) Elem<T>::st(wb + ((size_t)c * Tn + t) * O + o, v);
+    }
+}
+
+__global__ void unpack_wgrad_kernel(const float *__restrict__ dw, float *__restrict__ g, int O, int I, int Tn, float scale) {
+    const size_t total = (size_t)O * I * Tn;
+    GRID_STRIDE(i, total) {   // i indexes the OIHW destination
+        const int t = (int)(i % Tn);
+        const int c = (int)((i / Tn) % I);
+        const int o = (int)(i / ((size_t)Tn * I));
+        g[i] = scale * dw[((size_t)o * Tn + t) * I + c];
+    }
+}
+
+// ---- layout ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_pm_kernel(const float *__restrict__ s, T *__restrict__ d, int N, int C, int HW, int ld) {
+    const size_t total = (size_t)N * C * HW;
+    GRID_STRIDE(i, total) {   // destination-major: i = (n*HW + p)*C + c
+        const int c = (int)(i % C);
+        const size_t np = i / C;
+        const int p = (int)(np % HW);
+        const int n = (int)(np / HW);
+        Elem<T>::st(d + np * ld + c, s[((size_t)n * C + c) * HW + p]);
+    }
+}
+template <typename T>
+__global__ void pm_to_nchw_kernel(const T *__restrict__ s, float *__restrict__ d, int N, int C, int HW, int ld) {
+    const size_t total = (size_t)N * C * HW;
+    GRID_STRIDE(i, total) {   // destination-major: i = (n*C + c)*HW + p
+        const int p = (int)(i % HW);
+        const int c = (int)((i / HW) % C);
+        const int n = (int)(i / ((size_t)HW * C));
+        d[i] = Elem<T>::ld(s + ((size_t)n * HW + p) * ld + c);
+    }
+}
+
+template <typename T, bool VECP>
+__global__ void copy_window_kernel(const T *__restrict__ s, T *__restrict__ d, int N, int Hs, int Ws, int Hd, int Wd, int C,
+                                   int lds, int ldd, int accumulate) {
+    constexpr int V = VECP ? Elem<T>::VEC : 1;
+    const int CV = C / V;
+    const size_t total = (size_t)N * Hd * Wd * CV;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % CV);
+        const size_t pd = i / CV;
+        const int xx = (int)(pd % Wd);
+        const int yy = (int)((pd / Wd) % Hd);
+        const int n = (int)(pd / ((size_t)Wd * Hd));
+        const size_t ps = ((size_t)n * Hs + yy) * Ws + xx;
+        if constexpr (VECP) {
+            Vec16<T> a;
+            a.load(s + ps * lds + cv * V);
+            if (accumulate) {
+                Vec16<T> b;
+                b.load(d + pd * ldd + cv * V);
+                for (int v = 0; v < V; ++v) a.set(v, a.get(v) + b.get(v));
+            }
+            a.store(d + pd * ldd + cv * V);
+        } else {
+            float v = Elem<T>::ld(s + ps * lds + cv);
+            if (accumulate) v += Elem<T>::ld(d + pd * ldd + cv);
+            Elem<T>::st(d + pd * ldd + cv, v);
+        }
+    }
+}
+
+__device__ inline int reflect(int i, int n) {   // nn.ReflectionPad2d index rule (no edge repeat)
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+template <typename T, bool VECP>
+__global__ void reflect_pad_kernel(const T *__restrict__ s, T *__restrict__ d, int N, int H, int W, int C, int pad) {
+    constexpr int V = VECP ? Elem<T>::VEC : 1;
+    const int CV = C / V, Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const size_t total = (size_t)N * Hp * Wp * CV;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % CV);
+        const size_t pd = i / CV;
+        const int xx = (int)(pd % Wp), yy = (int)((pd / Wp) % Hp), n = (int)(pd / ((size_t)Wp * Hp));
+        const size_t ps = ((size_t)n * H + reflect(yy - pad, H)) * W + reflect(xx - pad, W);
+        if constexpr (VECP) {
+            Vec16<T> a;
+            a.load(s + ps * C + cv * V);
+            a.store(d + pd * C + cv * V);
+        } else {
+            d[pd * C + cv] = s[ps * C + cv];
+        }
+    }
+}
+
+// adjoint as a gather: every source pixel sums the padded positions that read it
+template <typename T, bool VECP>
+__global__ void reflect_pad_adjoint_kernel(const T *__restrict__ dp, T *__restrict__ ds, int N, int H, int W, int C, int pad) {
+    constexpr int V = VECP ? Elem<T>::VEC : 1;
+    const int CV = C / V, Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const size_t total = (size_t)N * H * W * CV;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % CV);
+        const size_t ps = i / CV;
+        const int xx = (int)(ps % W), yy = (int)((ps / W) % H), n = (int)(ps / ((size_t)W * H));
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = yy + pad;
+        if (yy >= 1 && yy <= pad) ys[ny++] = pad - yy;
+        if (yy <= H - 2 && yy >= H - 1 - pad) ys[ny++] = 2 * (H - 1) - yy + pad;
+        xs[nx++] = xx + pad;
+        if (xx >= 1 && xx <= pad) xs[nx++] = pad - xx;
+        if (xx <= W - 2 && xx >= W - 1 - pad) xs[nx++] = 2 * (W - 1) - xx + pad;
+        float acc[V];
+        for (int v = 0; v < V; ++v) acc[v] = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+                const size_t pp = ((size_t)n * Hp + ys[a]) * Wp + xs[b];
+                if constexpr (VECP) {
+                    Vec16<T> t;
+                    t.load(dp + pp * C + cv * V);
+                    for (int v = 0; v < V; ++v) acc[v] += t.get(v);
+                } else {
+                    acc[0] += Elem<T>::ld(dp + pp * C + cv);
+                }
+            }
+        if constexpr (VECP) {
+            Vec16<T> o;
+            for (int v = 0; v < V; ++v) o.set(v, acc[v]);
+            o.store(ds + ps * C + cv * V);
+        } else {
+            Elem<T>::st(ds + ps * C + cv, acc[0]);
+        }
+    }
+}
+
+// ---- generator output head (rdf_generator.py:400-406) -------------------------------------------
+__global__ void fusion_head_kernel(const float *d1, const float *c1, const float *d2, const float *c2, float *d2c, float *pred, int n) {
+    GRID_STRIDE(i, (size_t)n) {
+        const float b = fminf(fmaxf(d2[i], -1.f), 1.f);
+        const float s1 = 1.f / (1.f + expf(c2[i] - c1[i]));   // softmax over (c1, c2), first component
+        d2c[i] = b;
+        pred[i] = d1[i] * s1 + b * (1.f - s1);
+    }
+}
+__global__ void fusion_head_bwd_kernel(const float *d1, const float *c1, const float *d2, const float *c2, const float *gp,
+                                       const float *gd2c, float *gd1, float *gc1, float *gd2, float *gc2, int n) {
+    GRID_STRIDE(i, (size_t)n) {
+        const float raw = d2[i];
+        const float b = fminf(fmaxf(raw, -1.f), 1.f);
+        const float s1 = 1.f / (1.f + expf(c2[i] - c1[i]));
+        const float g = gp ? gp[i] : 0.f;
+        const float gb = g * (1.f - s1) + (gd2c ? gd2c[i] : 0.f);
+        gd1[i] = g * s1;
+        const float gs = g * (d1[i] - b) * s1 * (1.f - s1);   // d pred / d c1 = (d1 - b) s1 (1 - s1)
+        gc1[i] = gs;
+        gc2[i] = -gs;
+        gd2[i] = (raw >= -1.f && raw <= 1.f) ? gb : 0.f;       // torch.clamp passes the gradient on the closed interval
+    }
+}
+
+// ---- weighted loss reductions -----------------------------------------------------------------------
+constexpr int LCHUNK = 4096;
+__global__ __launch_bounds__(NT) void loss_kernel(const float *__restrict__ pred, const float *__restrict__ target, float tconst,
+                                                  const float *__restrict__ weight, float uw, int C, int HW, size_t total, int kind,
+                                                  float *__restrict__ partial, float *__restrict__ grad, float gscale) {
+    const size_t b0 = (size_t)blockIdx.x * LCHUNK;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < LCHUNK; k += NT) {
+        const size_t i = b0 + k;
+        if (i >= total) break;
+        const float t = target ? target[i] : tconst;
+        float w = uw;
+        if (weight) {
+            const size_t n = i / ((size_t)C * HW);
+            w = weight[n * HW + i % HW];
+        }
+        const float d = pred[i] - t;
+        s += w * (kind == 1 ? fabsf(d) : d * d);
+        if (grad) grad[i] = gscale * w * (kind == 1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d);
+    }
+    s = wave_sum(s);
+    __shared__ float red[NT / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void loss_finalize_kernel(const float *partial, int n, float *out) {
+    // one wave; fixed order
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x == 0) *out = (float)s;
+}
+
+// ---- Adam (torch.optim.Adam, amsgrad=False, weight_decay=0) ------------------------------------------
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                            size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    GRID_STRIDE(i, n) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+__global__ void pepper_kernel(float *img, const uint8_t *mask, int C, int HW, size_t total) {
+    GRID_STRIDE(i, total) {
+        const size_t n = i / ((size_t)C * HW);
+        const uint8_t mk = mask[n * HW + i % HW];
+        if (mk == 1) img[i] = 1.f;
+        else if (mk == 2) img[i] = -1.f;
+    }
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, ...)                                      \
+    if ((dtype) == RDFC_BF16) { using T = bf16_t; __VA_ARGS__; } \
+    else { using T = float; __VA_ARGS__; }
+#define CHECK_DTYPE(who, dtype) RDFC_REQUIRE((dtype) == RDFC_F32 || (dtype) == RDFC_BF16, "%s: bad dtype %d", who, dtype)
+
+extern "C" int rdfc_pack_weight(const float *w, void *wf, void *wb, int O, int I, int KH, int KW, int dtype, float scale, void *stream) {
+    CHECK_DTYPE("rdfc_pack_weight", dtype);
+    RDFC_REQUIRE(O > 0 && I > 0 && KH > 0 && KW > 0, "rdfc_pack_weight: bad shape");
+    const size_t total = (size_t)O * I * KH * KW;
+    DISPATCH(dtype, hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, w, (T *)wf,
+                                       (T *)wb, O, I, KH * KW, scale));
+    RDFC_LAUNCH_CHECK("rdfc_pack_weight");
+    return 0;
+}
+
+extern "C" int rdfc_unpack_wgrad(const float *dw, float *g, int O, int I, int KH, int KW, float scale, void *stream) {
+    const size_t total = (size_t)O * I * KH * KW;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, dw, g, O, I, KH * KW, scale);
+    RDFC_LAUNCH_CHECK("rdfc_unpack_wgrad");
+    return 0;
+}
+
+extern "C" int rdfc_nchw_to_pm(const float *src, void *dst, int N, int C, int H, int W, int ld, int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_nchw_to_pm", dtype);
+    RDFC_REQUIRE(ld >= C, "rdfc_nchw_to_pm: ld < C");
+    const size_t total = (size_t)N * C * H * W;
+    DISPATCH(dtype, hipLaunchKernelGGL(nchw_to_pm_kernel<T>, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, src, (T *)dst, N, C, H * W, ld));
+    RDFC_LAUNCH_CHECK("rdfc_nchw_to_pm");
+    return 0;
+}
+extern "C" int rdfc_pm_to_nchw(const void *src, float *dst, int N, int C, int H, int W, int ld, int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_pm_to_nchw", dtype);
+    RDFC_REQUIRE(ld >= C, "rdfc_pm_to_nchw: ld < C");
+    const size_t total = (size_t)N * C * H * W;
+    DISPATCH(dtype, hipLaunchKernelGGL(pm_to_nchw_kernel<T>, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)src, dst, N, C, H * W, ld));
+    RDFC_LAUNCH_CHECK("rdfc_pm_to_nchw");
+    return 0;
+}
+
+extern "C" int rdfc_copy_window(const void *src, void *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, int ld_src, int ld_dst,
+                                int dtype, int accumulate, void *stream) {
+    CHECK_DTYPE("rdfc_copy_window", dtype);
+    RDFC_REQUIRE(Hd <= Hs && Wd <= Ws && ld_src >= C && ld_dst >= C, "rdfc_copy_window: window / ld mismatch");
+    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    const bool v = C % vec == 0 && ld_src % vec == 0 && ld_dst % vec == 0;
+    const size_t total = (size_t)N * Hd * Wd * (v ? C / vec : C);
+    DISPATCH(dtype, if (v) hipLaunchKernelGGL((copy_window_kernel<T, true>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
+                                              (const T *)src, (T *)dst, N, Hs, Ws, Hd, Wd, C, ld_src, ld_dst, accumulate);
+             else hipLaunchKernelGGL((copy_window_kernel<T, false>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
+                                     (const T *)src, (T *)dst, N, Hs, Ws, Hd, Wd, C, ld_src, ld_dst, accumulate));
+    RDFC_LAUNCH_CHECK("rdfc_copy_window");
+    return 0;
+}
+
+extern "C" int rdfc_reflect_pad(const void *src, void *dst, int N, int H, int W, int C, int pad, int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_reflect_pad", dtype);
+    RDFC_REQUIRE(pad >= 0 && pad < H && pad < W, "rdfc_reflect_pad: pad must be smaller than the map");
+    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    const bool v = C % vec == 0;
+    const size_t total = (size_t)N * (H + 2 * pad) * (W + 2 * pad) * (v ? C / vec : C);
+    DISPATCH(dtype, if (v) hipLaunchKernelGGL((reflect_pad_kernel<T, true>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
+                                              (const T *)src, (T *)dst, N, H, W, C, pad);
+             else hipLaunchKernelGGL((reflect_pad_kernel<T, false>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
+                                     (const T *)src, (T *)dst, N, H, W, C, pad));
+    RDFC_LAUNCH_CHECK("rdfc_reflect_pad");
+    return 0;
+}
+extern "C" int rdfc_reflect_pad_adjoint(const void *dpad, void *dsrc, int N, int H, int W, int C, int pad, int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_reflect_pad_adjoint", dtype);
+    RDFC_REQUIRE(pad >= 0 && pad < H && pad < W, "rdfc_reflect_pad_adjoint: pad must be smaller than the map");
+    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    const bool v = C % vec == 0;
+    const size_t total = (size_t)N * H * W * (v ? C / vec : C);
+    DISPATCH(dtype, if (v) hipLaunchKernelGGL((reflect_pad_adjoint_kernel<T, true>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
+                                              (const T *)dpad, (T *)dsrc, N, H, W, C, pad);
+             else hipLaunchKernelGGL((reflect_pad_adjoint_kernel<T, false>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
+                                     (const T *)dpad, (T *)dsrc, N, H, W, C, pad));
+    RDFC_LAUNCH_CHECK("rdfc_reflect_pad_adjoint");
+    return 0;
+}
+
+extern "C" int rdfc_fusion_head(const float *d1, const float *c1, const float *d2, const float *c2, float *d2c, float *pred, int n, void *stream) {
+    hipLaunchKernelGGL(fusion_head_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, d1, c1, d2, c2, d2c, pred, n);
+    RDFC_LAUNCH_CHECK("rdfc_fusion_head");
+    return 0;
+}
+extern "C" int rdfc_fusion_head_bwd(const float *d1, const float *c1, const float *d2, const float *c2, const float *gp, const float *gd2c,
+                                    float *gd1, float *gc1, float *gd2, float *gc2, int n, void *stream) {
+    hipLaunchKernelGGL(fusion_head_bwd_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, d1, c1, d2, c2, gp, gd2c, gd1, gc1, gd2, gc2, n);
+    RDFC_LAUNCH_CHECK("rdfc_fusion_head_bwd");
+    return 0;
+}
+
+extern "C" int rdfc_loss_nchunk(int numel) { return cdiv(numel, LCHUNK); }
+extern "C" int rdfc_weighted_loss(const float *pred, const float *target, float tconst, const float *weight, float uw, int N, int C,
+                                  int HW, int kind, float *partial, float *loss_out, float *grad, float gscale, void *stream) {
+    RDFC_REQUIRE(kind == 1 || kind == 2, "rdfc_weighted_loss: kind must be 1 (L1) or 2 (L2)");
+    const size_t total = (size_t)N * C * HW;
+    const int nb = cdiv(total, LCHUNK);
+    hipLaunchKernelGGL(loss_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, pred, target, tconst, weight, uw, C, HW, total, kind, partial, grad, gscale);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, loss_out);
+    RDFC_LAUNCH_CHECK("rdfc_weighted_loss");
+    return 0;
+}
+
+extern "C" int rdfc_adam_step(float *param, const float *grad, float *m, float *v, size_t n, float lr, float b1, float b2, float eps,
+                              int step, float gscale, void *stream) {
+    RDFC_REQUIRE(step >= 1, "rdfc_adam_step: step counts from 1");
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, m, v, n, lr, b1, b2, eps,
+                       (float)bc1, (float)sqrt(bc2), gscale);
+    RDFC_LAUNCH_CHECK("rdfc_adam_step");
+    return 0;
+}
+
+extern "C" int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, int HW, void *stream) {
+    const size_t total = (size_t)N * C * HW;
+    hipLaunchKernelGGL(pepper_kernel, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, img, mask, C, HW, total);
+    RDFC_LAUNCH_CHECK("rdfc_apply_pepper");
+    return 0;
+}

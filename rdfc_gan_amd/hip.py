@@ -1,0 +1,342 @@
+"""ctypes binding of include/rdfc_hip.h (librdfc_hip.so) + thin tensor-level wrappers.
+
+Torch is used for device memory and streams only: every wrapper passes raw device
+pointers, sizes and the current HIP stream to the C ABI.  There is no fallback:
+if the library is missing or a kernel rejects its arguments this raises.
+
+Feature maps are "pixel-major" 4-D torch tensors of shape [N, H, W, C] whose last
+dimension is contiguous and whose pixel stride ``ld = t.stride(2)`` may exceed C
+(a channel slice ``buf[..., a:b]`` of a wider map) -- see include/rdfc_hip.h.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librdfc_hip.so')
+
+F32, BF16 = 0, 1
+ACT = dict(none=0, relu=1, lrelu=2, tanh=3, sigmoid=4, prelu=5)
+_lib = None
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('N', 'Hi', 'Wi', 'Ci', 'Ho', 'Wo', 'Co', 'KH', 'KW', 'sh', 'sw', 'ph', 'pw',
+                                         'dh', 'dw', 'ldx', 'ldy', 'dtype', 'act')] + \
+               [('slope', C.c_float), ('out_f32', C.c_int32)]
+
+
+class MDConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('B', 'C', 'H', 'W', 'Co', 'KH', 'KW', 'sh', 'sw', 'ph', 'pw', 'dh', 'dw',
+                                         'group', 'dgroup')]
+
+
+def lib():
+    """Load librdfc_hip.so (built ahead of time by rdfc_gan_amd.build).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: run `python -m rdfc_gan_amd.build` '
+                               '(there is no CPU or PyTorch fallback for the HIP kernels)')
+        _lib = C.CDLL(LIB_PATH)
+        _lib.rdfc_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {lib().rdfc_last_error().decode()}')
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda, 'HIP kernels need device tensors'
+    return C.c_void_p(t.data_ptr())
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f'unsupported dtype {t.dtype}')
+
+
+def ld(t):
+    """pixel stride of a pixel-major map [N,H,W,C]"""
+    N, H, W, Cc = t.shape
+    l = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else (t.stride(0) if N > 1 else Cc))
+    assert t.stride(3) == 1 or Cc == 1, 'channel dim must be contiguous'
+    assert (W == 1 or t.stride(2) == l) and (H == 1 or t.stride(1) == W * l) and (N == 1 or t.stride(0) == H * W * l), \
+        f'not a pixel-major map: shape {tuple(t.shape)} stride {t.stride()}'
+    return l
+
+
+def _f(x):
+    return C.c_float(float(x))
+
+
+# --------------------------------------------------------------------------- convolution
+def conv_desc(x_shape, Co, k, stride, pad, dil=1, *, ldx, ldy, dtype, act='none', slope=0.0, out_f32=False,
+              out_hw=None):
+    N, Hi, Wi, Ci = x_shape
+    kh, kw = (k, k) if isinstance(k, int) else k
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    dh, dw = (dil, dil) if isinstance(dil, int) else dil
+    if out_hw is None:
+        Ho = (Hi + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+        Wo = (Wi + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    else:
+        Ho, Wo = out_hw
+    return ConvDesc(N, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, sh, sw, ph, pw, dh, dw, ldx, ldy, dtype, ACT[act], slope,
+                    int(out_f32))
+
+
+def pack_weight(w_oihw, dtype, scale=1.0, fwd=True, bwd=True):
+    """-> (w_fwd [O][T][I], w_bwd [I][T][O]) in the compute dtype."""
+    O, I, KH, KW = w_oihw.shape
+    w = w_oihw.detach()
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    wf = torch.empty(O, KH * KW, I, dtype=dtype, device=w.device) if fwd else None
+    wb = torch.empty(I, KH * KW, O, dtype=dtype, device=w.device) if bwd else None
+    _chk(lib().rdfc_pack_weight(_p(w), _p(wf), _p(wb), O, I, KH, KW, dt(wf if fwd else wb), _f(scale), _st()),
+         'rdfc_pack_weight')
+    return wf, wb
+
+
+def unpack_wgrad(dw_packed, O, I, KH, KW, scale=1.0):
+    g = torch.empty(O, I, KH, KW, dtype=torch.float32, device=dw_packed.device)
+    _chk(lib().rdfc_unpack_wgrad(_p(dw_packed), _p(g), O, I, KH, KW, _f(scale), _st()), 'rdfc_unpack_wgrad')
+    return g
+
+
+def conv_forward(d, x, w_fwd, bias, y):
+    _chk(lib().rdfc_conv2d_forward(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _st()), 'rdfc_conv2d_forward')
+    return y
+
+
+def conv_dgrad(d, dy, w_bwd, bias, dx):
+    _chk(lib().rdfc_conv2d_dgrad(C.byref(d), _p(dy), _p(w_bwd), _p(bias), _p(dx), _st()), 'rdfc_conv2d_dgrad')
+    return dx
+
+
+def conv_wgrad(d, x, dy):
+    dw = torch.zeros(d.Co, d.KH * d.KW, d.Ci, dtype=torch.float32, device=x.device)
+    _chk(lib().rdfc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _st()), 'rdfc_conv2d_wgrad')
+    return dw
+
+
+# --------------------------------------------------------------------------- layout
+def nchw_to_pm(src, dtype, out=None):
+    N, Cc, H, W = src.shape
+    src = src.contiguous()
+    assert src.dtype == torch.float32
+    if out is None:
+        out = torch.empty(N, H, W, Cc, dtype=dtype, device=src.device)
+    _chk(lib().rdfc_nchw_to_pm(_p(src), _p(out), N, Cc, H, W, ld(out), dt(out), _st()), 'rdfc_nchw_to_pm')
+    return out
+
+
+def pm_to_nchw(src):
+    N, H, W, Cc = src.shape
+    out = torch.empty(N, Cc, H, W, dtype=torch.float32, device=src.device)
+    _chk(lib().rdfc_pm_to_nchw(_p(src), _p(out), N, Cc, H, W, ld(src), dt(src), _st()), 'rdfc_pm_to_nchw')
+    return out
+
+
+def copy_window(src, dst, accumulate=False):
+    N, Hs, Ws, Cc = src.shape
+    _, Hd, Wd, Cd = dst.shape
+    assert Cc == Cd and src.dtype == dst.dtype
+    _chk(lib().rdfc_copy_window(_p(src), _p(dst), N, Hs, Ws, Hd, Wd, Cc, ld(src), ld(dst), dt(src), int(accumulate), _st()),
+         'rdfc_copy_window')
+    return dst
+
+
+def reflect_pad(src, pad):
+    N, H, W, Cc = src.shape
+    assert src.is_contiguous()
+    out = torch.empty(N, H + 2 * pad, W + 2 * pad, Cc, dtype=src.dtype, device=src.device)
+    _chk(lib().rdfc_reflect_pad(_p(src), _p(out), N, H, W, Cc, pad, dt(src), _st()), 'rdfc_reflect_pad')
+    return out
+
+
+def reflect_pad_adjoint(dpad, pad):
+    N, Hp, Wp, Cc = dpad.shape
+    assert dpad.is_contiguous()
+    H, W = Hp - 2 * pad, Wp - 2 * pad
+    out = torch.empty(N, H, W, Cc, dtype=dpad.dtype, device=dpad.device)
+    _chk(lib().rdfc_reflect_pad_adjoint(_p(dpad), _p(out), N, H, W, Cc, pad, dt(dpad), _st()), 'rdfc_reflect_pad_adjoint')
+    return out
+
+
+# --------------------------------------------------------------------------- normalisation
+def norm_nchunk(P):
+    return lib().rdfc_norm_nchunk(P)
+
+
+def norm_stats(x, G, eps, run_mean=None, run_var=None, momentum=0.1):
+    """x [N,H,W,C]; G = 1 (batch) or N (instance). -> mean[G,C], rstd[G,C]"""
+    N, H, W, Cc = x.shape
+    P = N * H * W // G
+    partial = torch.empty(G * norm_nchunk(P) * 2 * Cc, dtype=torch.float32, device=x.device)
+    mean = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
+    _chk(lib().rdfc_norm_stats(_p(x), _p(partial), G, P, Cc, ld(x), dt(x), _st()), 'rdfc_norm_stats')
+    _chk(lib().rdfc_norm_finalize(_p(partial), _p(mean), _p(rstd), G, P, Cc, _f(eps), _p(run_mean), _p(run_var),
+                                  _f(momentum), _st()), 'rdfc_norm_finalize')
+    return mean, rstd
+
+
+def norm_apply(x, mean, rstd, gamma, beta, res, z, act='none', slope=0.0, prelu=None):
+    N, H, W, Cc = x.shape
+    G = mean.shape[0]
+    P = N * H * W // G
+    _chk(lib().rdfc_norm_apply(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(z), G, P, Cc, ld(x),
+                               ld(res) if res is not None else 0, ld(z), dt(x), ACT[act], _f(slope), _p(prelu), _st()),
+         'rdfc_norm_apply')
+    return z
+
+
+def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, prelu=None, frozen=False,
+                  want_dres=False):
+    """-> dx, dres (or None), sums[G,3,C] (sum du, sum du*xhat, sum dz*min(u,0))"""
+    N, H, W, Cc = x.shape
+    G = mean.shape[0]
+    P = N * H * W // G
+    nch = norm_nchunk(P)
+    partial = torch.empty(G * nch * 3 * Cc, dtype=torch.float32, device=x.device)
+    sums = torch.empty(G, 3, Cc, dtype=torch.float32, device=x.device)
+    ldr = ld(res) if res is not None else 0
+    _chk(lib().rdfc_norm_bwd_reduce(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(partial), G, P, Cc,
+                                    ld(dz), ld(x), ldr, dt(x), ACT[act], _f(slope), _p(prelu), _st()), 'rdfc_norm_bwd_reduce')
+    _chk(lib().rdfc_norm_bwd_finalize(_p(partial), _p(sums), G, P, Cc, _st()), 'rdfc_norm_bwd_finalize')
+    dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
+    dres = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device) if want_dres else None
+    _chk(lib().rdfc_norm_bwd_apply(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(sums), _p(dx), _p(dres),
+                                   G, P, Cc, ld(dz), ld(x), ldr, Cc, Cc, dt(x), ACT[act], _f(slope), _p(prelu), int(frozen),
+                                   _st()), 'rdfc_norm_bwd_apply')
+    return dx, dres, sums
+
+
+def adain_apply(x, mean, rstd, gb, out):
+    N, H, W, Cc = x.shape
+    _chk(lib().rdfc_adain_apply(_p(x), _p(mean), _p(rstd), _p(gb), _p(out), N, H * W, Cc, ld(x), ld(gb), ld(out), dt(x), _st()),
+         'rdfc_adain_apply')
+    return out
+
+
+def adain_backward(dout, x, mean, rstd, gb):
+    N, H, W, Cc = x.shape
+    P = H * W
+    nch = norm_nchunk(P)
+    partial = torch.empty(N * nch * 3 * Cc, dtype=torch.float32, device=x.device)
+    sums = torch.empty(N, 3, Cc, dtype=torch.float32, device=x.device)
+    _chk(lib().rdfc_adain_bwd_reduce(_p(dout), _p(x), _p(mean), _p(rstd), _p(gb), _p(partial), N, P, Cc, ld(dout), ld(x),
+                                     ld(gb), dt(x), _st()), 'rdfc_adain_bwd_reduce')
+    _chk(lib().rdfc_norm_bwd_finalize(_p(partial), _p(sums), N, P, Cc, _st()), 'rdfc_norm_bwd_finalize')
+    dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
+    dgb = torch.empty(N, H, W, 2 * Cc, dtype=x.dtype, device=x.device)
+    _chk(lib().rdfc_adain_bwd_apply(_p(dout), _p(x), _p(mean), _p(rstd), _p(gb), _p(sums), _p(dx), _p(dgb), N, P, Cc,
+                                    ld(dout), ld(x), ld(gb), Cc, 2 * Cc, dt(x), _st()), 'rdfc_adain_bwd_apply')
+    return dx, dgb
+
+
+def channel_sum(x):
+    N, H, W, Cc = x.shape
+    P = N * H * W
+    partial = torch.empty(norm_nchunk(P) * Cc, dtype=torch.float32, device=x.device)
+    out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    _chk(lib().rdfc_channel_sum(_p(x), _p(partial), _p(out), P, Cc, ld(x), dt(x), _st()), 'rdfc_channel_sum')
+    return out
+
+
+def act_bwd(dy, y, act, slope=0.0):
+    N, H, W, Cc = dy.shape
+    dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
+    _chk(lib().rdfc_act_bwd(_p(dy), _p(y), _p(dx), N * H * W, Cc, ld(dy), ld(y), Cc, dt(dy), int(y.dtype == torch.float32),
+                            ACT[act], _f(slope), _st()), 'rdfc_act_bwd')
+    return dx
+
+
+# --------------------------------------------------------------------------- heads, losses, optimizer
+def fusion_head(d1, c1, d2, c2):
+    d2c, pred = torch.empty_like(d2), torch.empty_like(d2)
+    _chk(lib().rdfc_fusion_head(_p(d1), _p(c1), _p(d2), _p(c2), _p(d2c), _p(pred), d1.numel(), _st()), 'rdfc_fusion_head')
+    return d2c, pred
+
+
+def fusion_head_bwd(d1, c1, d2, c2, g_pred, g_d2c):
+    outs = [torch.empty_like(d1) for _ in range(4)]
+    _chk(lib().rdfc_fusion_head_bwd(_p(d1), _p(c1), _p(d2), _p(c2), _p(g_pred), _p(g_d2c), *[_p(o) for o in outs],
+                                    d1.numel(), _st()), 'rdfc_fusion_head_bwd')
+    return outs
+
+
+def weighted_loss(pred, target, weight, kind, want_grad=True, grad_scale=1.0):
+    """pred [N,C,H,W] f32 (upstream layout); target tensor or python float; weight [N,1,H,W] / [N,H,W] or None."""
+    N, Cc, H, W = pred.shape
+    pred = pred.contiguous()
+    numel = pred.numel()
+    tconst, tt = (float(target), None) if not torch.is_tensor(target) else (0.0, target.contiguous())
+    uw = 0.0
+    if weight is None:
+        uw = 1.0 / (numel + 1e-6)
+    else:
+        weight = weight.to(torch.float32).contiguous()
+        assert weight.numel() == N * H * W, 'weight must broadcast over channels'
+    nch = lib().rdfc_loss_nchunk(numel)
+    partial = torch.empty(nch, dtype=torch.float32, device=pred.device)
+    out = torch.empty((), dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    _chk(lib().rdfc_weighted_loss(_p(pred), _p(tt), _f(tconst), _p(weight), _f(uw), N, Cc, H * W, kind, _p(partial), _p(out),
+                                  _p(grad), _f(grad_scale), _st()), 'rdfc_weighted_loss')
+    return out, grad
+
+
+def adam_step(param, grad, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+    _chk(lib().rdfc_adam_step(_p(param), _p(grad), _p(m), _p(v), C.c_size_t(param.numel()), _f(lr), _f(b1), _f(b2), _f(eps),
+                              int(step), _f(grad_scale), _st()), 'rdfc_adam_step')
+
+
+def apply_pepper(img, mask_u8):
+    N, Cc, H, W = img.shape
+    _chk(lib().rdfc_apply_pepper(_p(img), _p(mask_u8), N, Cc, H * W, _st()), 'rdfc_apply_pepper')
+    return img
+
+
+# --------------------------------------------------------------------------- modulated deformable conv
+def _md_desc(inp, weight, stride, pad, dil, group, dgroup):
+    B, Cc, H, W = inp.shape
+    Co, _, KH, KW = weight.shape
+    return MDConvDesc(B, Cc, H, W, Co, KH, KW, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], group, dgroup)
+
+
+def mdconv_forward(inp, offset, mask, weight, bias, stride, pad, dil, group, dgroup):
+    d = _md_desc(inp, weight, stride, pad, dil, group, dgroup)
+    Ho = (d.H + 2 * d.ph - (d.dh * (d.KH - 1) + 1)) // d.sh + 1
+    Wo = (d.W + 2 * d.pw - (d.dw * (d.KW - 1) + 1)) // d.sw + 1
+    out = torch.empty(d.B, d.Co, Ho, Wo, dtype=torch.float32, device=inp.device)
+    _chk(lib().rdfc_mdconv_forward(C.byref(d), _p(inp), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), _st()),
+         'rdfc_mdconv_forward')
+    return out
+
+
+def mdconv_backward(inp, offset, mask, weight, grad_out, stride, pad, dil, group, dgroup,
+                    need=(True, True, True, True, True)):
+    d = _md_desc(inp, weight, stride, pad, dil, group, dgroup)
+    gi = torch.empty_like(inp) if need[0] else None
+    go = torch.empty_like(offset) if need[1] else None
+    gm = torch.empty_like(mask) if need[2] else None
+    gw = torch.empty_like(weight) if need[3] else None
+    gb = torch.empty(d.Co, dtype=torch.float32, device=inp.device) if need[4] else None
+    _chk(lib().rdfc_mdconv_backward(C.byref(d), _p(inp), _p(offset), _p(mask), _p(weight), _p(grad_out), _p(gi), _p(go),
+                                    _p(gm), _p(gw), _p(gb), _st()), 'rdfc_mdconv_backward')
+    return gi, go, gm, gw, gb

@@ -1,0 +1,337 @@
+"""GPU: every HIP kernel behind the C ABI against a plain PyTorch fp32 CPU reference
+of the same op (kernel-level parity; module-level parity against the oracle and the
+golden fixtures is in test_modules_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def hip():
+    from rdfc_gan_amd import hip as h
+    return h
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.5e-2
+
+
+def rel_err(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def to_pm(x_nchw, dtype, ld_extra=0):
+    """NCHW cpu f32 -> pixel-major device tensor (optionally a channel slice of a wider map)."""
+    N, C, H, W = x_nchw.shape
+    v = x_nchw.permute(0, 2, 3, 1).contiguous().to(dtype)
+    if ld_extra:
+        buf = torch.full((N, H, W, C + ld_extra), 7.0, dtype=dtype)
+        buf[..., :C] = v
+        return buf.to(DEV)[..., :C]
+    return v.to(DEV)
+
+
+def from_pm(x_pm):
+    return x_pm.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, Ci, Co, k, s, p
+    (2, 12, 14, 64, 64, 3, 1, 1),
+    (2, 13, 15, 64, 128, 3, 2, 1),
+    (1, 9, 11, 128, 256, 1, 2, 0),
+    (2, 10, 12, 128, 1, 3, 1, 1),
+    (2, 10, 12, 96, 1, 3, 1, 1),
+    (2, 10, 12, 128, 32, 3, 1, 1),
+    (2, 10, 12, 3, 48, 3, 1, 1),
+    (2, 10, 12, 1, 16, 3, 1, 1),
+    (2, 16, 18, 3, 64, 4, 2, 1),
+    (2, 16, 18, 1, 64, 4, 2, 1),
+    (2, 9, 9, 512, 1, 4, 1, 1),
+    (1, 20, 22, 1, 64, 7, 1, 0),
+    (1, 20, 22, 64, 3, 7, 1, 0),
+    (1, 7, 8, 768, 128, 3, 1, 1),
+    (2, 15, 19, 256, 512, 4, 1, 1),
+    (3, 29, 38, 64, 64, 3, 1, 1),
+    (2, 8, 8, 8, 24, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    h = hip()
+    N, H, W, Ci, Co, k, s, p = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    # the reference sees the same rounded operands as the kernel
+    xq, wq = x.to(dtype).float(), w.to(dtype).float()
+    xr = xq.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    y_ref = F.leaky_relu(F.conv2d(xr, wr, b, s, p), 0.2)
+    gy = rnd(*y_ref.shape, seed=4)
+    gyq = gy.to(dtype).float()
+    pre = F.conv2d(xr, wr, None, s, p)
+    pre.backward(gyq)
+
+    x_pm = to_pm(x, dtype, ld_extra=8)
+    wf, wb = h.pack_weight(w.to(DEV), dtype)
+    Ho, Wo = y_ref.shape[2:]
+    y_pm = torch.empty(N, Ho, Wo, Co, dtype=dtype, device=DEV)
+    d = h.conv_desc(x_pm.shape, Co, k, s, p, ldx=h.ld(x_pm), ldy=h.ld(y_pm), dtype=h.dt(x_pm), act='lrelu', slope=0.2)
+    h.conv_forward(d, x_pm, wf, b.to(DEV), y_pm)
+    assert rel_err(from_pm(y_pm), y_ref.detach()) < tol(dtype), 'forward'
+
+    # f32 output flag
+    y32 = torch.empty(N, Ho, Wo, Co, dtype=torch.float32, device=DEV)
+    d32 = h.conv_desc(x_pm.shape, Co, k, s, p, ldx=h.ld(x_pm), ldy=Co, dtype=h.dt(x_pm), act='none', out_f32=True)
+    h.conv_forward(d32, x_pm, wf, None, y32)
+    assert rel_err(from_pm(y32), pre.detach()) < tol(dtype), 'forward f32 out'
+
+    gy_pm = to_pm(gy, dtype)
+    dx_pm = torch.empty(N, H, W, Ci, dtype=dtype, device=DEV)
+    dd = h.conv_desc(x_pm.shape, Co, k, s, p, ldx=Ci, ldy=Co, dtype=h.dt(x_pm))
+    h.conv_dgrad(dd, gy_pm, wb, None, dx_pm)
+    assert rel_err(from_pm(dx_pm), xr.grad) < tol(dtype), 'dgrad'
+
+    dwd = h.conv_desc(x_pm.shape, Co, k, s, p, ldx=h.ld(x_pm), ldy=Co, dtype=h.dt(x_pm))
+    dw = h.conv_wgrad(dwd, x_pm, gy_pm)
+    gw = h.unpack_wgrad(dw, Co, Ci, k, k)
+    assert rel_err(gw, wr.grad) < tol(dtype), 'wgrad'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 5, 7, 512, 256), (2, 8, 10, 192, 64), (1, 15, 19, 128, 64)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_transpose_through_primitives(case, dtype):
+    """ConvTranspose2d(3, s2, p1, op1): forward = dgrad primitive, input-grad = forward primitive,
+    weight-grad = wgrad primitive with x <-> dy."""
+    h = hip()
+    N, H, W, Cin, Cout = case
+    x = rnd(N, Cin, H, W, seed=1).to(dtype).float()
+    w = (rnd(Cin, Cout, 3, 3, seed=2) * (Cin * 9) ** -0.5).to(dtype).float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv_transpose2d(xr, wr, None, 2, 1, 1)
+    gy = rnd(*y_ref.shape, seed=3).to(dtype).float()
+    y_ref.backward(gy)
+    # equivalent conv: x_c = Y_T space (Ci_c = Cout), y_c = X_T space (Co_c = Cin), weight [O=Cin][I=Cout]
+    wf, wb = h.pack_weight(w.to(DEV), dtype)
+    x_pm = to_pm(x, dtype)
+    y_pm = torch.empty(N, 2 * H, 2 * W, Cout, dtype=dtype, device=DEV)
+    d = h.conv_desc((N, 2 * H, 2 * W, Cout), Cin, 3, 2, 1, ldx=Cout, ldy=Cin, dtype=h.dt(x_pm), out_hw=(H, W))
+    h.conv_dgrad(d, x_pm, wb, None, y_pm)
+    assert rel_err(from_pm(y_pm), y_ref.detach()) < tol(dtype), 'convT forward'
+    gy_pm = to_pm(gy, dtype)
+    dx_pm = torch.empty(N, H, W, Cin, dtype=dtype, device=DEV)
+    h.conv_forward(d, gy_pm, wf, None, dx_pm)
+    assert rel_err(from_pm(dx_pm), xr.grad) < tol(dtype), 'convT input grad'
+    dw = h.conv_wgrad(d, gy_pm, x_pm)
+    assert rel_err(h.unpack_wgrad(dw, Cin, Cout, 3, 3), wr.grad) < tol(dtype), 'convT weight grad'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['bn', 'in'])
+@pytest.mark.parametrize('act,res', [('relu', True), ('lrelu', False), ('prelu', False), ('none', False)])
+def test_norm_fwd_bwd(dtype, mode, act, res):
+    h = hip()
+    N, H, W, C = 3, 9, 11, 96
+    x = (rnd(N, C, H, W, seed=1) * 1.5 + 0.3).to(dtype).float()
+    r = rnd(N, C, H, W, seed=2).to(dtype).float() if res else None
+    gamma = (1 + 0.1 * rnd(C, seed=3)) if mode == 'bn' else None
+    beta = 0.1 * rnd(C, seed=4) if mode == 'bn' else None
+    slope_t = torch.tensor([0.25])
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    gr = gamma.clone().requires_grad_(True) if gamma is not None else None
+    br = beta.clone().requires_grad_(True) if beta is not None else None
+    ar = slope_t.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    if mode == 'bn':
+        u = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+    else:
+        u = F.instance_norm(xr, eps=1e-5)
+    if res:
+        u = u + rr
+    z_ref = {'relu': F.relu, 'lrelu': lambda t: F.leaky_relu(t, 0.2), 'prelu': lambda t: F.prelu(t, ar),
+             'none': lambda t: t}[act](u)
+    gz = rnd(N, C, H, W, seed=5).to(dtype).float()
+    z_ref.backward(gz)
+
+    x_pm = to_pm(x, dtype, ld_extra=8)
+    r_pm = to_pm(r, dtype) if res else None
+    G = 1 if mode == 'bn' else N
+    rm_d, rv_d = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, rstd = h.norm_stats(x_pm, G, 1e-5, rm_d if mode == 'bn' else None, rv_d if mode == 'bn' else None, 0.1)
+    z = torch.empty(N, H, W, C, dtype=dtype, device=DEV)
+    gd = gamma.to(DEV) if gamma is not None else None
+    bd = beta.to(DEV) if beta is not None else None
+    pr = slope_t.to(DEV)
+    h.norm_apply(x_pm, mean, rstd, gd, bd, r_pm, z, act, 0.2, pr)
+    assert rel_err(from_pm(z), z_ref.detach()) < tol(dtype), 'forward'
+    if mode == 'bn':
+        assert rel_err(rm_d, rm) < 1e-4 and rel_err(rv_d, rv) < 1e-4, 'running stats'
+    gz_pm = to_pm(gz, dtype)
+    dx, dres, sums = h.norm_backward(gz_pm, x_pm, mean, rstd, gd, bd, r_pm, act, 0.2, pr, want_dres=res)
+    t = 4 * tol(dtype)
+    assert rel_err(from_pm(dx), xr.grad) < t, 'dx'
+    if res:
+        assert rel_err(from_pm(dres), rr.grad) < t, 'dres'
+    if mode == 'bn':
+        assert rel_err(sums[0, 1], gr.grad) < t, 'dgamma'
+        assert rel_err(sums[0, 0], br.grad) < t, 'dbeta'
+    if act == 'prelu':
+        assert rel_err(sums[:, 2].sum(), ar.grad.sum()) < t, 'dslope'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_adain(dtype):
+    h = hip()
+    N, H, W, C = 2, 7, 9, 192
+    x = rnd(N, C, H, W, seed=1).to(dtype).float()
+    gb = (rnd(N, 2 * C, H, W, seed=2) * 0.5).to(dtype).float()
+    xr, gbr = x.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+    out_ref = gbr[:, :C] * F.instance_norm(xr, eps=1e-5) + gbr[:, C:]
+    go = rnd(N, C, H, W, seed=3).to(dtype).float()
+    out_ref.backward(go)
+    x_pm, gb_pm = to_pm(x, dtype), to_pm(gb, dtype)
+    mean, rstd = h.norm_stats(x_pm, N, 1e-5)
+    out = torch.empty(N, H, W, C, dtype=dtype, device=DEV)
+    h.adain_apply(x_pm, mean, rstd, gb_pm, out)
+    assert rel_err(from_pm(out), out_ref.detach()) < tol(dtype)
+    dx, dgb = h.adain_backward(to_pm(go, dtype), x_pm, mean, rstd, gb_pm)
+    assert rel_err(from_pm(dx), xr.grad) < 4 * tol(dtype)
+    assert rel_err(from_pm(dgb), gbr.grad) < 4 * tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_layout_window_pad_sum(dtype):
+    h = hip()
+    x = rnd(2, 24, 9, 7, seed=1).to(dtype).float()
+    pm = h.nchw_to_pm(x.to(DEV), dtype)
+    assert rel_err(from_pm(pm), x) == 0
+    assert rel_err(h.pm_to_nchw(pm), x) == 0
+    x3 = rnd(2, 3, 9, 7, seed=2)
+    assert rel_err(h.pm_to_nchw(h.nchw_to_pm(x3.to(DEV), torch.float32)), x3) == 0
+    # crop + channel-slice copy (torch.cat of a cropped decoder map and a skip map)
+    dst = torch.zeros(2, 8, 6, 48, dtype=dtype, device=DEV)
+    h.copy_window(pm, dst[..., :24])
+    h.copy_window(pm[:, :8, :6].contiguous(), dst[..., 24:])
+    ref = torch.cat([x[:, :, :8, :6], x[:, :, :8, :6]], 1)
+    assert rel_err(from_pm(dst), ref) == 0
+    h.copy_window(pm, dst[..., :24], accumulate=True)
+    assert rel_err(from_pm(dst[..., :24].contiguous()), 2 * x[:, :, :8, :6]) < tol(dtype)
+    # reflection pad and its adjoint
+    for pad in (1, 3):
+        xr = x.clone().requires_grad_(True)
+        yp = F.pad(xr, (pad,) * 4, mode='reflect')
+        g = rnd(*yp.shape, seed=3).to(dtype).float()
+        yp.backward(g)
+        assert rel_err(from_pm(h.reflect_pad(pm, pad)), yp.detach()) == 0
+        assert rel_err(from_pm(h.reflect_pad_adjoint(to_pm(g, dtype), pad)), xr.grad) < tol(dtype)
+    # per-channel sums, odd channel counts
+    for C in (1, 3, 24, 1536 if dtype == torch.float32 else 768):
+        t = rnd(2, C, 5, 6, seed=C).to(dtype).float()
+        assert rel_err(h.channel_sum(to_pm(t, dtype)), t.sum((0, 2, 3))) < tol(dtype)
+    # activation backward from the output
+    y = torch.tanh(rnd(2, 1, 9, 7, seed=5))
+    g = rnd(2, 1, 9, 7, seed=6)
+    got = h.act_bwd(to_pm(g, torch.float32), to_pm(y, torch.float32), 'tanh')
+    assert rel_err(from_pm(got), g * (1 - y * y)) < 1e-6
+
+
+def test_fusion_head_losses_adam_pepper():
+    h = hip()
+    shp = (2, 1, 9, 11)
+    d1, c1, d2, c2 = (rnd(*shp, seed=i) * (1.5 if i == 3 else 1.0) for i in range(1, 5))
+    leaves = [t.clone().requires_grad_(True) for t in (d1, c1, d2, c2)]
+    d2c = leaves[2].clamp(-1, 1)
+    score = torch.softmax(torch.cat([leaves[1], leaves[3]], 1), 1)
+    pred = (torch.cat([leaves[0], d2c], 1) * score).sum(1, keepdim=True)
+    gp, gd = rnd(*shp, seed=7), rnd(*shp, seed=8)
+    (pred * gp).sum().backward(retain_graph=True)
+    (d2c * gd).sum().backward()
+    dev = [t.to(DEV) for t in (d1, c1, d2, c2)]
+    o_d2c, o_pred = h.fusion_head(*dev)
+    assert rel_err(o_pred, pred.detach()) < 1e-6 and rel_err(o_d2c, d2c.detach()) == 0
+    grads = h.fusion_head_bwd(*dev, gp.to(DEV), gd.to(DEV))
+    for g, leaf in zip(grads, leaves):
+        assert rel_err(g, leaf.grad) < 1e-5
+    # losses
+    for C in (1, 3):
+        a, b = rnd(2, C, 20, 24, seed=1), rnd(2, C, 20, 24, seed=2)
+        m = torch.rand(2, 1, 20, 24, generator=torch.Generator().manual_seed(3)) > 0.3
+        w = m / (m.sum() + 1e-6)
+        for kind, fn in ((1, lambda p, t: (p - t).abs()), (2, lambda p, t: (p - t) ** 2)):
+            for ww in (w, None):
+                ar = a.clone().requires_grad_(True)
+                wt = ww if ww is not None else torch.ones_like(a) / (a.numel() + 1e-6)
+                ref = (wt * fn(ar, b)).sum()
+                (ref * 3.0).backward()
+                val, grad = h.weighted_loss(a.to(DEV), b.to(DEV), ww.to(DEV) if ww is not None else None, kind, True, 3.0)
+                assert abs(float(val) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+                assert rel_err(grad, ar.grad) < 1e-5
+    p = rnd(2, 1, 26, 36, seed=5)
+    val, grad = h.weighted_loss(p.to(DEV), 1.0, None, 2, True, 1.0)
+    ref = ((p - 1) ** 2).sum() / (p.numel() + 1e-6)
+    assert abs(float(val) - float(ref)) < 1e-5
+    # Adam against torch.optim.Adam
+    prm = torch.nn.Parameter(rnd(1000, seed=1))
+    opt = torch.optim.Adam([prm], lr=2e-3, betas=(0.5, 0.999))
+    pd, md, vd = prm.detach().clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 4):
+        g = rnd(1000, seed=10 + step)
+        prm.grad = g.clone()
+        opt.step()
+        h.adam_step(pd, g.to(DEV), md, vd, 2e-3, 0.5, 0.999, 1e-8, step)
+    assert rel_err(pd, prm.detach()) < 1e-6
+    # pepper
+    img = rnd(2, 3, 5, 6, seed=1)
+    mask = torch.randint(0, 3, (2, 1, 5, 6), generator=torch.Generator().manual_seed(2), dtype=torch.uint8)
+    ref = img.clone()
+    mm = mask.expand(2, 3, 5, 6)
+    ref[mm == 1] = 1
+    ref[mm == 2] = -1
+    got = h.apply_pepper(img.to(DEV), mask.to(DEV))
+    assert rel_err(got, ref) == 0
+
+
+MD_CASES = [dict(B=2, C=1, H=9, W=11, Co=1, k=3, s=1, p=1, g=1, dg=1),
+            dict(B=2, C=1, H=9, W=11, Co=1, k=1, s=1, p=0, g=1, dg=1),
+            dict(B=2, C=4, H=7, W=9, Co=6, k=3, s=1, p=1, g=2, dg=2),
+            dict(B=1, C=4, H=8, W=8, Co=4, k=3, s=2, p=1, g=1, dg=1)]
+
+
+@pytest.mark.parametrize('c', MD_CASES, ids=lambda c: f"C{c['C']}k{c['k']}s{c['s']}g{c['g']}")
+def test_mdconv_against_oracle(c):
+    """rdfc_mdconv_* against the C oracle (which restates upstream's CUDA kernels)."""
+    from oracle import mdconv as om
+    h = hip()
+    k, s, p = c['k'], c['s'], c['p']
+    Ho = (c['H'] + 2 * p - k) // s + 1
+    Wo = (c['W'] + 2 * p - k) // s + 1
+    x = rnd(c['B'], c['C'], c['H'], c['W'], seed=1)
+    off = rnd(c['B'], c['dg'] * 2 * k * k, Ho, Wo, seed=2, scale=2.0)
+    msk = torch.sigmoid(rnd(c['B'], c['dg'] * k * k, Ho, Wo, seed=3)) * 2
+    w = rnd(c['Co'], c['C'] // c['g'], k, k, seed=4, scale=0.3)
+    b = rnd(c['Co'], seed=5)
+    go = rnd(c['B'], c['Co'], Ho, Wo, seed=6)
+    ref = om.forward(x, off, msk, w, b, s, p, 1, c['g'], c['dg'])
+    refs = om.backward(x, off, msk, w, go, s, p, 1, c['g'], c['dg'])
+    dv = [t.to(DEV) for t in (x, off, msk, w)]
+    got = h.mdconv_forward(*dv, b.to(DEV), (s, s), (p, p), (1, 1), c['g'], c['dg'])
+    assert rel_err(got, ref) < 1e-5
+    gots = h.mdconv_backward(*dv, go.to(DEV), (s, s), (p, p), (1, 1), c['g'], c['dg'])
+    for name, a, r in zip(('input', 'offset', 'mask', 'weight', 'bias'), gots, refs):
+        assert rel_err(a, r) < 2e-5, name
