@@ -88,9 +88,10 @@ int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const void *dy, fl
 /* upstream NCHW f32 tensor -> pixel-major `dtype` (and back, f32 out). */
 int rdfc_nchw_to_pm(const float *src, void *dst, int N, int C, int H, int W, int ld, int dtype, void *stream);
 int rdfc_pm_to_nchw(const void *src, float *dst, int N, int C, int H, int W, int ld, int dtype, void *stream);
-/* dst[p, 0:C] (ld_dst) = src[p', 0:C] (ld_src) for the top-left Hd x Wd window of an Hs x Ws map:
- * the crop of rdf_generator.py:244-260 and the channel-slice copy of torch.cat. accumulate!=0: dst += src. */
-int rdfc_copy_window(const void *src, void *dst, int N, int Hs, int Ws, int Hd, int Wd, int C,
+/* dst[n, y, x, 0:C] (map Hd x Wd, ld_dst) = src[n, y, x, 0:C] (map Hs x Ws, ld_src) for the top-left Hw x Ww
+ * window: the crop of rdf_generator.py:244-260 (and its adjoint, a zero-extended copy) and the channel-slice
+ * copy of torch.cat.  accumulate != 0: dst += src. */
+int rdfc_copy_window(const void *src, void *dst, int N, int Hs, int Ws, int Hd, int Wd, int Hw, int Ww, int C,
                      int ld_src, int ld_dst, int dtype, int accumulate, void *stream);
 /* nn.ReflectionPad2d(pad) forward, and its adjoint (fold the border back). resnet_generator.py:19,50,68,84 */
 int rdfc_reflect_pad(const void *src, void *dst, int N, int H, int W, int C, int pad, int dtype, void *stream);

@@ -71,18 +71,19 @@ __global__ void pm_to_nchw_kernel(const T *__restrict__ s, float *__restrict__ d
 }
 
 template <typename T, bool VECP>
-__global__ void copy_window_kernel(const T *__restrict__ s, T *__restrict__ d, int N, int Hs, int Ws, int Hd, int Wd, int C,
-                                   int lds, int ldd, int accumulate) {
+__global__ void copy_window_kernel(const T *__restrict__ s, T *__restrict__ d, int N, int Hs, int Ws, int Hd, int Wd, int Hw,
+                                   int Ww, int C, int lds, int ldd, int accumulate) {
     constexpr int V = VECP ? Elem<T>::VEC : 1;
     const int CV = C / V;
-    const size_t total = (size_t)N * Hd * Wd * CV;
+    const size_t total = (size_t)N * Hw * Ww * CV;
     GRID_STRIDE(i, total) {
         const int cv = (int)(i % CV);
-        const size_t pd = i / CV;
-        const int xx = (int)(pd % Wd);
-        const int yy = (int)((pd / Wd) % Hd);
-        const int n = (int)(pd / ((size_t)Wd * Hd));
+        const size_t pw_ = i / CV;
+        const int xx = (int)(pw_ % Ww);
+        const int yy = (int)((pw_ / Ww) % Hw);
+        const int n = (int)(pw_ / ((size_t)Ww * Hw));
         const size_t ps = ((size_t)n * Hs + yy) * Ws + xx;
+        const size_t pd = ((size_t)n * Hd + yy) * Wd + xx;
         if constexpr (VECP) {
             Vec16<T> a;
             a.load(s + ps * lds + cv * V);
@@ -289,17 +290,17 @@ extern "C" int rdfc_pm_to_nchw(const void *src, float *dst, int N, int C, int H,
     return 0;
 }
 
-extern "C" int rdfc_copy_window(const void *src, void *dst, int N, int Hs, int Ws, int Hd, int Wd, int C, int ld_src, int ld_dst,
-                                int dtype, int accumulate, void *stream) {
+extern "C" int rdfc_copy_window(const void *src, void *dst, int N, int Hs, int Ws, int Hd, int Wd, int Hw, int Ww, int C,
+                                int ld_src, int ld_dst, int dtype, int accumulate, void *stream) {
     CHECK_DTYPE("rdfc_copy_window", dtype);
-    RDFC_REQUIRE(Hd <= Hs && Wd <= Ws && ld_src >= C && ld_dst >= C, "rdfc_copy_window: window / ld mismatch");
+    RDFC_REQUIRE(Hw <= Hs && Ww <= Ws && Hw <= Hd && Ww <= Wd && ld_src >= C && ld_dst >= C, "rdfc_copy_window: window / ld mismatch");
     const int vec = dtype == RDFC_BF16 ? 8 : 4;
     const bool v = C % vec == 0 && ld_src % vec == 0 && ld_dst % vec == 0;
-    const size_t total = (size_t)N * Hd * Wd * (v ? C / vec : C);
+    const size_t total = (size_t)N * Hw * Ww * (v ? C / vec : C);
     DISPATCH(dtype, if (v) hipLaunchKernelGGL((copy_window_kernel<T, true>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
-                                              (const T *)src, (T *)dst, N, Hs, Ws, Hd, Wd, C, ld_src, ld_dst, accumulate);
+                                              (const T *)src, (T *)dst, N, Hs, Ws, Hd, Wd, Hw, Ww, C, ld_src, ld_dst, accumulate);
              else hipLaunchKernelGGL((copy_window_kernel<T, false>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
-                                     (const T *)src, (T *)dst, N, Hs, Ws, Hd, Wd, C, ld_src, ld_dst, accumulate));
+                                     (const T *)src, (T *)dst, N, Hs, Ws, Hd, Wd, Hw, Ww, C, ld_src, ld_dst, accumulate));
     RDFC_LAUNCH_CHECK("rdfc_copy_window");
     return 0;
 }

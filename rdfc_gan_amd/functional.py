@@ -1,0 +1,347 @@
+"""Autograd blocks over the HIP kernels.
+
+Every block is one torch.autograd.Function whose forward/backward are sequences of
+C-ABI calls (rdfc_gan_amd.hip).  Activations flowing between blocks are pixel-major
+maps [N,H,W,C] in the compute dtype (bf16 or f32); module inputs / outputs are
+converted from / to upstream's NCHW f32 at the network boundary only.
+
+Blocks
+  conv_block   conv | conv-transpose  [+bias] [+BatchNorm | InstanceNorm] [+residual] [+act]
+  wadain       W-AdaIN fusion (per-pixel style affine of an instance-normalised map)
+  crop_cat     upstream's `_concat` (crop trailing rows/cols, concatenate channels)
+  reflect_pad, to_pm / to_nchw, fusion_head
+"""
+import math
+
+import torch
+
+from . import hip
+
+_compute_dtype = torch.bfloat16
+_weights_epoch = 0
+_pack_cache = {}
+
+
+def set_compute_dtype(dtype):
+    """torch.bfloat16 (fast path: bf16 MFMA) or torch.float32 (exact-f32 MFMA, parity mode)."""
+    global _compute_dtype
+    assert dtype in (torch.bfloat16, torch.float32)
+    _compute_dtype = dtype
+
+
+def compute_dtype():
+    return _compute_dtype
+
+
+def invalidate_packed_weights():
+    """call after parameters were changed behind autograd's back (fused optimizer step, load_state_dict)."""
+    global _weights_epoch
+    _weights_epoch += 1
+    _pack_cache.clear()
+
+
+def _packed(weight, dtype, scale):
+    key = (weight.data_ptr(), weight._version, _weights_epoch, dtype, scale)
+    hit = _pack_cache.get(key)
+    if hit is None:
+        hit = hip.pack_weight(weight.detach().contiguous(), dtype, scale)
+        _pack_cache[key] = hit
+    return hit
+
+
+class ConvSpec:
+    """static description of one conv block (shared by forward and backward)"""
+    __slots__ = ('k', 'stride', 'pad', 'transposed', 'out_pad', 'norm', 'act', 'slope', 'eps', 'momentum',
+                 'out_f32', 'wscale')
+
+    def __init__(self, k, stride=1, pad=0, transposed=False, out_pad=0, norm='none', act='none', slope=0.0,
+                 eps=1e-5, momentum=0.1, out_f32=False, wscale=1.0):
+        self.k, self.stride, self.pad, self.transposed, self.out_pad = k, stride, pad, transposed, out_pad
+        self.norm, self.act, self.slope, self.eps, self.momentum = norm, act, slope, eps, momentum
+        self.out_f32, self.wscale = out_f32, wscale
+
+
+def _geometry(spec, x, weight):
+    """-> (desc for conv-primitive orientation, Cout, Ho, Wo)"""
+    N, H, W, Cin = x.shape
+    k, s, p = spec.k, spec.stride, spec.pad
+    if not spec.transposed:
+        Cout = weight.shape[0]
+        Ho = (H + 2 * p - k) // s + 1
+        Wo = (W + 2 * p - k) // s + 1
+    else:   # ConvTranspose2d weight [Cin, Cout, k, k]
+        Cout = weight.shape[1]
+        Ho = (H - 1) * s - 2 * p + k + spec.out_pad
+        Wo = (W - 1) * s - 2 * p + k + spec.out_pad
+    return Cout, Ho, Wo
+
+
+class _ConvBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var):
+        dtype = x.dtype
+        N, H, W, Cin = x.shape
+        Cout, Ho, Wo = _geometry(spec, x, weight)
+        wf, wb = _packed(weight, dtype, spec.wscale)
+        has_norm = spec.norm != 'none'
+        epi_act = 'none' if has_norm else spec.act
+        out_f32 = spec.out_f32 and not has_norm
+        y = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32 if out_f32 else dtype, device=x.device)
+        if not spec.transposed:
+            d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
+                              act=epi_act, slope=spec.slope, out_f32=out_f32)
+            hip.conv_forward(d, x, wf, bias, y)
+        else:   # equivalent conv maps the (larger) output map onto x
+            d = hip.conv_desc((N, Ho, Wo, Cout), Cin, spec.k, spec.stride, spec.pad, ldx=Cout, ldy=hip.ld(x),
+                              dtype=hip.dt(x), act=epi_act, slope=spec.slope, out_f32=out_f32, out_hw=(H, W))
+            hip.conv_dgrad(d, x, wb, bias, y)
+        ctx.spec, ctx.training, ctx.shapes = spec, training, (Cout, Ho, Wo)
+        ctx.has_bias = bias is not None
+        if not has_norm:
+            ctx.save_for_backward(x, weight, y if spec.act != 'none' else None)
+            return y
+        G = N if spec.norm == 'in' else 1
+        if spec.norm == 'bn' and not training:
+            mean = run_mean.view(1, -1).float()
+            rstd = torch.rsqrt(run_var.view(1, -1).float() + spec.eps)
+        else:
+            upd = spec.norm == 'bn' and run_mean is not None
+            mean, rstd = hip.norm_stats(y, G, spec.eps, run_mean if upd else None, run_var if upd else None, spec.momentum)
+        z = torch.empty(N, Ho, Wo, Cout, dtype=dtype, device=x.device)
+        hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
+        ctx.save_for_backward(x, weight, y, mean, rstd, gamma, beta, res, prelu)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        spec = ctx.spec
+        Cout, Ho, Wo = ctx.shapes
+        has_norm = spec.norm != 'none'
+        g_gamma = g_beta = g_res = g_prelu = g_bias = None
+        if has_norm:
+            x, weight, y, mean, rstd, gamma, beta, res, prelu = ctx.saved_tensors
+            dz = dz if dz.dtype == x.dtype else dz.to(x.dtype)
+            frozen = spec.norm == 'bn' and not ctx.training
+            dy, g_res, sums = hip.norm_backward(dz, y, mean, rstd, gamma, beta, res, spec.act, spec.slope, prelu,
+                                                frozen=frozen, want_dres=res is not None and ctx.needs_input_grad[5])
+            if gamma is not None:
+                g_gamma, g_beta = sums[0, 1].clone(), sums[0, 0].clone()
+            if prelu is not None:
+                g_prelu = sums[:, 2].sum().view(1)
+        else:
+            x, weight, yout = ctx.saved_tensors
+            dz = dz.contiguous()
+            if spec.act != 'none':
+                if dz.dtype != x.dtype:
+                    dz = dz.to(x.dtype)
+                dy = hip.act_bwd(dz, yout, spec.act, spec.slope)
+            else:
+                dy = dz if dz.dtype == x.dtype else dz.to(x.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g_bias = hip.channel_sum(dy)
+        N, H, W, Cin = x.shape
+        wf, wb = _packed(weight, x.dtype, spec.wscale)
+        g_x = g_w = None
+        if not spec.transposed:
+            d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, ldx=Cin, ldy=hip.ld(dy), dtype=hip.dt(x))
+            if ctx.needs_input_grad[0]:
+                g_x = torch.empty(N, H, W, Cin, dtype=x.dtype, device=x.device)
+                hip.conv_dgrad(d, dy, wb, None, g_x)
+            if ctx.needs_input_grad[1]:
+                d.ldx = hip.ld(x)
+                dw = hip.conv_wgrad(d, x, dy)
+                g_w = hip.unpack_wgrad(dw, Cout, Cin, spec.k, spec.k, spec.wscale)
+        else:
+            d = hip.conv_desc((N, Ho, Wo, Cout), Cin, spec.k, spec.stride, spec.pad, ldx=hip.ld(dy), ldy=Cin,
+                              dtype=hip.dt(x), out_hw=(H, W))
+            if ctx.needs_input_grad[0]:
+                g_x = torch.empty(N, H, W, Cin, dtype=x.dtype, device=x.device)
+                hip.conv_forward(d, dy, wf, None, g_x)
+            if ctx.needs_input_grad[1]:
+                d.ldy = hip.ld(x)
+                dw = hip.conv_wgrad(d, dy, x)           # [O = Cin][T][I = Cout]
+                g_w = hip.unpack_wgrad(dw, Cin, Cout, spec.k, spec.k, spec.wscale)
+        return g_x, g_w, g_bias, g_gamma, g_beta, g_res, g_prelu, None, None, None, None
+
+
+def conv_block(x, weight, bias=None, gamma=None, beta=None, res=None, prelu=None, *, spec, training=True,
+               run_mean=None, run_var=None):
+    return _ConvBlock.apply(x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var)
+
+
+class _WAdaIN(torch.autograd.Function):
+    """model_utils.py:72-90 with EqualLR's sqrt(2/fan_in) folded into the packed 1x1 weights."""
+
+    @staticmethod
+    def forward(ctx, x, style, weight_orig, bias):
+        N, H, W, C = x.shape
+        Cs = style.shape[3]
+        scale = math.sqrt(2.0 / Cs)
+        w4 = weight_orig.view(2 * C, Cs, 1, 1)
+        wf, _ = _packed(w4, x.dtype, scale)
+        gb = torch.empty(N, H, W, 2 * C, dtype=x.dtype, device=x.device)
+        d = hip.conv_desc(style.shape, 2 * C, 1, 1, 0, ldx=hip.ld(style), ldy=2 * C, dtype=hip.dt(x))
+        hip.conv_forward(d, style, wf, bias, gb)
+        mean, rstd = hip.norm_stats(x, N, 1e-5)
+        out = torch.empty(N, H, W, C, dtype=x.dtype, device=x.device)
+        hip.adain_apply(x, mean, rstd, gb, out)
+        ctx.save_for_backward(x, style, weight_orig, gb, mean, rstd)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, style, weight_orig, gb, mean, rstd = ctx.saved_tensors
+        N, H, W, C = x.shape
+        Cs = style.shape[3]
+        dx, dgb = hip.adain_backward(dout, x, mean, rstd, gb)
+        w4 = weight_orig.view(2 * C, Cs, 1, 1)
+        _, wb = _packed(w4, x.dtype, ctx.scale)
+        d = hip.conv_desc(style.shape, 2 * C, 1, 1, 0, ldx=Cs, ldy=2 * C, dtype=hip.dt(x))
+        dstyle = torch.empty(N, H, W, Cs, dtype=x.dtype, device=x.device)
+        hip.conv_dgrad(d, dgb, wb, None, dstyle)
+        d.ldx = hip.ld(style)
+        dw = hip.conv_wgrad(d, style, dgb)
+        g_w = hip.unpack_wgrad(dw, 2 * C, Cs, 1, 1, ctx.scale).view(2 * C, Cs)
+        return dx, dstyle, g_w, hip.channel_sum(dgb)
+
+
+def wadain(x, style, weight_orig, bias):
+    return _WAdaIN.apply(x, style, weight_orig, bias)
+
+
+class _CropCat(torch.autograd.Function):
+    """rdf_generator.py:244-260: fd loses trailing rows/cols beyond fe's size, then cat((fd, fe), C)."""
+
+    @staticmethod
+    def forward(ctx, fd, fe):
+        N, He, We, Ce = fe.shape
+        Cd = fd.shape[3]
+        out = torch.empty(N, He, We, Cd + Ce, dtype=fd.dtype, device=fd.device)
+        hip.copy_window(fd, out[..., :Cd])
+        hip.copy_window(fe, out[..., Cd:])
+        ctx.fd_shape = fd.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, Hd, Wd, Cd = ctx.fd_shape
+        _, He, We, _ = dout.shape
+        g_fe = dout[..., Cd:]                       # channel slice: consumers take ld > C
+        if (Hd, Wd) == (He, We):
+            g_fd = dout[..., :Cd]
+        else:
+            g_fd = torch.zeros(N, Hd, Wd, Cd, dtype=dout.dtype, device=dout.device)
+            hip.copy_window(dout[..., :Cd], g_fd)
+        return g_fd, g_fe
+
+
+def crop_cat(fd, fe):
+    return _CropCat.apply(fd, fe)
+
+
+class _Cat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        N, H, W, Ca = a.shape
+        out = torch.empty(N, H, W, Ca + b.shape[3], dtype=a.dtype, device=a.device)
+        hip.copy_window(a, out[..., :Ca])
+        hip.copy_window(b, out[..., Ca:])
+        ctx.ca = Ca
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout[..., :ctx.ca], dout[..., ctx.ca:]
+
+
+def cat(a, b):
+    return _Cat.apply(a, b)
+
+
+class _ReflectPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pad):
+        ctx.pad = pad
+        return hip.reflect_pad(x.contiguous(), pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return hip.reflect_pad_adjoint(dy.contiguous(), ctx.pad), None
+
+
+def reflect_pad(x, pad):
+    return _ReflectPad.apply(x, pad)
+
+
+class _ToPM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        return hip.nchw_to_pm(x.float(), dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return hip.pm_to_nchw(g), None
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.dtype = x.dtype
+        return hip.pm_to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return hip.nchw_to_pm(g.contiguous(), ctx.dtype)
+
+
+def to_pm(x_nchw, dtype=None):
+    return _ToPM.apply(x_nchw, dtype or _compute_dtype)
+
+
+def to_nchw(x_pm):
+    """[N,H,W,C] -> [N,C,H,W] f32.  1-channel f32 maps are reinterpreted, not copied."""
+    if x_pm.shape[3] == 1 and x_pm.dtype == torch.float32 and x_pm.is_contiguous():
+        return x_pm.permute(0, 3, 1, 2)
+    return _ToNCHW.apply(x_pm)
+
+
+class _FusionHead(torch.autograd.Function):
+    """rdf_generator.py:400-406 on 1-channel f32 maps: clamp, softmax(2), weighted sum."""
+
+    @staticmethod
+    def forward(ctx, d1, c1, d2, c2):
+        d1, c1, d2, c2 = (t.contiguous() for t in (d1, c1, d2, c2))
+        d2c, pred = hip.fusion_head(d1, c1, d2, c2)
+        ctx.save_for_backward(d1, c1, d2, c2)
+        return d2c, pred
+
+    @staticmethod
+    def backward(ctx, g_d2c, g_pred):
+        d1, c1, d2, c2 = ctx.saved_tensors
+        g_d2c = g_d2c.contiguous() if g_d2c is not None else None
+        g_pred = g_pred.contiguous() if g_pred is not None else None
+        return tuple(hip.fusion_head_bwd(d1, c1, d2, c2, g_pred, g_d2c))
+
+
+def fusion_head(d1, c1, d2, c2):
+    return _FusionHead.apply(d1, c1, d2, c2)
+
+
+class _WeightedLoss(torch.autograd.Function):
+    """gan_loss.py L1_loss / L2_loss / mse_loss: sum_i w_i |p_i - t_i|^k, fused value + gradient."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, kind):
+        val, grad = hip.weighted_loss(pred, target, weight, kind, want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(grad)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+def weighted_loss(pred, target, weight, kind):
+    return _WeightedLoss.apply(pred, target, weight, kind)

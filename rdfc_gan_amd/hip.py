@@ -152,11 +152,13 @@ def pm_to_nchw(src):
 
 
 def copy_window(src, dst, accumulate=False):
+    """copy the common top-left window of two maps (crop when dst is smaller, zero-extension's
+    data part when dst is larger)"""
     N, Hs, Ws, Cc = src.shape
     _, Hd, Wd, Cd = dst.shape
     assert Cc == Cd and src.dtype == dst.dtype
-    _chk(lib().rdfc_copy_window(_p(src), _p(dst), N, Hs, Ws, Hd, Wd, Cc, ld(src), ld(dst), dt(src), int(accumulate), _st()),
-         'rdfc_copy_window')
+    _chk(lib().rdfc_copy_window(_p(src), _p(dst), N, Hs, Ws, Hd, Wd, min(Hs, Hd), min(Ws, Wd), Cc, ld(src), ld(dst),
+                                dt(src), int(accumulate), _st()), 'rdfc_copy_window')
     return dst
 
 

@@ -1,0 +1,118 @@
+"""Parameter-holding building blocks with upstream-identical state_dict keys whose
+forward runs the fused HIP blocks (rdfc_gan_amd.functional).
+
+The torch.nn layers inside these containers (nn.Conv2d, nn.BatchNorm2d, ...) only own
+parameters / buffers -- their own forward is never called.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fh
+from .functional import ConvSpec
+
+# >1 while one forward stands in for several identical ones (rdfc_gan.py elides upstream's dead
+# forwards): BatchNorm running statistics advance as if the forward had run BN_STAT_REPEAT times.
+BN_STAT_REPEAT = 1
+
+_ACTS = {nn.ReLU: ('relu', 0.0), nn.LeakyReLU: ('lrelu', None), nn.PReLU: ('prelu', 0.0), nn.Tanh: ('tanh', 0.0),
+         nn.Sigmoid: ('sigmoid', 0.0)}
+
+
+def _act_of(m):
+    if m is None:
+        return 'none', 0.0, None
+    name, slope = _ACTS[type(m)]
+    if name == 'lrelu':
+        slope = m.negative_slope
+    return name, slope, (m.weight if name == 'prelu' else None)
+
+
+def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
+    """conv (nn.Conv2d | nn.ConvTranspose2d) [+ norm (BatchNorm2d | InstanceNorm2d)] [+ res] [+ act module]"""
+    transposed = isinstance(conv, nn.ConvTranspose2d)
+    aname, slope, prelu = _act_of(act)
+    if norm is None:
+        nname = 'none'
+    elif isinstance(norm, nn.BatchNorm2d):
+        nname = 'bn'
+    elif isinstance(norm, nn.InstanceNorm2d):
+        nname = 'in'
+    else:
+        raise TypeError(f'unsupported norm layer {type(norm)}')
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    assert conv.kernel_size[0] == conv.kernel_size[1] and conv.dilation == (1, 1) and conv.groups == 1
+    momentum = getattr(norm, 'momentum', 0.1) or 0.1
+    if BN_STAT_REPEAT != 1:
+        momentum = 1.0 - (1.0 - momentum) ** BN_STAT_REPEAT
+    spec = ConvSpec(k, s, p, transposed, conv.output_padding[0] if transposed else 0, nname, aname, slope,
+                    eps=getattr(norm, 'eps', 1e-5), momentum=momentum, out_f32=out_f32)
+    gamma = beta = rm = rv = None
+    training = True
+    if nname == 'bn':
+        gamma, beta, rm, rv = norm.weight, norm.bias, norm.running_mean, norm.running_var
+        training = norm.training
+        if training and norm.num_batches_tracked is not None:
+            norm.num_batches_tracked += BN_STAT_REPEAT
+    return Fh.conv_block(x, conv.weight, conv.bias, gamma, beta, res, prelu, spec=spec, training=training,
+                         run_mean=rm, run_var=rv)
+
+
+class ConvSeq(nn.Sequential):
+    """nn.Sequential(conv, [norm], [act]) as built by upstream's conv_bn_relu / convt_bn_relu
+    (encoder_decoder/common.py:29-61); forward = one fused block."""
+
+    def forward(self, x, res=None, out_f32=False):
+        conv, norm, act = self[0], None, None
+        for m in list(self)[1:]:
+            if isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d)):
+                norm = m
+            else:
+                act = m
+        return run_conv(x, conv, norm, act, res, out_f32)
+
+
+def conv_bn_relu(cin, cout, kernel, stride=1, padding=0, bn=True, _in=False, relu=True):
+    assert not (bn and _in)
+    mods = [nn.Conv2d(cin, cout, kernel, stride, padding, bias=not bn)]
+    if bn:
+        mods.append(nn.BatchNorm2d(cout))
+    if _in:
+        mods.append(nn.InstanceNorm2d(cout))
+    if relu:
+        mods.append(nn.LeakyReLU(0.2, inplace=True))
+    return ConvSeq(*mods)
+
+
+def convt_bn_relu(cin, cout, kernel, stride=1, padding=0, output_padding=0, bn=True, relu=True):
+    assert kernel % 2 == 1, f'only odd kernel is supported but kernel = {kernel}'
+    mods = [nn.ConvTranspose2d(cin, cout, kernel, stride, padding, output_padding, bias=not bn)]
+    if bn:
+        mods.append(nn.BatchNorm2d(cout))
+    if relu:
+        mods.append(nn.LeakyReLU(0.2, inplace=True))
+    return ConvSeq(*mods)
+
+
+class BasicBlock(nn.Module):
+    """torchvision resnet BasicBlock (keys conv1/bn1/conv2/bn2/downsample.{0,1})."""
+    expansion = 1
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = run_conv(x, self.conv1, self.bn1, self.relu)
+        idt = x if self.downsample is None else run_conv(x, self.downsample[0], self.downsample[1], None)
+        return run_conv(y, self.conv2, self.bn2, self.relu, res=idt)
+
+
+def resnet_stage(cin, cout, stride, blocks):
+    return nn.Sequential(*[BasicBlock(cin if i == 0 else cout, cout, stride if i == 0 else 1) for i in range(blocks)])

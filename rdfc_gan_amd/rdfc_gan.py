@@ -1,0 +1,294 @@
+"""Train-step wrapper for the hot-path nets with upstream's RDFCGAN surface.
+
+Mirrors RDFC-GAN/lib/models/rdfc_gan.py (set_input :66-77, forward :184-207,
+backward_G :209-289, backward_D_basic :292-300, optimize_parameters :318-340,
+forward_test :168-182) and base.py (:28-157) for G_A2B, G_B2A, disc_A, disc_B.
+
+Outside the hot path: the surface-normal net G_normal and the label
+net G_label.  The normals they would produce enter through `normal_provider`
+(default: the batch's `gt_normal`, unit-normalised), and the label / normal /
+manhattan loss terms are not part of this step.
+
+Differences from upstream that do not change results:
+  * upstream's two dead forwards (rdfc_gan.py:197,207 -- recomputed at :228,:234) are
+    elided by default.  G_B2A has no running statistics, so its dead forward has no side
+    effect at all; G_A2B's dead forward only advances its BatchNorm running statistics a
+    second time with the very same batch statistics, which is reproduced exactly by one
+    update with momentum 1-(1-m)^2 (`exact_schedule=True` runs upstream's literal schedule).
+  * the 23 per-key `all_reduce` + `.item()` calls of Base.reduce_loss (base.py:121-132)
+    are one packed all-reduce and one device->host copy.
+  * per-step `dist.barrier()` (rdfc_gan.py:337-338) is dropped (the all-reduces order ranks).
+"""
+import itertools
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import functional as Fh
+from . import hip, layers
+from .discriminator import build_discriminator
+from .gan_loss import GANLoss, L1_loss
+from .generator import build_generator
+from .init_weights import init_weights
+from .optim import FlatAdam, broadcast_module_state
+
+
+def norm_normalize(norm_out):
+    """helper.py:404-408"""
+    n = torch.sqrt((norm_out ** 2.0).sum(1, keepdim=True)) + 1e-10
+    return norm_out / n
+
+
+def draw_pepper_mask(shape, snr=0.98, p=0.9):
+    """host RNG draw of helper.py:384-402 (python `random` + numpy), returned as uint8 (B,1,H,W) or None"""
+    if not random.uniform(0, 1) < p:
+        return None
+    b, c, h, w = shape
+    pct = 1 - snr
+    return np.random.choice((0, 1, 2), size=(b, 1, h, w), p=[snr, pct / 2., pct / 2.]).astype(np.uint8)
+
+
+class _PepperNoise(torch.autograd.Function):
+    """in-place salt/pepper (img[mask==1]=1, img[mask==2]=-1): gradient is cut at the replaced pixels"""
+
+    @staticmethod
+    def forward(ctx, img, mask_u8):
+        out = hip.apply_pepper(img.contiguous().clone(), mask_u8)
+        ctx.save_for_backward(mask_u8)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, = ctx.saved_tensors
+        return g * (mask == 0).to(g.dtype), None
+
+
+def _cfg_get(node, key, default=None):
+    if isinstance(node, dict):
+        return node.get(key, default)
+    return getattr(node, key, default)
+
+
+class RDFCGAN:
+    def __init__(self, device, distributed, args, is_train=True, fixed_training_samples=None, fixed_testing_samples=None,
+                 num_classes=14, out_height=224, out_width=304, label_wall=12, label_floor=5, label_ceiling=3,
+                 normal_provider=None, exact_schedule=False, compute_dtype=None):
+        self.device, self.distributed, self.args, self.is_train = device, distributed, args, is_train
+        self.local_rank = _cfg_get(args, 'local_rank', 0)
+        self.out_height, self.out_width = out_height, out_width
+        self.normal_provider = normal_provider
+        self.exact_schedule = exact_schedule
+        if compute_dtype is not None:
+            Fh.set_compute_dtype(compute_dtype)
+        self.init_model()
+        if self.is_train:
+            self.init_optimizer()
+            self.init_lr_scheduler()
+            self.criterionGAN = GANLoss(_cfg_get(args, 'gan_loss_type', 'lsgan')).to(device)
+            self.criterionCycle = L1_loss
+            self.criterionL1 = L1_loss
+            self.fixed_training_samples, self.fixed_testing_samples = fixed_training_samples, fixed_testing_samples
+
+    # ---- construction ------------------------------------------------------------------------
+    def init_model(self):
+        m = _cfg_get(self.args, 'model')
+        self.G_A2B = build_generator(_cfg_get(m, 'G_A2B')).to(self.device)
+        self.G_B2A = build_generator(_cfg_get(m, 'G_B2A')).to(self.device)
+        self.disc_A = build_discriminator(_cfg_get(m, 'D_A')).to(self.device)
+        self.disc_B = build_discriminator(_cfg_get(m, 'D_B')).to(self.device)
+        for net in (self.G_A2B, self.G_B2A, self.disc_A, self.disc_B):
+            init_weights(net, verbose=False)
+        self.models = dict(G_A2B=self.G_A2B, G_B2A=self.G_B2A, disc_A=self.disc_A, disc_B=self.disc_B)
+        if self.distributed:
+            # DDP-constructor semantics without DDP: same start on every rank; gradients are
+            # exchanged by FlatAdam.all_reduce_grads_async (one bucket per optimizer)
+            broadcast_module_state(self.models.values())
+
+    def init_optimizer(self):
+        a = self.args
+        lr, betas = _cfg_get(a, 'lr', 2e-3), (_cfg_get(a, 'beta1', 0.5), _cfg_get(a, 'beta2', 0.999))
+        self.optimizer_G = FlatAdam(itertools.chain(self.G_A2B.parameters(), self.G_B2A.parameters()), lr=lr, betas=betas)
+        self.optimizer_D = FlatAdam(itertools.chain(self.disc_A.parameters(), self.disc_B.parameters()), lr=lr, betas=betas)
+        self.optimizers = dict(G=self.optimizer_G, D=self.optimizer_D)
+
+    def init_lr_scheduler(self):
+        a = self.args
+        sched = str(_cfg_get(a, 'scheduler', 'linear')).lower()
+        if sched == 'linear':
+            e0, dec, n = _cfg_get(a, 'epoch', 0), _cfg_get(a, 'decay_epoch', 100), _cfg_get(a, 'n_epochs', 150)
+            make = lambda opt: torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda ep: 1.0 - max(0, ep + e0 - dec) / (n - dec))
+        elif sched == 'step':
+            make = lambda opt: torch.optim.lr_scheduler.MultiStepLR(opt, milestones=_cfg_get(a, 'lr_decay_epochs'),
+                                                                    gamma=_cfg_get(a, 'lr_decay_rate'))
+        elif sched == 'cosine':
+            make = lambda opt: torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=_cfg_get(a, 'n_epochs', 150), eta_min=0)
+        else:
+            raise NotImplementedError
+        self.lr_scheduler_G, self.lr_scheduler_D = make(self.optimizer_G), make(self.optimizer_D)
+        self.lr_schedulers = dict(G=self.lr_scheduler_G, D=self.lr_scheduler_D)
+
+    # ---- data ------------------------------------------------------------------------------------
+    def set_input(self, data):
+        dev = self.device
+        self.real_A, self.real_B = data['rgb'].to(dev), data['gt_depth'].to(dev)
+        self.aux_A = data['raw_depth'].to(dev)
+        self.gt_normal = data['gt_normal'].to(dev) if 'gt_normal' in data else None
+        self.mask = data['depth_masks'].to(dev) if 'depth_masks' in data else torch.ones_like(self.real_B)
+        self.image_loss_weight = self.mask / (self.mask.sum() + 1e-6)
+        self._batch = data
+
+    def _normal(self, tag, img):
+        if self.normal_provider is not None:
+            return norm_normalize(self.normal_provider(tag, img)[:, 0:3])
+        if self.gt_normal is None:
+            raise RuntimeError('no normal_provider and no gt_normal in the batch: the hot path takes surface normals as input')
+        return norm_normalize(self.gt_normal[:, 0:3])
+
+    # ---- inference (forward_test :168-182) -----------------------------------------------------------
+    @torch.no_grad()
+    def forward_test(self, **kwargs):
+        rgb, raw = kwargs['rgb'].to(self.device), kwargs['raw_depth'].to(self.device)
+        if 'gt_normal' in kwargs:
+            self.gt_normal = kwargs['gt_normal'].to(self.device)
+        pred_normal = self._normal('real_A', rgb)
+        ret = self.G_A2B(rgb, raw, pred_normal)
+        return dict(pred_depth=ret['pred_depth'], pred_normal=pred_normal)
+
+    def __call__(self, **kwargs):
+        return self.forward_test(**kwargs)
+
+    def generator(self):
+        return self.G_A2B
+
+    # ---- one optimisation step -----------------------------------------------------------------------
+    def set_requires_grad(self, models, requires_grad=False):
+        for m in (models if isinstance(models, list) else [models]):
+            if m is not None:
+                for p in m.parameters():
+                    p.requires_grad = requires_grad
+
+    def forward(self):
+        self.fake_B = self.G_A2B(self.real_A, self.aux_A, self._normal('real_A', self.real_A))['pred_depth']
+        mask = draw_pepper_mask(self.fake_B.shape)
+        if mask is not None:
+            self.fake_B = _PepperNoise.apply(self.fake_B, torch.from_numpy(mask).to(self.device))
+        if self.exact_schedule:
+            with torch.no_grad():
+                self.G_B2A(self.fake_B)                                          # dead forward (:197)
+        self.fake_A = self.G_B2A(self.real_B)
+        self.fake_normal_fakeA = self._normal('fake_A', self.fake_A)
+        if self.exact_schedule:
+            with torch.no_grad():
+                self.G_A2B(self.fake_A, self.aux_A, self.fake_normal_fakeA)      # dead forward (:207)
+
+    def backward_G(self):
+        a = self.args
+        lam_A, lam_B, lam_1 = _cfg_get(a, 'lambda_A', 100.0), _cfg_get(a, 'lambda_B', 100.0), _cfg_get(a, 'lambda_L1', 100.0)
+        loss_G_A2B = self.criterionGAN(self.disc_A(self.fake_B), True)
+        loss_G_B2A = self.criterionGAN(self.disc_B(self.fake_A), True)
+        loss_A2B_L1 = self.criterionL1(self.fake_B, self.real_B, weight=self.image_loss_weight) * lam_1 * 5
+        loss_B2A_L1 = self.criterionL1(self.fake_A, self.real_A, weight=self.image_loss_weight) * lam_1 * 3
+        rec_A = self.G_B2A(self.fake_B)
+        loss_cycle_A2B = self.criterionCycle(rec_A, self.real_A) * lam_A
+        fakeA_normal = self._normal('fake_A_again', self.fake_A)
+        layers.BN_STAT_REPEAT = 1 if self.exact_schedule else 2                  # stands in for the elided dead forward
+        try:
+            rec_B = self.G_A2B(self.fake_A, self.aux_A, fakeA_normal)['pred_depth']
+        finally:
+            layers.BN_STAT_REPEAT = 1
+        loss_cycle_B2A = self.criterionCycle(rec_B, self.real_B, weight=self.image_loss_weight) * lam_B
+        loss_G = loss_G_A2B + loss_cycle_A2B + loss_cycle_B2A + loss_G_B2A + loss_A2B_L1 + loss_B2A_L1
+        loss_G.backward()
+        return dict(loss_G=loss_G, loss_G_A2B=loss_G_A2B, loss_G_B2A=loss_G_B2A, loss_B2A_L1=loss_B2A_L1,
+                    loss_A2B_L1=loss_B2A_L1,          # upstream logs B2A under this key (rdfc_gan.py:276)
+                    loss_cycle_A=loss_cycle_A2B, loss_cycle_B=loss_cycle_B2A)
+
+    def backward_D_basic(self, model_D, real, fake):
+        loss_D_real = self.criterionGAN(model_D(real), True)
+        loss_D_fake = self.criterionGAN(model_D(fake.detach()), False)
+        loss_D = (loss_D_real + loss_D_fake) * 0.5
+        loss_D.backward()
+        return loss_D_real, loss_D_fake, loss_D
+
+    def backward_D_A2B(self):
+        r, f, d = self.backward_D_basic(self.disc_A, self.real_B, self.fake_B)
+        return dict(loss_D_A=d, loss_D_A_real=r, loss_D_A_fake=f)
+
+    def backward_D_B2A(self):
+        r, f, d = self.backward_D_basic(self.disc_B, self.real_A, self.fake_A)
+        return dict(loss_D_B=d, loss_D_B_real=r, loss_D_B_fake=f)
+
+    def optimize_parameters(self, sync_losses=True):
+        loss_stats = {}
+        self.forward()
+        self.set_requires_grad([self.disc_A, self.disc_B], False)
+        self.optimizer_G.zero_grad()
+        loss_stats.update(self.backward_G())
+        # G gradients fly over xGMI on the side stream while the D step computes
+        self.optimizer_G.all_reduce_grads_async()
+        self.set_requires_grad([self.disc_A, self.disc_B], True)
+        self.optimizer_D.zero_grad()
+        loss_stats.update(self.backward_D_A2B())
+        loss_stats.update(self.backward_D_B2A())
+        self.optimizer_D.all_reduce_grads_async()
+        self.optimizer_G.step()
+        self.optimizer_D.step()
+        return self.reduce_loss(loss_stats) if sync_losses else loss_stats
+
+    def reduce_loss(self, loss):
+        """base.py:121-132 semantics (mean over ranks, python floats) with one collective and one D2H copy"""
+        keys = list(loss)
+        packed = torch.stack([loss[k].detach().float().reshape(()) for k in keys])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            packed = packed / dist.get_world_size()
+            dist.all_reduce(packed)
+        return dict(zip(keys, packed.tolist()))
+
+    # ---- mode / lr / checkpoints (base.py:74-117; lib/utils/checkpoint.py:21-58,113-166) -----------------------
+    def eval(self):
+        for m in self.models.values():
+            m.eval()
+
+    def train(self):
+        for m in self.models.values():
+            m.train()
+
+    def update_learning_rate(self):
+        for s in self.lr_schedulers.values():
+            s.step()
+
+    def save_ckpt(self, filename, meta=None):
+        ckpt = dict(meta=meta or {})
+        for name, m in self.models.items():
+            ckpt[f'{name}_state_dict'] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        if self.is_train:
+            for name, o in self.optimizers.items():
+                ckpt[f'{name}_optimizer_state_dict'] = o.state_dict()
+            for name, s in self.lr_schedulers.items():
+                ckpt[f'{name}_lr_scheduler_state_dict'] = s.state_dict()
+        torch.save(ckpt, filename)
+
+    def load_from(self, load_path, strict=False):
+        ckpt = torch.load(load_path, map_location='cpu')
+        for name, m in self.models.items():
+            if f'{name}_state_dict' in ckpt:
+                sd = {k[7:] if k.startswith('module.') else k: v for k, v in ckpt[f'{name}_state_dict'].items()}
+                m.load_state_dict(sd, strict=strict)
+        Fh.invalidate_packed_weights()
+        return ckpt
+
+    def resume_from(self, resume_path):
+        ckpt = self.load_from(resume_path, strict=True)
+        for name, o in self.optimizers.items():
+            if f'{name}_optimizer_state_dict' in ckpt:
+                o.load_state_dict(ckpt[f'{name}_optimizer_state_dict'])
+        for name, s in self.lr_schedulers.items():
+            if f'{name}_lr_scheduler_state_dict' in ckpt:
+                s.load_state_dict(ckpt[f'{name}_lr_scheduler_state_dict'])
+        return ckpt['meta'].get('epoch', 0)
+
+    def save_samples(self, save_dir, iters):
+        """visualisation dumps are outside the hot path (rdfc_gan.py:342-410)"""
+        return None

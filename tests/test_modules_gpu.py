@@ -1,0 +1,218 @@
+"""GPU: the HIP-backed modules (rdfc_gan_amd) against the golden fixtures generated from the
+upstream reference, and against the CPU oracle on the same seeded inputs.
+
+f32 mode (exact-f32 MFMA) is the parity mode: tolerances below are fp32-reordering sized.
+bf16 mode (the benchmarked configuration) is checked against the same references with
+bf16-sized tolerances, including the north-star acceptance metric (dense-depth RMSE
+within 1e-3 of the reference).
+"""
+import numpy as np
+import pytest
+import torch
+
+from cases import NLSPN_CFG, STEP_HP, gen_inputs, grad_summary, out_weights, step_batch
+from detweights import det_state_dict, det_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def setup_dtype(dtype):
+    from rdfc_gan_amd import functional as Fh
+    Fh.set_compute_dtype(dtype)
+    Fh.invalidate_packed_weights()
+
+
+def run(net, inputs, tag):
+    res = {}
+    net.eval()
+    with torch.no_grad():
+        o = net(*inputs)
+    o = o if isinstance(o, dict) else {'out': o}
+    res.update({f'eval.{k}': v for k, v in o.items()})
+    net.train()
+    ins = [t.clone().requires_grad_(True) for t in inputs]
+    o = net(*ins)
+    o = o if isinstance(o, dict) else {'out': o}
+    loss = 0
+    for k, v in o.items():
+        res[f'train.{k}'] = v
+        loss = loss + (v * out_weights(tag, k, v.shape).to(DEV)).sum()
+    loss.backward()
+    for i, t in enumerate(ins):
+        if t.grad is not None:
+            res[f'grad_in.{i}'] = t.grad
+    return res
+
+
+def err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max()), float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def check(net, res, g, out_atol, grad_rel, buf_rtol):
+    report = []
+    for k in g.files:
+        if k.startswith(('eval.', 'train.')):
+            e_abs, _ = err(res[k].detach().cpu().numpy(), g[k])
+            report.append((k, e_abs))
+            assert e_abs < out_atol, f'{k}: max abs err {e_abs:.3e} >= {out_atol}'
+        elif k.startswith('grad_in.'):
+            _, e_rel = err(res[k].detach().cpu().numpy(), g[k])
+            report.append((k, e_rel))
+            assert e_rel < grad_rel, f'{k}: rel err {e_rel:.3e} >= {grad_rel}'
+        elif k.startswith('grad.'):
+            got = dict(net.named_parameters())[k[5:]].grad.detach().cpu().numpy()
+            _, e_rel = err(got, g[k])
+            report.append((k, e_rel))
+            assert e_rel < grad_rel, f'{k}: rel err {e_rel:.3e} >= {grad_rel}'
+    names, summ = grad_summary(net)
+    ref = dict(zip(g['grad_names'], g['grad_summary'][:, 1]))
+    assert sorted(names) == sorted(ref)
+    rel = np.array([abs(s - ref[n]) / (abs(ref[n]) + 1e-8) for n, s in zip(names, summ[:, 1]) if abs(ref[n]) > 1e-6])
+    assert np.median(rel) < grad_rel and rel.max() < 10 * grad_rel, f'param-grad norms: median {np.median(rel):.3e} max {rel.max():.3e}'
+    sd = net.state_dict()
+    bs = np.array([[float(sd[k].sum()), float(sd[k].norm())] for k in g['buf_names']])
+    if len(bs):
+        np.testing.assert_allclose(bs[:, 1], g['buf_summary'][:, 1], rtol=buf_rtol, atol=1e-4)
+    return report
+
+
+TOLS = {torch.float32: dict(out_atol=2e-3, grad_rel=2e-3, buf_rtol=1e-3),
+        torch.bfloat16: dict(out_atol=0.12, grad_rel=0.12, buf_rtol=2e-2)}
+DT = [torch.float32, torch.bfloat16]
+IDS = ['f32', 'bf16']
+
+
+@pytest.mark.parametrize('dtype', DT, ids=IDS)
+@pytest.mark.parametrize('nlspn,name', [(False, 'g_a2b_small'), (True, 'g_a2b_nlspn_small')])
+def test_g_a2b(golden, nlspn, name, dtype):
+    from rdfc_gan_amd.generator import RDFGenerator
+    setup_dtype(dtype)
+    net = RDFGenerator(pretrained_on_imagenet=False, use_nlspn_refine=nlspn, nlspn_configs=NLSPN_CFG)
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    net.to(DEV)
+    rgb, depth, normal = (t.to(DEV) for t in gen_inputs('g_a2b', 2, 60, 76))
+    res = run(net, (rgb, depth, normal), name)
+    res.pop('grad_in.0', None)
+    tol = dict(TOLS[dtype])
+    if nlspn:            # 18 propagation steps amplify rounding (oracle vs upstream already differ by 2e-3 here)
+        tol = {k: v * 5 for k, v in tol.items()}
+    print(check(net, res, golden(name), **tol))
+
+
+@pytest.mark.parametrize('dtype', DT, ids=IDS)
+def test_g_b2a(golden, dtype):
+    from rdfc_gan_amd.generator import ResnetGenerator
+    setup_dtype(dtype)
+    net = ResnetGenerator(1, 3, 64, 'IN2d')
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    net.to(DEV)
+    x = gen_inputs('g_b2a', 2, 60, 76)[1].to(DEV)
+    print(check(net, run(net, (x,), 'g_b2a_small'), golden('g_b2a_small'), **TOLS[dtype]))
+
+
+@pytest.mark.parametrize('dtype', DT, ids=IDS)
+@pytest.mark.parametrize('cin,name', [(1, 'd_a_small'), (3, 'd_b_small')])
+def test_patchgan(golden, cin, name, dtype):
+    from rdfc_gan_amd.discriminator import PatchGANDiscriminator
+    setup_dtype(dtype)
+    net = PatchGANDiscriminator(cin, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    net.to(DEV)
+    x = det_tensor(3, f'disc{cin}', (2, cin, 60, 76)).to(DEV)
+    print(check(net, run(net, (x,), name), golden(name), **TOLS[dtype]))
+
+
+@pytest.mark.parametrize('dtype', DT, ids=IDS)
+def test_g_a2b_full_resolution_odd_sizes(golden, dtype):
+    """B=1, 228x304: 228->114->57->29->15 and the trailing-row crops of `_concat`."""
+    from rdfc_gan_amd.generator import RDFGenerator
+    setup_dtype(dtype)
+    g = golden('g_a2b_full_b1')
+    net = RDFGenerator(pretrained_on_imagenet=False)
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    net.to(DEV)
+    rgb, depth, normal = (t.to(DEV) for t in gen_inputs('g_a2b', 1, 228, 304))
+    res = run(net, (rgb, depth, normal), 'g_a2b_full_b1')
+    res.pop('grad_in.0', None)
+    print(check(net, res, g, **TOLS[dtype]))
+    # north-star acceptance metric: dense-depth RMSE (metres, x5+5 de-normalised) within 1e-3 of the reference's
+    gt = (torch.from_numpy(g['eval.pred_depth']) * 0.9 + 0.02) * 5 + 5      # any fixed "ground truth"
+    ours = res['eval.pred_depth'].cpu() * 5 + 5
+    ref = torch.from_numpy(g['eval.pred_depth']) * 5 + 5
+    rmse = lambda p: float(((p - gt) ** 2).mean().sqrt())
+    assert abs(rmse(ours) - rmse(ref)) < 1e-3, (rmse(ours), rmse(ref))
+
+
+@pytest.mark.parametrize('exact', [True, False], ids=['exact_schedule', 'dead_forwards_elided'])
+def test_train_step_against_upstream_trace(golden, exact):
+    """Two optimisation steps of the HIP RDFCGAN (f32 mode) against the trace recorded from upstream's own
+    RDFCGAN.optimize_parameters (tests/golden/step_trace.npz)."""
+    import random
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    setup_dtype(torch.float32)
+    g = golden('step_trace')
+    hp = STEP_HP
+    cfg = dict(local_rank=0, lr=hp['lr'], beta1=hp['beta1'], beta2=hp['beta2'], gan_loss_type='lsgan', scheduler='linear',
+               epoch=0, decay_epoch=100, n_epochs=150, lambda_A=hp['lambda_A'], lambda_B=hp['lambda_B'], lambda_L1=hp['lambda_L1'],
+               model=dict(G_A2B=dict(type='RDFGenerator', pretrained_on_imagenet=False),
+                          G_B2A=dict(type='ResnetGenerator', input_channels=1, output_channels=3, ngf=64, norm_layer='IN2d'),
+                          D_A=dict(type='PatchGANDiscriminator', in_channels=1, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'),
+                          D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')))
+    normals = {}
+    m = RDFCGAN(torch.device(DEV), False, cfg, is_train=True, exact_schedule=exact,
+                normal_provider=lambda tag, img: normals[tag])
+    for key, net in m.models.items():
+        net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    from rdfc_gan_amd import functional as Fh
+    Fh.invalidate_packed_weights()
+    m.train()
+    for it in range(2):
+        data, nA, nfA = step_batch(it, hp['B'], hp['H'], hp['W'])
+        normals.update(real_A=nA.to(DEV), fake_A=nfA.to(DEV), fake_A_again=nfA.to(DEV))
+        random.seed(100 + it)
+        np.random.seed(100 + it)
+        m.set_input(data)
+        ls = m.optimize_parameters()
+        extra = float(g[f'loss_extra.{it}'])
+        for k, v in zip(g[f'loss_names.{it}'], g[f'loss_values.{it}']):
+            ref = v - extra if k == 'loss_G' else v
+            assert abs(ls[k] - ref) <= 2e-3 * abs(ref) + 1e-4, f'step {it} {k}: {ls[k]} vs {ref}'
+        np.testing.assert_allclose(m.fake_B.detach().cpu().numpy(), g[f'fake_B.{it}'], atol=5e-3)
+        np.testing.assert_allclose(m.fake_A.detach().cpu().numpy(), g[f'fake_A.{it}'], atol=5e-3)
+        for key, net in m.models.items():
+            sd = net.state_dict()
+            got = np.array([float(sd[k].double().norm()) for k in g[f'sd_names.{key}']])
+            np.testing.assert_allclose(got, g[f'sd_summary.{key}.{it}'][:, 1], rtol=5e-3, atol=2e-4, err_msg=f'step {it} {key}')
+
+
+def test_train_step_bf16_runs_and_tracks_f32():
+    """bf16 (benchmark) configuration: finite losses close to the f32 parity mode on the same batch."""
+    import random
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    from rdfc_gan_amd import functional as Fh
+    hp = STEP_HP
+    cfg = dict(local_rank=0, lr=hp['lr'], beta1=0.5, beta2=0.999, gan_loss_type='lsgan',
+               model=dict(G_A2B=dict(type='RDFGenerator', pretrained_on_imagenet=False),
+                          G_B2A=dict(type='ResnetGenerator', input_channels=1, output_channels=3, ngf=64, norm_layer='IN2d'),
+                          D_A=dict(type='PatchGANDiscriminator', in_channels=1, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'),
+                          D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')))
+    out = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        setup_dtype(dtype)
+        m = RDFCGAN(torch.device(DEV), False, cfg, is_train=True)
+        for key, net in m.models.items():
+            net.load_state_dict(det_state_dict(net.state_dict(), 0))
+        Fh.invalidate_packed_weights()
+        m.train()
+        data, nA, _ = step_batch(0, hp['B'], hp['H'], hp['W'])
+        data['gt_normal'] = nA
+        random.seed(5)
+        np.random.seed(5)
+        m.set_input(data)
+        out[dtype] = m.optimize_parameters()
+    for k, v in out[torch.bfloat16].items():
+        assert np.isfinite(v), k
+        ref = out[torch.float32][k]
+        assert abs(v - ref) <= 0.08 * abs(ref) + 0.02, f'{k}: bf16 {v} vs f32 {ref}'
