@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- RGB-D pairs/s per train step (G+D) of the RDFC-GAN hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = RDFCGAN.optimize_parameters on one synthetic batch (8 pairs per GPU at 228x304,
+BASELINE.json configs[1]): G_A2B + G_B2A + D_A + D_B forward, backward, Adam.  Weak scaling: every
+rank draws its own shard; gradients are all-reduced with RCCL on a side stream.
+Prints ONE JSON line (rank 0) with the metric, a roofline block for the dominant kernel family
+(per-launch HIP events inside the timed region) and a CPU baseline (the oracle timed on the host).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# forward GFLOP per pair (2*MAC over conv / conv-transpose / linear) at 228x304
+GFLOP_FWD = dict(G_A2B=209.64, G_B2A=73.28, D_A=6.49, D_B=6.56)
+PEAK_TFLOPS = dict(bf16=2500.0, f32=157.3)        # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def step_gflop_per_pair(exact_schedule, scale=1.0):
+    """G nets: fwd x3 (x2 when the dead forwards are elided) + bwd x2 (bwd = 2x fwd);
+    D nets: fwd x3 + input-gradient-only pass x1 + full bwd x2."""
+    nf = 3 if exact_schedule else 2
+    g = (GFLOP_FWD['G_A2B'] + GFLOP_FWD['G_B2A']) * (nf + 2 * 2)
+    d = (GFLOP_FWD['D_A'] + GFLOP_FWD['D_B']) * (3 + 1 + 2 * 2)
+    return (g + d) * scale
+
+
+def synth_batch(B, H, W, seed, device):
+    """NYUv2-shaped synthetic batch (same keys / ranges as the upstream loader)."""
+    g = torch.Generator().manual_seed(seed)
+    rgb = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    m = (2.84 + 0.99 * torch.randn(B, 1, H, W, generator=g))
+    m = F.avg_pool2d(F.pad(m, (4, 4, 4, 4), mode='replicate'), 9, 1).clamp(0.713, 9.995)
+    gt = (m - 5.0) / 5.0
+    raw = gt.clone()
+    for b in range(B):                      # ~30 % of the pixels in random rectangles -> 0 m -> -1.0
+        for _ in range(6):
+            y0, x0 = int(torch.randint(0, H - 8, (1,), generator=g)), int(torch.randint(0, W - 8, (1,), generator=g))
+            hh, ww = int(torch.randint(8, H // 3, (1,), generator=g)), int(torch.randint(8, W // 3, (1,), generator=g))
+            raw[b, :, y0:y0 + hh, x0:x0 + ww] = -1.0
+    normal = F.normalize(torch.randn(B, 3, H, W, generator=g), dim=1)
+    data = dict(rgb=rgb, gt_depth=gt, raw_depth=raw, depth_masks=m > 1e-4, gt_normal=normal,
+                labels=torch.zeros(B, H, W, dtype=torch.long), normal_masks=torch.ones(B, 1, H, W))
+    return {k: v.to(device) for k, v in data.items()}
+
+
+def model_cfg(nlspn):
+    from cases import NLSPN_CFG
+    ga2b = dict(type='RDFGenerator', pretrained_on_imagenet=False)
+    if nlspn:
+        ga2b.update(use_nlspn_refine=True, nlspn_configs=NLSPN_CFG)
+    return dict(local_rank=int(os.environ.get('LOCAL_RANK', 0)), lr=2e-3, beta1=0.5, beta2=0.999, gan_loss_type='lsgan',
+                lambda_A=100.0, lambda_B=100.0, lambda_L1=100.0,
+                model=dict(G_A2B=ga2b,
+                           G_B2A=dict(type='ResnetGenerator', input_channels=1, output_channels=3, ngf=64, norm_layer='IN2d'),
+                           D_A=dict(type='PatchGANDiscriminator', in_channels=1, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'),
+                           D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')))
+
+
+def cpu_baseline(H, W, exact_schedule, budget_s=40.0):
+    """The oracle's train step (plain torch.nn on the host cores), bounded sample: batch 1, full
+    resolution, one untimed-free step (first step includes no lazy init worth excluding)."""
+    from oracle import nets as onets
+    from oracle.step import HotPathStep
+    torch.manual_seed(0)
+    B = 1
+    nets = (onets.RDFGenerator(), onets.ResnetGenerator(1, 3, 64, 'IN2d'), onets.PatchGANDiscriminator(1),
+            onets.PatchGANDiscriminator(3))
+    for n in nets:
+        n.train()
+    st = HotPathStep(*nets)
+    data = synth_batch(B, H, W, 999, 'cpu')
+    st.set_input(data)
+    nrm = data['gt_normal']
+    t0 = time.perf_counter()
+    st.step(lambda tag: nrm)
+    dt_ = time.perf_counter() - t0
+    return dict(value=round(B / dt_, 5), unit='pairs/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'1 train step (upstream schedule incl. dead forwards), batch {B}, {H}x{W}, fp32 torch CPU oracle, '
+                       f'{dt_:.1f} s wall')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='pairs per GPU')
+    ap.add_argument('--height', type=int, default=228)
+    ap.add_argument('--width', type=int, default=304)
+    ap.add_argument('--dtype', choices=('bf16', 'f32'), default='bf16')
+    ap.add_argument('--nlspn', action='store_true', help='BASELINE configs[2]: NLSPN refinement on')
+    ap.add_argument('--exact-schedule', action='store_true', help="run upstream's two dead forwards too")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (there is no CPU fallback for the HIP path)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+
+    from rdfc_gan_amd import functional as Fh
+    from rdfc_gan_amd import hip
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    Fh.set_compute_dtype(torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
+    torch.manual_seed(0)
+    random.seed(1234 + rank)
+    np.random.seed(1234 + rank)
+    model = RDFCGAN(dev, world > 1, model_cfg(a.nlspn), is_train=True, exact_schedule=a.exact_schedule)
+    model.train()
+    batches = [synth_batch(a.batch, a.height, a.width, 1234 + rank * 100 + i, dev) for i in range(2)]
+
+    def one_step(i):
+        model.set_input(batches[i % len(batches)])
+        return model.optimize_parameters(sync_losses=False)
+
+    for i in range(a.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not a.no_kernel_events:
+        hip.PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        losses = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, hip.PROFILE = hip.PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final = model.reduce_loss(losses)
+    assert all(np.isfinite(v) for v in final.values()), f'non-finite losses: {final}'
+
+    if rank == 0:
+        scale = (a.height * a.width) / (228.0 * 304.0)
+        gflop_pair = step_gflop_per_pair(a.exact_schedule, scale)
+        pairs_s = world * a.batch * a.steps / elapsed
+        out = dict(metric='RGB-D pairs/sec per train step (G+D), NYUv2 304x228', value=round(pairs_s, 3), unit='pairs/s',
+                   n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * elapsed / a.steps, 3),
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.dtype, data='synthetic',
+                   config=dict(workload=f'RDFCGAN.optimize_parameters: G_A2B(RDFGenerator, NLSPN {"on" if a.nlspn else "off"}) + '
+                                        f'G_B2A(ResnetGenerator IN2d) + D_A + D_B (PatchGAN), fwd+bwd+Adam, {a.height}x{a.width}, '
+                                        f'batch {a.batch}/GPU, random-init weights',
+                               global_batch=world * a.batch, parallelism=f'dp{world}',
+                               dead_forwards='executed' if a.exact_schedule else 'elided (result-identical, see DESIGN.md)',
+                               step_gflop_per_pair=round(gflop_pair, 1)),
+                   step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
+                   step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
+        if prof:
+            fam = {}
+            for name, flops, e0, e1 in prof:
+                d = fam.setdefault(name, [0.0, 0.0, 0])
+                d[0] += flops
+                d[1] += e0.elapsed_time(e1) * 1e-3
+                d[2] += 1
+            top = max(fam, key=lambda k: fam[k][1])
+            fl, sec, n = fam[top]
+            peak = PEAK_TFLOPS[a.dtype]
+            out['roofline'] = dict(bound='mfma', kernel=top, achieved=round(fl / sec / 1e12, 2), peak=peak, unit='TFLOP/s',
+                                   frac=round(fl / sec / 1e12 / peak, 4), traffic=None, launches=n,
+                                   avg_launch_us=round(1e6 * sec / n, 2),
+                                   share_of_step=round(sec / (elapsed / 1.0), 4))
+            out['kernel_families'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), seconds=round(v[1], 4), launches=v[2],
+                                              share_of_step=round(v[1] / elapsed, 4)) for k, v in sorted(fam.items())}
+        if not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.height, a.width, True)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -28,6 +28,28 @@ from . import nlspn as _nlspn
 # --------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------
+def instance_norm(x, eps=1e-5):
+    """InstanceNorm2d (no affine, biased variance) written out with elementwise ops.
+
+    Deliberately NOT F.instance_norm: the PyTorch 2.10 CPU kernel behind it returns wrong
+    input gradients when the incoming cotangent is channels-last strided, which happens at
+    batch size 1 behind a ConvTranspose2d (found while pinning this oracle: autograd result
+    differs from the closed form by O(1); see DESIGN.md "Oracle").  Forward values are identical."""
+    mu = x.mean((2, 3), keepdim=True)
+    var = x.var((2, 3), unbiased=False, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps)
+
+
+class _IN(nn.Module):
+    """parameter-free stand-in for nn.InstanceNorm2d(c) (no state_dict entries either way)"""
+
+    def __init__(self, c=None):
+        super().__init__()
+
+    def forward(self, x):
+        return instance_norm(x)
+
+
 def _cna(cin, cout, k, s=1, p=0, bn=True, act=True):
     """conv [+BN] [+LeakyReLU(0.2)]  (common.py:29-43); conv bias iff no BN."""
     mods = [nn.Conv2d(cin, cout, k, s, p, bias=not bn)]
@@ -119,7 +141,7 @@ class WAdaIN(nn.Module):
     def forward(self, x, style):
         gb = self.style.linear(style.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
         gamma, beta = gb[:, :self.c], gb[:, self.c:]
-        return gamma * F.instance_norm(x, eps=1e-5) + beta
+        return gamma * instance_norm(x) + beta
 
 
 def _crop_cat(fd, fe):
@@ -195,8 +217,8 @@ class _ResBlk(nn.Module):
     def __init__(self, c):
         super().__init__()
         self.conv_block = nn.Sequential(
-            nn.ReflectionPad2d(1), nn.Conv2d(c, c, 3), nn.InstanceNorm2d(c), nn.LeakyReLU(0.01),
-            nn.ReflectionPad2d(1), nn.Conv2d(c, c, 3), nn.InstanceNorm2d(c))
+            nn.ReflectionPad2d(1), nn.Conv2d(c, c, 3), _IN(c), nn.LeakyReLU(0.01),
+            nn.ReflectionPad2d(1), nn.Conv2d(c, c, 3), _IN(c))
 
     def forward(self, x):
         return x + self.conv_block(x)
@@ -208,14 +230,14 @@ class ResnetGenerator(nn.Module):
     def __init__(self, input_channels=1, output_channels=3, ngf=64, norm_layer='IN2d', n_blocks=6, **_unused):
         super().__init__()
         assert norm_layer.lower() == 'in2d', 'oracle covers the shipped IN2d configuration'
-        m = [nn.ReflectionPad2d(3), nn.Conv2d(input_channels, ngf, 7), nn.InstanceNorm2d(ngf), nn.LeakyReLU(0.01)]
+        m = [nn.ReflectionPad2d(3), nn.Conv2d(input_channels, ngf, 7), _IN(ngf), nn.LeakyReLU(0.01)]
         c = ngf
         for _ in range(2):
-            m += [nn.Conv2d(c, 2 * c, 3, 2, 1), nn.InstanceNorm2d(2 * c), nn.PReLU(init=0.25)]
+            m += [nn.Conv2d(c, 2 * c, 3, 2, 1), _IN(2 * c), nn.PReLU(init=0.25)]
             c *= 2
         m += [_ResBlk(c) for _ in range(n_blocks)]
         for _ in range(2):
-            m += [nn.ConvTranspose2d(c, c // 2, 3, 2, 1, 1), nn.InstanceNorm2d(c // 2), nn.PReLU(init=0.25)]
+            m += [nn.ConvTranspose2d(c, c // 2, 3, 2, 1, 1), _IN(c // 2), nn.PReLU(init=0.25)]
             c //= 2
         m += [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_channels, 7), nn.Tanh()]
         self.model = nn.Sequential(*m)

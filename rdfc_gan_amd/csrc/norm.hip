@@ -167,14 +167,15 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
 #pragma unroll
     for (int v = 0; v < VEC; ++v) s[0][v] = s[1][v] = s[2][v] = 0.f;
     if (cx.active) {
-        float ga[VEC], be[VEC], mu[VEC], rs[VEC];
+        float sc[VEC], sh[VEC], mu[VEC], rs[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const int c = cx.c0 + v;
-            ga[v] = a.gamma ? a.gamma[c] : 1.f;
-            be[v] = a.beta ? a.beta[c] : 0.f;
+            const float ga = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
             rs[v] = a.rstd[cx.g * m.C + c];
             mu[v] = a.mean[cx.g * m.C + c];
+            sc[v] = ga * rs[v];                 // the forward's (apply_kernel) pre-activation, bit for bit,
+            sh[v] = be - mu[v] * ga * rs[v];    // so the activation mask cannot disagree with the forward
         }
         const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
         const size_t gb = (size_t)cx.g * m.P;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const float xh = (xv.get(v) - mu[v]) * rs[v];
-                float u = ga[v] * xh + be[v];
+                float u = sc[v] * xv.get(v) + sh[v];
                 if (res) u += rv.get(v);
                 const float d = dv.get(v);
                 const float du = d * act_grad_pre(u, a.act, slope);
@@ -216,15 +217,17 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     if (!cx.active) return;
-    float ga[VEC], be[VEC], mu[VEC], rs[VEC], m1[VEC], m2[VEC];
+    float ga[VEC], sc[VEC], sh[VEC], mu[VEC], rs[VEC], m1[VEC], m2[VEC];
     const float invP = 1.f / (float)m.P;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         const int c = cx.c0 + v;
         ga[v] = a.gamma ? a.gamma[c] : 1.f;
-        be[v] = a.beta ? a.beta[c] : 0.f;
+        const float be = a.beta ? a.beta[c] : 0.f;
         rs[v] = a.rstd[cx.g * m.C + c];
         mu[v] = a.mean[cx.g * m.C + c];
+        sc[v] = ga[v] * rs[v];
+        sh[v] = be - mu[v] * ga[v] * rs[v];
         m1[v] = frozen ? 0.f : sums[(cx.g * 3 + 0) * m.C + c] * invP;
         m2[v] = frozen ? 0.f : sums[(cx.g * 3 + 1) * m.C + c] * invP;
     }
@@ -238,10 +241,10 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const float xh = (xv.get(v) - mu[v]) * rs[v];
-            float u = ga[v] * xh + be[v];
+            float u = sc[v] * xv.get(v) + sh[v];
             if (res) u += rv.get(v);
             const float du = dv.get(v) * act_grad_pre(u, a.act, slope);
-            o.set(v, ga[v] * rs[v] * (du - m1[v] - xh * m2[v]));
+            o.set(v, sc[v] * (du - m1[v] - xh * m2[v]));
             orr.set(v, du);
         }
         o.store(dx + (gb + p) * lddx + cx.c0);

@@ -12,6 +12,7 @@ Blocks
   reflect_pad, to_pm / to_nchw, fusion_head
 """
 import math
+import os
 
 import torch
 
@@ -228,8 +229,12 @@ class _CropCat(torch.autograd.Function):
         N, Hd, Wd, Cd = ctx.fd_shape
         _, He, We, _ = dout.shape
         g_fe = dout[..., Cd:]                       # channel slice: consumers take ld > C
+        if os.environ.get('RDFC_DEBUG_CONTIG'):
+            g_fe = g_fe.contiguous()
         if (Hd, Wd) == (He, We):
             g_fd = dout[..., :Cd]
+            if os.environ.get('RDFC_DEBUG_CONTIG'):
+                g_fd = g_fd.contiguous()
         else:
             g_fd = torch.zeros(N, Hd, Wd, Cd, dtype=dout.dtype, device=dout.device)
             hip.copy_window(dout[..., :Cd], g_fd)

@@ -17,6 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librdfc_hip.so')
 
 F32, BF16 = 0, 1
+# bench.py sets this to a list: every conv launch then appends (family, algorithmic flops, start, end) with
+# HIP events recorded on the launch stream (per-kernel roofline measured inside the timed region)
+PROFILE = None
 ACT = dict(none=0, relu=1, lrelu=2, tanh=3, sigmoid=4, prelu=5)
 _lib = None
 
@@ -117,19 +120,44 @@ def unpack_wgrad(dw_packed, O, I, KH, KW, scale=1.0):
     return g
 
 
+def _conv_flops(d):
+    return 2.0 * d.N * d.Ho * d.Wo * d.Co * d.Ci * d.KH * d.KW
+
+
+class _Timed:
+    """records a HIP event pair around one launch when PROFILE is active"""
+
+    def __init__(self, family, d):
+        self.on = PROFILE is not None
+        if self.on:
+            self.rec = (family, _conv_flops(d), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def __enter__(self):
+        if self.on:
+            self.rec[2].record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.rec[3].record()
+            PROFILE.append(self.rec)
+
+
 def conv_forward(d, x, w_fwd, bias, y):
-    _chk(lib().rdfc_conv2d_forward(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _st()), 'rdfc_conv2d_forward')
+    with _Timed('igemm_kernel (conv fwd / dgrad)', d):
+        _chk(lib().rdfc_conv2d_forward(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _st()), 'rdfc_conv2d_forward')
     return y
 
 
 def conv_dgrad(d, dy, w_bwd, bias, dx):
-    _chk(lib().rdfc_conv2d_dgrad(C.byref(d), _p(dy), _p(w_bwd), _p(bias), _p(dx), _st()), 'rdfc_conv2d_dgrad')
+    with _Timed('igemm_kernel (conv fwd / dgrad)', d):
+        _chk(lib().rdfc_conv2d_dgrad(C.byref(d), _p(dy), _p(w_bwd), _p(bias), _p(dx), _st()), 'rdfc_conv2d_dgrad')
     return dx
 
 
 def conv_wgrad(d, x, dy):
     dw = torch.zeros(d.Co, d.KH * d.KW, d.Ci, dtype=torch.float32, device=x.device)
-    _chk(lib().rdfc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _st()), 'rdfc_conv2d_wgrad')
+    with _Timed('wgrad_kernel (conv weight grad)', d):
+        _chk(lib().rdfc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _st()), 'rdfc_conv2d_wgrad')
     return dw
 
 

@@ -82,3 +82,11 @@ def pepper_mask(seed, shape):
     snr = 0.98
     pct = 1 - snr
     return np.random.choice((0, 1, 2), size=(b, 1, h, w), p=[snr, pct / 2., pct / 2.])
+
+
+def noise_driven(net_key, param_key):
+    """Parameters whose gradient is analytically zero (a conv bias in front of an InstanceNorm in
+    G_B2A): autograd returns rounding noise for them and Adam turns that noise into lr-sized
+    updates, upstream included -- their trajectories are not comparable between implementations
+    (and they cannot influence any output)."""
+    return net_key == 'G_B2A' and param_key.endswith('.bias') and param_key != 'model.23.bias'

@@ -82,7 +82,7 @@ def g_b2a(B, H, W, name):
     net = RB(1, 3, 64, 'IN2d')
     net.load_state_dict(det_state_dict(net.state_dict(), 0))
     x = gen_inputs('g_b2a', B, H, W)[1]
-    save(name, **run_module(net, (x,), name, full_grads=('model.1.bias', 'model.6.weight', 'model.23.weight', 'model.18.weight')))
+    save(name, **run_module(net, (x,), name, full_grads=('model.23.bias', 'model.6.weight', 'model.23.weight', 'model.18.weight')))
 
 
 def disc(cin, B, H, W, name):

@@ -14,6 +14,12 @@ the arithmetic path that the fixtures pin, except where stated:
   / ``lib.utils.dist_utils`` git-ignored upstream -> 3-line registries
 * ``NNET`` / ``PSPNet``      out-of-scope nets -> constant-output stand-ins
 * cv2, imageio, open3d, ...  import-only dummies
+
+One behavioural patch: torch.nn.functional.instance_norm is wrapped so that the cotangent
+reaching its backward is made contiguous.  PyTorch 2.10's CPU instance_norm backward returns
+wrong input gradients for a channels-last-strided cotangent (batch size 1 behind a
+ConvTranspose2d); the wrapper only removes that stride pattern -- values, and the gradient
+upstream computes on a correct PyTorch, are unchanged (checked against the closed form).
 """
 import importlib
 import os
@@ -82,9 +88,32 @@ def _resnet(layers):
     return Net
 
 
+class _ContiguousCotangent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()          # a copy: upstream applies in-place activations to the result
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
+def _patch_instance_norm():
+    import torch.nn.functional as F
+    if getattr(F.instance_norm, '_rdfc_patched', False):
+        return
+    orig = F.instance_norm
+
+    def instance_norm(*a, **k):
+        return _ContiguousCotangent.apply(orig(*a, **k))
+    instance_norm._rdfc_patched = True
+    F.instance_norm = instance_norm
+
+
 def install():
     if 'lib.models.generator.rdf_generator.rdf_generator' in sys.modules:
         return
+    _patch_instance_norm()
     if not os.path.isdir(REF):
         raise RuntimeError('reference tree not present (ref_harness is build-container only)')
     for p in (REPO, os.path.join(REF, 'lib'), REF):
