@@ -105,12 +105,13 @@ int rdfc_reflect_pad_adjoint(const void *dpad, void *dsrc, int N, int H, int W, 
  * groups G = 1 (batch norm: statistics over N*H*W) or N (instance norm).
  * ------------------------------------------------------------------------------ */
 /* pass 1: per-(group, channel) sum and sum of squares -> partial[G][nchunk][2][C] (f32),
- * nchunk = rdfc_norm_nchunk(P) where P = pixels per group. */
-int rdfc_norm_nchunk(int pixels_per_group);
+ * nchunk = rdfc_norm_nchunk(P, C, dtype) where P = pixels per group (scratch sizing for every
+ * two-stage reduction below; rdfc_channel_sum: nchunk = rdfc_norm_nchunk(P, C, dtype) with G = 1). */
+int rdfc_norm_nchunk(int pixels_per_group, int C, int dtype);
 int rdfc_norm_stats(const void *x, float *partial, int G, int P, int C, int ld, int dtype, void *stream);
 /* pass 2: mean[G][C], rstd[G][C] (biased variance, eps); optional running-stat update
  * (momentum, unbiased variance) when run_mean != NULL. */
-int rdfc_norm_finalize(const float *partial, float *mean, float *rstd, int G, int P, int C, float eps,
+int rdfc_norm_finalize(const float *partial, float *mean, float *rstd, int G, int P, int C, int dtype, float eps,
                        float *run_mean, float *run_var, float momentum, void *stream);
 /* z = act(gamma*(x-mean)*rstd + beta + res).  gamma/beta f32[C] or NULL (1/0); res may be NULL.
  * prelu: device pointer to the slope when act == RDFC_ACT_PRELU. */
@@ -124,7 +125,7 @@ int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *mean, const
                          int lddz, int ldx, int ldr, int dtype, int act, float slope, const float *prelu,
                          void *stream);
 /* sums[G][3][C] from the partials (fixed order => deterministic). */
-int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, void *stream);
+int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, int dtype, void *stream);
 /* backward pass 2: dx = gamma*rstd*(du - S1/P - xhat*S2/P) (training) or gamma*rstd*du (frozen stats);
  * dres (may be NULL) = du. */
 int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
@@ -141,7 +142,8 @@ int rdfc_adain_bwd_apply(const void *dout, const void *x, const float *mean, con
                          const float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx,
                          int ldgb, int lddx, int lddgb, int dtype, void *stream);
 
-/* per-channel sum over all pixels (bias gradient): out[C] = sum_p x[p, c].  partial: [nchunk][C] scratch. */
+/* per-channel sum over all pixels (bias gradient): out[C] = sum_p x[p, c].
+ * partial: scratch of min(4096, P) * C floats (upper bound on the chunk count of either code path). */
 int rdfc_channel_sum(const void *x, float *partial, float *out, int P, int C, int ld, int dtype, void *stream);
 
 /* elementwise activation backward for conv epilogues without a norm:

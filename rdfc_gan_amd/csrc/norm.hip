@@ -13,11 +13,38 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int CHUNK = 2048;   // pixels per block
 
 struct Map {       // geometry shared by the kernels
     int G, P, C;   // groups, pixels per group, channels
+    int chunk;     // pixels per workgroup (host: chunk_pixels)
 };
+
+// Pixels per workgroup: ~8 rows per thread (4 independent 16-byte loads in flight per stream and
+// thread, two batches), so that a full-resolution map yields >= 2000 workgroups (8 per CU) and the
+// small instance-norm maps still spread over the chip; capped at 4096 chunks per group.
+inline int chunk_pixels(int P, int C, int vec) {
+    const int cvt = C / vec < NT ? (C / vec > 0 ? C / vec : 1) : NT;
+    const int rpb = NT / cvt;
+    int chunk = 8 * rpb;
+    const int lo = cdiv(P, 4096);
+    if (chunk < lo) chunk = cdiv(lo, rpb) * rpb;
+    return chunk;
+}
+inline Map make_map(int G, int P, int C, int vec) { return Map{G, P, C, chunk_pixels(P, C, vec)}; }
+
+// body(p) for p = begin + r0, +RPB, ... < end, four rows per trip so four independent loads are in flight
+#define ROW_LOOP(cx, body)                                                          \
+    {                                                                                \
+        int p_ = (cx).p_begin + (cx).r0;                                             \
+        const int st_ = (cx).RPB;                                                    \
+        for (; p_ + 3 * st_ < (cx).p_end; p_ += 4 * st_) {                           \
+            body(p_);                                                                \
+            body(p_ + st_);                                                          \
+            body(p_ + 2 * st_);                                                      \
+            body(p_ + 3 * st_);                                                      \
+        }                                                                            \
+        for (; p_ < (cx).p_end; p_ += st_) body(p_);                                 \
+    }
 
 template <typename T>
 struct Ctx {
@@ -37,13 +64,13 @@ struct Ctx {
         g = blockIdx.y;
         chunk = blockIdx.x;
         nchunk = gridDim.x;
-        p_begin = chunk * CHUNK;
-        p_end = min(p_begin + CHUNK, m.P);
+        p_begin = chunk * m.chunk;
+        p_end = min(p_begin + m.chunk, m.P);
     }
 };
 
 inline dim3 grid_for(const Map &m, int vec) {
-    return dim3(cdiv(m.P, CHUNK), m.G, cdiv(m.C / vec, NT));
+    return dim3(cdiv(m.P, m.chunk), m.G, cdiv(m.C / vec, NT));
 }
 
 // block-level reduction of K*VEC per-thread sums over the RPB rows, then write partial[g][chunk][k][c]
@@ -83,7 +110,7 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
     for (int v = 0; v < VEC; ++v) s[0][v] = s[1][v] = 0.f;
     if (cx.active) {
         const T *base = x + (size_t)cx.g * m.P * ld + cx.c0;
-        for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+        auto body = [&](int p) {
             Vec16<T> a;
             a.load(base + (size_t)p * ld);
 #pragma unroll
@@ -92,21 +119,37 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
                 s[0][v] += f;
                 s[1][v] += f * f;
             }
-        }
+        };
+        ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 2>(cx, m, s, partial);
 }
 
-__global__ void stats_finalize_kernel(Map m, int nchunk, const float *__restrict__ partial, float *__restrict__ mean,
-                                      float *__restrict__ rstd, float eps, float *run_mean, float *run_var, float momentum) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m.G * m.C) return;
-    const int g = i / m.C, c = i % m.C;
-    double s1 = 0, s2 = 0;
-    for (int k = 0; k < nchunk; ++k) {
-        s1 += partial[(((size_t)g * nchunk + k) * 2 + 0) * m.C + c];
-        s2 += partial[(((size_t)g * nchunk + k) * 2 + 1) * m.C + c];
-    }
+// fixed-order sum over the chunk partials of one (group, k, channel): 32 channels x 8 lanes per workgroup,
+// lane l adds chunks l, l+8, ... in f64, then the 8 lane sums are added in lane order (deterministic)
+__device__ inline double chunk_sum(const float *__restrict__ partial, int g, int K, int k, int C, int c, int nchunk,
+                                   double *red /* [8][32] */) {
+    const int lane = threadIdx.x >> 5, cl = threadIdx.x & 31;
+    double s = 0;
+    if (c < C)
+        for (int j = lane; j < nchunk; j += 8) s += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
+    __syncthreads();
+    red[lane * 32 + cl] = s;
+    __syncthreads();
+    double t = 0;
+    for (int l = 0; l < 8; ++l) t += red[l * 32 + cl];
+    return t;
+}
+
+__global__ __launch_bounds__(NT) void stats_finalize_kernel(Map m, int nchunk, const float *__restrict__ partial,
+                                                            float *__restrict__ mean, float *__restrict__ rstd, float eps,
+                                                            float *run_mean, float *run_var, float momentum) {
+    __shared__ double red[8 * 32];
+    const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const double s1 = chunk_sum(partial, g, 2, 0, m.C, c, nchunk, red);
+    const double s2 = chunk_sum(partial, g, 2, 1, m.C, c, nchunk, red);
+    if (threadIdx.x >= 32 || c >= m.C) return;
+    const int i = g * m.C + c;
     const double mu = s1 / m.P;
     double var = s2 / m.P - mu * mu;
     if (var < 0) var = 0;
@@ -142,7 +185,7 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
     }
     const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
     const size_t gb = (size_t)cx.g * m.P;
-    for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+    auto body = [&](int p) {
         Vec16<T> xv, rv, o;
         xv.load(x + (gb + p) * ldx + cx.c0);
         if (res) rv.load(res + (gb + p) * ldr + cx.c0);
@@ -153,7 +196,8 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
             o.set(v, act_fwd(u, a.act, slope));
         }
         o.store(z + (gb + p) * ldz + cx.c0);
-    }
+    };
+        ROW_LOOP(cx, body);
 }
 
 // backward pass 1: sums of du, du*xhat, dz*min(u,0)
@@ -179,7 +223,7 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
         }
         const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
         const size_t gb = (size_t)cx.g * m.P;
-        for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+        auto body = [&](int p) {
             Vec16<T> dv, xv, rv;
             dv.load(dz + (gb + p) * lddz + cx.c0);
             xv.load(x + (gb + p) * ldx + cx.c0);
@@ -195,18 +239,18 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
                 s[1][v] += du * xh;
                 s[2][v] += d * fminf(u, 0.f);
             }
-        }
+        };
+        ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 3>(cx, m, s, partial);
 }
 
-__global__ void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial, float *__restrict__ sums) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over G*K*C
-    if (i >= G * K * C) return;
-    const int g = i / (K * C), k = (i / C) % K, c = i % C;
-    double s = 0;
-    for (int j = 0; j < nchunk; ++j) s += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
-    sums[i] = (float)s;
+__global__ __launch_bounds__(NT) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
+                                                          float *__restrict__ sums) {
+    __shared__ double red[8 * 32];
+    const int g = blockIdx.y / K, k = blockIdx.y % K, c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const double s = chunk_sum(partial, g, K, k, C, c, nchunk, red);
+    if (threadIdx.x < 32 && c < C) sums[((size_t)g * K + k) * C + c] = (float)s;
 }
 
 template <typename T>
@@ -233,7 +277,7 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const
     }
     const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
     const size_t gb = (size_t)cx.g * m.P;
-    for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+    auto body = [&](int p) {
         Vec16<T> dv, xv, rv, o, orr;
         dv.load(dz + (gb + p) * lddz + cx.c0);
         xv.load(x + (gb + p) * ldx + cx.c0);
@@ -249,7 +293,8 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const
         }
         o.store(dx + (gb + p) * lddx + cx.c0);
         if (dres) orr.store(dres + (gb + p) * lddr + cx.c0);
-    }
+    };
+        ROW_LOOP(cx, body);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -268,7 +313,7 @@ __global__ __launch_bounds__(NT) void adain_apply_kernel(Map m, const float *__r
         rs[v] = rstd[cx.g * m.C + cx.c0 + v];
     }
     const size_t gb = (size_t)cx.g * m.P;
-    for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+    auto body = [&](int p) {
         Vec16<T> xv, gv, bv, o;
         xv.load(x + (gb + p) * ldx + cx.c0);
         gv.load(gbm + (gb + p) * ldgb + cx.c0);
@@ -276,7 +321,8 @@ __global__ __launch_bounds__(NT) void adain_apply_kernel(Map m, const float *__r
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o.set(v, gv.get(v) * ((xv.get(v) - mu[v]) * rs[v]) + bv.get(v));
         o.store(out + (gb + p) * ldo + cx.c0);
-    }
+    };
+        ROW_LOOP(cx, body);
 }
 
 template <typename T>
@@ -297,7 +343,7 @@ __global__ __launch_bounds__(NT) void adain_bwd_reduce_kernel(Map m, const float
             rs[v] = rstd[cx.g * m.C + cx.c0 + v];
         }
         const size_t gb = (size_t)cx.g * m.P;
-        for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+        auto body = [&](int p) {
             Vec16<T> dv, xv, gv;
             dv.load(dout + (gb + p) * lddo + cx.c0);
             xv.load(x + (gb + p) * ldx + cx.c0);
@@ -309,7 +355,8 @@ __global__ __launch_bounds__(NT) void adain_bwd_reduce_kernel(Map m, const float
                 s[0][v] += dxh;
                 s[1][v] += dxh * xh;
             }
-        }
+        };
+        ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 3>(cx, m, s, partial);
 }
@@ -334,7 +381,7 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(Map m, const float 
         m2[v] = sums[(cx.g * 3 + 1) * m.C + c] * invP;
     }
     const size_t gb = (size_t)cx.g * m.P;
-    for (int p = cx.p_begin + cx.r0; p < cx.p_end; p += cx.RPB) {
+    auto body = [&](int p) {
         Vec16<T> dv, xv, gv, o, og, ob;
         dv.load(dout + (gb + p) * lddo + cx.c0);
         xv.load(x + (gb + p) * ldx + cx.c0);
@@ -351,19 +398,39 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(Map m, const float 
         o.store(dx + (gb + p) * lddx + cx.c0);
         og.store(dgb + (gb + p) * lddgb + cx.c0);
         ob.store(dgb + (gb + p) * lddgb + m.C + cx.c0);
-    }
+    };
+        ROW_LOOP(cx, body);
 }
 
 // ------------------------------------------------------------------------------------------
-// per-channel sum for arbitrary C (scalar path: one thread per channel column slice)
+// per-channel sum.  Vector path (C a multiple of the 16-byte vector): the common Ctx mapping, K = 1.
 template <typename T>
-__global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, const T *__restrict__ x, float *__restrict__ partial) {
-    // block handles CHUNK pixels; thread t: channel c = t % Cb, row r0 = t / Cb (Cb = min(C,256) slab in blockIdx.z)
+__global__ __launch_bounds__(NT) void chsum_vec_kernel(Map m, int ld, const T *__restrict__ x, float *__restrict__ partial) {
+    constexpr int VEC = Elem<T>::VEC;
+    Ctx<T> cx(m);
+    float s[1][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[0][v] = 0.f;
+    if (cx.active) {
+        const T *base = x + cx.c0;
+        auto body = [&](int p) {
+            Vec16<T> a;
+            a.load(base + (size_t)p * ld);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s[0][v] += a.get(v);
+        };
+        ROW_LOOP(cx, body);
+    }
+    block_reduce_store<T, 1>(cx, m, s, partial);
+}
+// scalar path (C = 1, 3, ...): thread t -> channel t % Cb, rows t / Cb
+template <typename T>
+__global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, int chunk, const T *__restrict__ x, float *__restrict__ partial) {
     const int slab0 = blockIdx.z * NT, Cb = min(C - slab0, NT), RPB = NT / Cb;
     const int t = threadIdx.x, c = slab0 + t % Cb, r0 = t / Cb;
     const bool active = t < RPB * Cb;
     float s = 0.f;
-    const int pb = blockIdx.x * CHUNK, pe = min(pb + CHUNK, P);
+    const int pb = blockIdx.x * chunk, pe = min(pb + chunk, P);
     if (active)
         for (int p = pb + r0; p < pe; p += RPB) s += Elem<T>::ld(x + (size_t)p * ld + c);
     __shared__ float red[NT];
@@ -402,22 +469,24 @@ int check_map(const char *who, int G, int P, int C, int dtype, std::initializer_
     if ((dtype) == RDFC_BF16) { using T = bf16_t; __VA_ARGS__; } \
     else { using T = float; __VA_ARGS__; }
 
-extern "C" int rdfc_norm_nchunk(int pixels_per_group) { return cdiv(pixels_per_group, CHUNK); }
+extern "C" int rdfc_norm_nchunk(int pixels_per_group, int C, int dtype) {
+    return cdiv(pixels_per_group, chunk_pixels(pixels_per_group, C, dtype == RDFC_BF16 ? 8 : 4));
+}
 
 extern "C" int rdfc_norm_stats(const void *x, float *partial, int G, int P, int C, int ld, int dtype, void *stream) {
     if (int e = check_map("rdfc_norm_stats", G, P, C, dtype, {ld})) return e;
-    Map m{G, P, C};
+    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
     DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld, partial));
     RDFC_LAUNCH_CHECK("rdfc_norm_stats");
     return 0;
 }
 
-extern "C" int rdfc_norm_finalize(const float *partial, float *mean, float *rstd, int G, int P, int C, float eps,
+extern "C" int rdfc_norm_finalize(const float *partial, float *mean, float *rstd, int G, int P, int C, int dtype, float eps,
                                   float *run_mean, float *run_var, float momentum, void *stream) {
     RDFC_REQUIRE(G > 0 && P > 0 && C > 0, "rdfc_norm_finalize: non-positive size");
     RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_finalize: running statistics need G == 1 (batch norm)");
-    Map m{G, P, C};
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(G * C, 128)), dim3(128), 0, (hipStream_t)stream, m, cdiv(P, CHUNK),
+    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(C, 32), G), dim3(NT), 0, (hipStream_t)stream, m, cdiv(P, m.chunk),
                        partial, mean, rstd, eps, run_mean, run_var, momentum);
     RDFC_LAUNCH_CHECK("rdfc_norm_finalize");
     return 0;
@@ -428,7 +497,7 @@ extern "C" int rdfc_norm_apply(const void *x, const float *mean, const float *rs
                                int act, float slope, const float *prelu, void *stream) {
     if (int e = check_map("rdfc_norm_apply", G, P, C, dtype, {ldx, ldz})) return e;
     RDFC_REQUIRE(act != RDFC_ACT_PRELU || prelu != nullptr, "rdfc_norm_apply: PReLU needs the slope pointer");
-    Map m{G, P, C};
+    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)x, (const T *)res, (T *)z, ldx, ldr, ldz));
@@ -440,7 +509,7 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
                                     const float *beta, const void *res, float *partial, int G, int P, int C, int lddz,
                                     int ldx, int ldr, int dtype, int act, float slope, const float *prelu, void *stream) {
     if (int e = check_map("rdfc_norm_bwd_reduce", G, P, C, dtype, {lddz, ldx})) return e;
-    Map m{G, P, C};
+    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr));
@@ -448,9 +517,9 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
     return 0;
 }
 
-extern "C" int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, void *stream) {
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(G * 3 * C, 128)), dim3(128), 0, (hipStream_t)stream, G, C, 3,
-                       cdiv(P, CHUNK), partial, sums);
+extern "C" int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, int dtype, void *stream) {
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), G * 3), dim3(NT), 0, (hipStream_t)stream, G, C, 3,
+                       cdiv(P, chunk_pixels(P, C, dtype == RDFC_BF16 ? 8 : 4)), partial, sums);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_finalize");
     return 0;
 }
@@ -460,7 +529,7 @@ extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *m
                                    int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
                                    const float *prelu, int frozen_stats, void *stream) {
     if (int e = check_map("rdfc_norm_bwd_apply", G, P, C, dtype, {lddz, ldx, lddx})) return e;
-    Map m{G, P, C};
+    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
@@ -473,7 +542,7 @@ extern "C" int rdfc_adain_apply(const void *x, const float *mean, const float *r
                                 int C, int ldx, int ldgb, int ldo, int dtype, void *stream) {
     if (int e = check_map("rdfc_adain_apply", N, P, C, dtype, {ldx, ldo})) return e;
     RDFC_REQUIRE(ldgb >= 2 * C, "rdfc_adain_apply: ldgb must cover 2C channels");
-    Map m{N, P, C};
+    Map m = make_map(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
     DISPATCH(dtype, hipLaunchKernelGGL(adain_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, mean,
                                        rstd, (const T *)x, (const T *)gb, (T *)out, ldx, ldgb, ldo));
     RDFC_LAUNCH_CHECK("rdfc_adain_apply");
@@ -483,7 +552,7 @@ extern "C" int rdfc_adain_apply(const void *x, const float *mean, const float *r
 extern "C" int rdfc_adain_bwd_reduce(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb,
                                      float *partial, int N, int P, int C, int lddo, int ldx, int ldgb, int dtype, void *stream) {
     if (int e = check_map("rdfc_adain_bwd_reduce", N, P, C, dtype, {lddo, ldx})) return e;
-    Map m{N, P, C};
+    Map m = make_map(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
     DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
                                        mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, partial, lddo, ldx, ldgb));
     RDFC_LAUNCH_CHECK("rdfc_adain_bwd_reduce");
@@ -494,7 +563,7 @@ extern "C" int rdfc_adain_bwd_apply(const void *dout, const void *x, const float
                                     const float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx, int ldgb,
                                     int lddx, int lddgb, int dtype, void *stream) {
     if (int e = check_map("rdfc_adain_bwd_apply", N, P, C, dtype, {lddo, ldx, lddx})) return e;
-    Map m{N, P, C};
+    Map m = make_map(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
     DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
                                        mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, sums, (T *)dx, (T *)dgb, lddo,
                                        ldx, ldgb, lddx, lddgb));
@@ -505,9 +574,19 @@ extern "C" int rdfc_adain_bwd_apply(const void *dout, const void *x, const float
 extern "C" int rdfc_channel_sum(const void *x, float *partial, float *out, int P, int C, int ld, int dtype, void *stream) {
     RDFC_REQUIRE(dtype == RDFC_F32 || dtype == RDFC_BF16, "rdfc_channel_sum: bad dtype");
     RDFC_REQUIRE(P > 0 && C > 0 && ld >= C, "rdfc_channel_sum: bad size");
-    dim3 grid(cdiv(P, CHUNK), 1, cdiv(C, NT));
-    DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, (const T *)x, partial));
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, 1, C, 1, cdiv(P, CHUNK), partial, out);
+    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    int nchunk;
+    if (C % vec == 0 && ld % vec == 0) {
+        Map m = make_map(1, P, C, vec);
+        nchunk = cdiv(P, m.chunk);
+        DISPATCH(dtype, hipLaunchKernelGGL(chsum_vec_kernel<T>, grid_for(m, vec), dim3(NT), 0, (hipStream_t)stream, m, ld, (const T *)x, partial));
+    } else {
+        const int chunk = chunk_pixels(P, C, 1);
+        nchunk = cdiv(P, chunk);
+        dim3 grid(nchunk, 1, cdiv(C, NT));
+        DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, chunk, (const T *)x, partial));
+    }
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(NT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out);
     RDFC_LAUNCH_CHECK("rdfc_channel_sum");
     return 0;
 }

@@ -208,19 +208,19 @@ def reflect_pad_adjoint(dpad, pad):
 
 
 # --------------------------------------------------------------------------- normalisation
-def norm_nchunk(P):
-    return lib().rdfc_norm_nchunk(P)
+def norm_nchunk(P, Cc, dtype_code):
+    return lib().rdfc_norm_nchunk(P, Cc, dtype_code)
 
 
 def norm_stats(x, G, eps, run_mean=None, run_var=None, momentum=0.1):
     """x [N,H,W,C]; G = 1 (batch) or N (instance). -> mean[G,C], rstd[G,C]"""
     N, H, W, Cc = x.shape
     P = N * H * W // G
-    partial = torch.empty(G * norm_nchunk(P) * 2 * Cc, dtype=torch.float32, device=x.device)
+    partial = torch.empty(G * norm_nchunk(P, Cc, dt(x)) * 2 * Cc, dtype=torch.float32, device=x.device)
     mean = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
     rstd = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
     _chk(lib().rdfc_norm_stats(_p(x), _p(partial), G, P, Cc, ld(x), dt(x), _st()), 'rdfc_norm_stats')
-    _chk(lib().rdfc_norm_finalize(_p(partial), _p(mean), _p(rstd), G, P, Cc, _f(eps), _p(run_mean), _p(run_var),
+    _chk(lib().rdfc_norm_finalize(_p(partial), _p(mean), _p(rstd), G, P, Cc, dt(x), _f(eps), _p(run_mean), _p(run_var),
                                   _f(momentum), _st()), 'rdfc_norm_finalize')
     return mean, rstd
 
@@ -241,13 +241,13 @@ def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, pr
     N, H, W, Cc = x.shape
     G = mean.shape[0]
     P = N * H * W // G
-    nch = norm_nchunk(P)
+    nch = norm_nchunk(P, Cc, dt(x))
     partial = torch.empty(G * nch * 3 * Cc, dtype=torch.float32, device=x.device)
     sums = torch.empty(G, 3, Cc, dtype=torch.float32, device=x.device)
     ldr = ld(res) if res is not None else 0
     _chk(lib().rdfc_norm_bwd_reduce(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(partial), G, P, Cc,
                                     ld(dz), ld(x), ldr, dt(x), ACT[act], _f(slope), _p(prelu), _st()), 'rdfc_norm_bwd_reduce')
-    _chk(lib().rdfc_norm_bwd_finalize(_p(partial), _p(sums), G, P, Cc, _st()), 'rdfc_norm_bwd_finalize')
+    _chk(lib().rdfc_norm_bwd_finalize(_p(partial), _p(sums), G, P, Cc, dt(x), _st()), 'rdfc_norm_bwd_finalize')
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
     dres = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device) if want_dres else None
     _chk(lib().rdfc_norm_bwd_apply(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(sums), _p(dx), _p(dres),
@@ -266,12 +266,12 @@ def adain_apply(x, mean, rstd, gb, out):
 def adain_backward(dout, x, mean, rstd, gb):
     N, H, W, Cc = x.shape
     P = H * W
-    nch = norm_nchunk(P)
+    nch = norm_nchunk(P, Cc, dt(x))
     partial = torch.empty(N * nch * 3 * Cc, dtype=torch.float32, device=x.device)
     sums = torch.empty(N, 3, Cc, dtype=torch.float32, device=x.device)
     _chk(lib().rdfc_adain_bwd_reduce(_p(dout), _p(x), _p(mean), _p(rstd), _p(gb), _p(partial), N, P, Cc, ld(dout), ld(x),
                                      ld(gb), dt(x), _st()), 'rdfc_adain_bwd_reduce')
-    _chk(lib().rdfc_norm_bwd_finalize(_p(partial), _p(sums), N, P, Cc, _st()), 'rdfc_norm_bwd_finalize')
+    _chk(lib().rdfc_norm_bwd_finalize(_p(partial), _p(sums), N, P, Cc, dt(x), _st()), 'rdfc_norm_bwd_finalize')
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
     dgb = torch.empty(N, H, W, 2 * Cc, dtype=x.dtype, device=x.device)
     _chk(lib().rdfc_adain_bwd_apply(_p(dout), _p(x), _p(mean), _p(rstd), _p(gb), _p(sums), _p(dx), _p(dgb), N, P, Cc,
@@ -282,7 +282,7 @@ def adain_backward(dout, x, mean, rstd, gb):
 def channel_sum(x):
     N, H, W, Cc = x.shape
     P = N * H * W
-    partial = torch.empty(norm_nchunk(P) * Cc, dtype=torch.float32, device=x.device)
+    partial = torch.empty(min(4096, P) * Cc, dtype=torch.float32, device=x.device)   # upper bound on chunks
     out = torch.empty(Cc, dtype=torch.float32, device=x.device)
     _chk(lib().rdfc_channel_sum(_p(x), _p(partial), _p(out), P, Cc, ld(x), dt(x), _st()), 'rdfc_channel_sum')
     return out
