@@ -109,6 +109,7 @@ def main():
     ap.add_argument('--exact-schedule', action='store_true', help="run upstream's two dead forwards too")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--by-shape', default=None, help='write a per-conv-shape time / TFLOP/s table (debug aid) to this file')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -178,7 +179,7 @@ def main():
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
         if prof:
             fam = {}
-            for name, flops, e0, e1 in prof:
+            for name, flops, e0, e1, _shape in prof:
                 d = fam.setdefault(name, [0.0, 0.0, 0])
                 d[0] += flops
                 d[1] += e0.elapsed_time(e1) * 1e-3
@@ -192,6 +193,17 @@ def main():
                                    share_of_step=round(sec / (elapsed / 1.0), 4))
             out['kernel_families'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), seconds=round(v[1], 4), launches=v[2],
                                               share_of_step=round(v[1] / elapsed, 4)) for k, v in sorted(fam.items())}
+        if prof and a.by_shape:
+            tab = {}
+            for name, flops, e0, e1, shp in prof:
+                d = tab.setdefault((name.split(' ')[0],) + shp, [0.0, 0.0, 0])
+                d[0] += flops
+                d[1] += e0.elapsed_time(e1) * 1e-3
+                d[2] += 1
+            with open(a.by_shape, 'w') as f:
+                f.write('kernel N Hi Wi Ci Ho Wo Co K s | launches ms_total us_avg TFLOP/s\n')
+                for k, v in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                    f.write(' '.join(map(str, k)) + f' | {v[2]} {1e3 * v[1]:.2f} {1e6 * v[1] / v[2]:.1f} {v[0] / v[1] / 1e12:.1f}\n')
         if not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.height, a.width, True)
         print(json.dumps(out))

@@ -18,6 +18,8 @@
 // flight during the MFMAs of step i); LDS rows padded by 16 B against bank conflicts.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct IgemmParams {
@@ -162,28 +164,40 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p, const T 
     Vec16<T> rb[VECLOAD ? NB_V : 1], ra[VECLOAD ? NA_V : 1];
     T sb[VECLOAD ? 1 : NB_S], sa[VECLOAD ? 1 : NA_S];
 
+    // vector path: per-chunk state that does not depend on the tap (fixed rows per thread)
+    int b_off[VECLOAD ? NB_V : 1], b_y[VECLOAD ? NB_V : 1], b_x[VECLOAD ? NB_V : 1], a_off[VECLOAD ? NA_V : 1];
+    if constexpr (VECLOAD) {
+#pragma unroll
+        for (int j = 0; j < NB_V; ++j) {
+            const int e = tid + j * NTHREADS, row = e / CPR, ch = e % CPR;
+            const bool ok = row < TPX && pxn[row < TPX ? row : 0] >= 0;
+            b_y[j] = ok ? pxy[row] : -(1 << 28);         // invalid rows fail every bounds test below
+            b_x[j] = ok ? pxx[row] : -(1 << 28);
+            b_off[j] = ok ? (pxn[row] + pxy[row] * p.Win + pxx[row]) * p.ld_in + ch * VEC : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < NA_V; ++j) {
+            const int e = tid + j * NTHREADS, row = e / CPR, ch = e % CPR;
+            a_off[j] = (row < TCO && co0 + row < p.Cout) ? (co0 + row) * p.Krow + ch * VEC : -1;
+        }
+    }
+
     auto load_regs = [&](int it) {
         if constexpr (VECLOAD) {
             const int ti = it / cch, c0 = (it - ti * cch) * BK;
             const int tw = tap_w[ti], dy = tap_dy[ti], dx = tap_dx[ti];
+            const int tapoff = (dy * p.Win + dx) * p.ld_in + c0;     // uniform
+            const int woff = tw * p.Cin + c0;
 #pragma unroll
             for (int j = 0; j < NB_V; ++j) {
-                const int e = tid + j * NTHREADS;
-                const int row = e / CPR, ch = e % CPR;
                 rb[j].zero();
-                if (row < TPX) {
-                    const int nb = pxn[row], iy = pxy[row] + dy, ix = pxx[row] + dx;
-                    if (nb >= 0 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
-                        rb[j].load(x + (size_t)(nb + iy * p.Win + ix) * p.ld_in + c0 + ch * VEC);
-                }
+                if ((unsigned)(b_y[j] + dy) < (unsigned)p.Hin && (unsigned)(b_x[j] + dx) < (unsigned)p.Win)
+                    rb[j].load(x + b_off[j] + tapoff);
             }
 #pragma unroll
             for (int j = 0; j < NA_V; ++j) {
-                const int e = tid + j * NTHREADS;
-                const int row = e / CPR, ch = e % CPR;
                 ra[j].zero();
-                if (row < TCO && co0 + row < p.Cout)
-                    ra[j].load(w + (size_t)(co0 + row) * p.Krow + tw * p.Cin + c0 + ch * VEC);
+                if (a_off[j] >= 0) ra[j].load(w + a_off[j] + woff);
             }
         } else {
             const int kk = tid & 31, r0 = tid >> 5;
@@ -328,6 +342,9 @@ int check_desc(const rdfc_conv_desc *d, const char *who) {
                  d->KH, d->KW, MAXTAPS);
     RDFC_REQUIRE(d->sh > 0 && d->sw > 0 && d->dh > 0 && d->dw > 0 && d->ph >= 0 && d->pw >= 0, "%s: bad stride/pad/dilation", who);
     RDFC_REQUIRE(d->ldx >= d->Ci && d->ldy >= d->Co, "%s: ld smaller than channel count", who);
+    RDFC_REQUIRE((double)d->N * d->Hi * d->Wi * d->ldx < 2147483647.0 && (double)d->N * d->Ho * d->Wo * d->ldy < 2147483647.0 &&
+                     (double)d->Co * d->KH * d->KW * d->Ci < 2147483647.0,
+                 "%s: maps of 2^31 elements or more need 64-bit offsets (not built)", who);
     const int vec = d->dtype == RDFC_BF16 ? 8 : 4;
     RDFC_REQUIRE(d->Ci % BK != 0 || d->ldx % vec == 0, "%s: ldx=%d must be a multiple of %d for vector loads", who, d->ldx, vec);
     RDFC_REQUIRE(d->Co % BK != 0 || d->ldy % vec == 0, "%s: ldy=%d must be a multiple of %d for vector loads", who, d->ldy, vec);
@@ -335,6 +352,13 @@ int check_desc(const rdfc_conv_desc *d, const char *who) {
 }
 
 }  // namespace
+
+int rdfc_try_conv3x3_patch(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias,
+                           void *out, hipStream_t st);   // conv_patch.hip
+static bool patch_enabled() {
+    static const bool on = getenv("RDFC_NO_PATCH") == nullptr;
+    return on;
+}
 
 extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias,
                                    void *y, void *stream) {
@@ -345,7 +369,8 @@ extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const
     IgemmParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
                   d->ldx, d->ldy, 0, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Ci};
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, w_fwd, bias, y, st);
+    if (patch_enabled() && rdfc_try_conv3x3_patch(d, 0, x, w_fwd, bias, y, st)) {
+    } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, w_fwd, bias, y, st);
     else launch_T<float>(p, x, w_fwd, bias, y, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_forward");
     return 0;
@@ -358,7 +383,8 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
     IgemmParams p{d->N, d->Ho, d->Wo, d->Co, d->Hi, d->Wi, d->Ci, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
                   d->ldy, d->ldx, 1, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Co};
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, dy, w_bwd, bias, dx, st);
+    if (patch_enabled() && rdfc_try_conv3x3_patch(d, 1, dy, w_bwd, bias, dx, st)) {
+    } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, dy, w_bwd, bias, dx, st);
     else launch_T<float>(p, dy, w_bwd, bias, dx, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_dgrad");
     return 0;

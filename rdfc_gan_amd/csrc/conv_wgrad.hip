@@ -72,7 +72,7 @@ template <> struct WMma<float> {
     }
 };
 
-template <typename T, int TCO, int TCI, int WCO>
+template <typename T, int TCO, int TCI, int WCO, bool VY, bool VX>
 __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams p, const T *__restrict__ x,
                                                          const T *__restrict__ dy, float *__restrict__ dw) {
     constexpr int VEC = Elem<T>::VEC;
@@ -81,8 +81,11 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams p, const T 
     constexpr int MT = WTCO / 16, NT = WTCI / 16;
     constexpr int LDY = TCO + VEC, LDX = TCI + VEC;
     constexpr int CY = TCO / VEC, CX = TCI / VEC;                     // 16-byte chunks per pixel row
-    constexpr int NYV = (BKP * CY + NTHREADS - 1) / NTHREADS, NXV = (BKP * CX + NTHREADS - 1) / NTHREADS;
-    constexpr int NYS = (BKP * TCO + NTHREADS - 1) / NTHREADS, NXS = (BKP * TCI + NTHREADS - 1) / NTHREADS;
+    // loads per thread and k-step: vector path = 16-byte chunks, scalar path = single elements
+    constexpr int NY = VY ? (BKP * CY + NTHREADS - 1) / NTHREADS : (BKP * TCO + NTHREADS - 1) / NTHREADS;
+    constexpr int NX = VX ? (BKP * CX + NTHREADS - 1) / NTHREADS : (BKP * TCI + NTHREADS - 1) / NTHREADS;
+    constexpr int EY = VY ? CY : TCO, EX = VX ? CX : TCI;             // entries per pixel row
+    constexpr int SY = VY ? VEC : 1, SX = VX ? VEC : 1;               // elements per entry
 
     __shared__ __attribute__((aligned(16))) T Ys[2][BKP * LDY];
     __shared__ __attribute__((aligned(16))) T Xs[2][BKP * LDX];
@@ -96,26 +99,33 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams p, const T 
     int nsteps = nsteps_total - step0;
     if (nsteps > p.steps_per_slice) nsteps = p.steps_per_slice;
     if (nsteps <= 0) return;
-
-    const bool vecY = (p.Co % VEC == 0) && (p.ldy % VEC == 0);
-    const bool vecX = (p.Ci % VEC == 0) && (p.ldx % VEC == 0);
     const int HWo = p.Ho * p.Wo;
 
-    // incremental pixel coordinates of the X rows this thread loads (vector path: NXV rows; scalar: NXS)
-    constexpr int NXC = NXV > NXS ? NXV : NXS;
-    int xn[NXC], xoy[NXC], xox[NXC];
-    {
-        const int cnt = vecX ? NXV : NXS;
-        for (int j = 0; j < NXC; ++j) {
-            xn[j] = xoy[j] = xox[j] = 0;
-            if (j < cnt) {
-                const int e = tid + j * NTHREADS;
-                const int row = vecX ? e / CX : e / TCI;
-                const int m = step0 * BKP + row;
-                const int n = m / HWo, r = m - n * HWo;
-                xn[j] = n; xoy[j] = r / p.Wo; xox[j] = r - (r / p.Wo) * p.Wo;
-            }
-        }
+    // Per-entry state, advanced by BKP pixels per k-step with uniform increments only:
+    //   dY: linear pixel index m and element offset;  X: (n, oy, ox) and the element offset of the tapped pixel.
+    int ym[NY], yoff[NY];
+    bool yok[NY];
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+        const int e = tid + j * NTHREADS, row = e / EY, c = co0 + (e % EY) * SY;
+        ym[j] = step0 * BKP + row;
+        yok[j] = row < BKP && c < p.Co;
+        yoff[j] = ym[j] * p.ldy + c;                 // < 2^31 elements (checked on the host)
+    }
+    int xn[NX], xoy[NX], xox[NX], xoff[NX];
+    bool xok[NX];
+    const int dx_step = BKP * p.sw * p.ldx;                           // +32 output pixels along a row
+    const int dx_row = (p.sh * p.Wi - p.Wo * p.sw) * p.ldx;           // wrap to the next output row
+    const int dx_img = (p.Hi - p.Ho * p.sh) * p.Wi * p.ldx;           // wrap to the next image
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int e = tid + j * NTHREADS, row = e / EX, c = ci0 + (e % EX) * SX;
+        const int m = step0 * BKP + row;
+        const int n = m / HWo, r = m - n * HWo;
+        xn[j] = n; xoy[j] = r / p.Wo; xox[j] = r - xoy[j] * p.Wo;
+        xok[j] = row < BKP && c < p.Ci;
+        const int iy = xoy[j] * p.sh - p.ph + kh * p.dh, ix = xox[j] * p.sw - p.pw + kw * p.dw;
+        xoff[j] = ((n * p.Hi + iy) * p.Wi + ix) * p.ldx + c;
     }
 
     f32x4 acc[MT][NT];
@@ -124,90 +134,64 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams p, const T 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-    Vec16<T> vy[NYV], vx[NXV];
-    T sy[NYS], sx[NXS];
+    Vec16<T> vy[VY ? NY : 1], vx[VX ? NX : 1];
+    T sy[VY ? 1 : NY], sx[VX ? 1 : NX];
 
-    auto load_regs = [&](int s) {
-        const int mbase = (step0 + s) * BKP;
-        if (vecY) {
+    auto load_regs = [&]() {
 #pragma unroll
-            for (int j = 0; j < NYV; ++j) {
-                const int e = tid + j * NTHREADS, row = e / CY, ch = e % CY;
+        for (int j = 0; j < NY; ++j) {
+            const bool ok = yok[j] && ym[j] < p.P;
+            if constexpr (VY) {
                 vy[j].zero();
-                const int m = mbase + row, c = co0 + ch * VEC;
-                if (row < BKP && m < p.P && c < p.Co) vy[j].load(dy + (size_t)m * p.ldy + c);
+                if (ok) vy[j].load(dy + yoff[j]);
+            } else {
+                sy[j] = ok ? dy[yoff[j]] : (T)0.0f;
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NYS; ++j) {
-                const int e = tid + j * NTHREADS, row = e / TCO, c = co0 + e % TCO;
-                const int m = mbase + row;
-                sy[j] = (row < BKP && m < p.P && c < p.Co) ? dy[(size_t)m * p.ldy + c] : (T)0.0f;
-            }
+            ym[j] += BKP;
+            yoff[j] += BKP * p.ldy;
         }
-        if (vecX) {
 #pragma unroll
-            for (int j = 0; j < NXV; ++j) {
-                const int e = tid + j * NTHREADS, row = e / CX, ch = e % CX;
+        for (int j = 0; j < NX; ++j) {
+            const int iy = xoy[j] * p.sh - p.ph + kh * p.dh, ix = xox[j] * p.sw - p.pw + kw * p.dw;
+            const bool ok = xok[j] && xn[j] < p.N && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            if constexpr (VX) {
                 vx[j].zero();
-                const int c = ci0 + ch * VEC;
-                const int iy = xoy[j] * p.sh - p.ph + kh * p.dh, ix = xox[j] * p.sw - p.pw + kw * p.dw;
-                if (row < BKP && xn[j] < p.N && c < p.Ci && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-                    vx[j].load(x + ((size_t)(xn[j] * p.Hi + iy) * p.Wi + ix) * p.ldx + c);
+                if (ok) vx[j].load(x + xoff[j]);
+            } else {
+                sx[j] = ok ? x[xoff[j]] : (T)0.0f;
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NXS; ++j) {
-                const int e = tid + j * NTHREADS, row = e / TCI, c = ci0 + e % TCI;
-                const int iy = xoy[j] * p.sh - p.ph + kh * p.dh, ix = xox[j] * p.sw - p.pw + kw * p.dw;
-                sx[j] = (row < BKP && xn[j] < p.N && c < p.Ci && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-                            ? x[((size_t)(xn[j] * p.Hi + iy) * p.Wi + ix) * p.ldx + c] : (T)0.0f;
-            }
-        }
-        // advance the tracked pixels by one k-step
-#pragma unroll
-        for (int j = 0; j < NXC; ++j) {
             xox[j] += BKP;
-            while (xox[j] >= p.Wo) { xox[j] -= p.Wo; ++xoy[j]; }
-            while (xoy[j] >= p.Ho) { xoy[j] -= p.Ho; ++xn[j]; }
+            xoff[j] += dx_step;
+            while (xox[j] >= p.Wo) { xox[j] -= p.Wo; ++xoy[j]; xoff[j] += dx_row; }
+            while (xoy[j] >= p.Ho) { xoy[j] -= p.Ho; ++xn[j]; xoff[j] += dx_img; }
         }
     };
     auto store_lds = [&](int buf) {
-        if (vecY) {
 #pragma unroll
-            for (int j = 0; j < NYV; ++j) {
-                const int e = tid + j * NTHREADS, row = e / CY, ch = e % CY;
-                if (row < BKP) vy[j].store(&Ys[buf][row * LDY + ch * VEC]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NYS; ++j) {
-                const int e = tid + j * NTHREADS, row = e / TCO;
-                if (row < BKP) Ys[buf][row * LDY + e % TCO] = sy[j];
+        for (int j = 0; j < NY; ++j) {
+            const int e = tid + j * NTHREADS, row = e / EY, ch = e % EY;
+            if (row < BKP) {
+                if constexpr (VY) vy[j].store(&Ys[buf][row * LDY + ch * VEC]);
+                else Ys[buf][row * LDY + ch] = sy[j];
             }
         }
-        if (vecX) {
 #pragma unroll
-            for (int j = 0; j < NXV; ++j) {
-                const int e = tid + j * NTHREADS, row = e / CX, ch = e % CX;
-                if (row < BKP) vx[j].store(&Xs[buf][row * LDX + ch * VEC]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NXS; ++j) {
-                const int e = tid + j * NTHREADS, row = e / TCI;
-                if (row < BKP) Xs[buf][row * LDX + e % TCI] = sx[j];
+        for (int j = 0; j < NX; ++j) {
+            const int e = tid + j * NTHREADS, row = e / EX, ch = e % EX;
+            if (row < BKP) {
+                if constexpr (VX) vx[j].store(&Xs[buf][row * LDX + ch * VEC]);
+                else Xs[buf][row * LDX + ch] = sx[j];
             }
         }
     };
 
     const int wr = wave / WCI, wc = wave % WCI;
-    load_regs(0);
+    load_regs();
     store_lds(0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) load_regs(s + 1);
+        if (s + 1 < nsteps) load_regs();
         WMma<T>::template step<MT, NT>(Ys[buf], Xs[buf], LDY, LDX, wr * WTCO, wc * WTCI, lane, acc);
         if (s + 1 < nsteps) store_lds(buf ^ 1);
         __syncthreads();
@@ -240,7 +224,13 @@ void launch_cfg(const WgradParams &p0, const void *x, const void *dy, float *dw,
     p.steps_per_slice = cdiv(nsteps, slices);
     slices = cdiv(nsteps, p.steps_per_slice);
     dim3 grid(slices, tiles, taps);
-    hipLaunchKernelGGL((wgrad_kernel<T, TCO, TCI, WCO>), grid, dim3(NTHREADS), 0, st, p, (const T *)x, (const T *)dy, dw);
+    constexpr int VEC = Elem<T>::VEC;
+    const bool vy = (p.Co % VEC == 0) && (p.ldy % VEC == 0), vx = (p.Ci % VEC == 0) && (p.ldx % VEC == 0);
+    const T *xp = (const T *)x, *yp = (const T *)dy;
+    if (vy && vx) hipLaunchKernelGGL((wgrad_kernel<T, TCO, TCI, WCO, true, true>), grid, dim3(NTHREADS), 0, st, p, xp, yp, dw);
+    else if (vy) hipLaunchKernelGGL((wgrad_kernel<T, TCO, TCI, WCO, true, false>), grid, dim3(NTHREADS), 0, st, p, xp, yp, dw);
+    else if (vx) hipLaunchKernelGGL((wgrad_kernel<T, TCO, TCI, WCO, false, true>), grid, dim3(NTHREADS), 0, st, p, xp, yp, dw);
+    else hipLaunchKernelGGL((wgrad_kernel<T, TCO, TCI, WCO, false, false>), grid, dim3(NTHREADS), 0, st, p, xp, yp, dw);
 }
 
 template <typename T>
@@ -260,6 +250,8 @@ extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const v
                  "rdfc_conv2d_wgrad: non-positive dimension");
     RDFC_REQUIRE(d->ldx >= d->Ci && d->ldy >= d->Co, "rdfc_conv2d_wgrad: ld smaller than channel count");
     RDFC_REQUIRE(d->KH * d->KW <= 65535, "rdfc_conv2d_wgrad: too many taps");
+    RDFC_REQUIRE((double)d->N * d->Hi * d->Wi * d->ldx < 2147483647.0 && (double)d->N * d->Ho * d->Wo * d->ldy < 2147483647.0,
+                 "rdfc_conv2d_wgrad: maps of 2^31 elements or more need 64-bit offsets (not built)");
     WgradParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
                   d->ldx, d->ldy, d->N * d->Ho * d->Wo, 0};
     hipStream_t st = (hipStream_t)stream;

@@ -130,7 +130,8 @@ class _Timed:
     def __init__(self, family, d):
         self.on = PROFILE is not None
         if self.on:
-            self.rec = (family, _conv_flops(d), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.rec = (family, _conv_flops(d), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+                        (d.N, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.KH, d.sh))
 
     def __enter__(self):
         if self.on:
