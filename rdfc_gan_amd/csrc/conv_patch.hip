@@ -18,9 +18,10 @@
 namespace {
 
 struct PatchParams {
-    int N, H, W, Cin, Cout;     // stride-1 same-size conv: in and out maps are H x W
+    int N, Hin, Win, H, W, Cin, Cout;   // gathered map Hin x Win, produced map H x W (stride 1)
     int ld_in, ld_out;
-    int transposed;             // 1: input-gradient form (tap offset 1-k instead of k-1)
+    int transposed;             // 1: input-gradient form (tap offset 2-k inside the patch instead of k)
+    int oy0, ox0;               // patch origin relative to the tile origin: -pad (forward) or pad-2 (transposed)
     int act;
     float slope;
     int out_f32;
@@ -32,26 +33,39 @@ struct PatchParams {
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 
-template <typename T> struct Frag;
-template <> struct Frag<bf16_t> {
-    typedef bf16x8 type;
+// LDS tile layout: [row][32 k] with 16-byte chunks.
+//   bf16: 64-byte rows, NO padding, chunk index XOR-swizzled with bit 2 of the row:  chunk' = chunk ^ ((row >> 1) & 2).
+//         ds_read_b128 fragment reads (16 consecutive rows x one chunk per 16-lane group) are then bank-conflict
+//         free for every starting row (brute-forced over all offsets; the padded 80-byte rows used before were a
+//         2-way conflict on every read: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).
+//   f32 (parity mode): 144-byte padded rows, no swizzle.
+template <typename T> struct Lay;
+template <> struct Lay<bf16_t> {
+    static constexpr int LDK = BK;
+    __device__ static int off(int row, int chunk) { return row * LDK + ((chunk ^ ((row >> 1) & 2)) << 3); }
+    typedef bf16x8 frag;
     static constexpr int KSUB = 1;
-    __device__ static type ld(const bf16_t *row, int lane, int) { return *reinterpret_cast<const bf16x8 *>(row + (lane >> 4) * 8); }
-    __device__ static f32x4 mma(type a, type b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    __device__ static frag ld(const bf16_t *tile, int row, int lane, int) {
+        return *reinterpret_cast<const bf16x8 *>(tile + off(row, lane >> 4));
+    }
+    __device__ static f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
-template <> struct Frag<float> {
-    typedef float type;
+template <> struct Lay<float> {
+    static constexpr int LDK = BK + 4;
+    __device__ static int off(int row, int chunk) { return row * LDK + chunk * 4; }
+    typedef float frag;
     static constexpr int KSUB = 8;
-    __device__ static type ld(const float *row, int lane, int kk) { return row[4 * kk + (lane >> 4)]; }
-    __device__ static f32x4 mma(type a, type b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static frag ld(const float *tile, int row, int lane, int kk) { return tile[row * LDK + 4 * kk + (lane >> 4)]; }
+    __device__ static f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
 
 template <typename T, int TCO, int TPX, int WCO>
-__global__ __launch_bounds__(NTHREADS) void conv3x3_patch_kernel(PatchParams p, const T *__restrict__ x, const T *__restrict__ w,
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? 2 : 1) void conv3x3_patch_kernel(PatchParams p, const T *__restrict__ x, const T *__restrict__ w,
                                                                  const float *__restrict__ bias, void *__restrict__ yout) {
+    typedef Lay<T> L;
     constexpr int VEC = Elem<T>::VEC;
     constexpr int CPR = BK / VEC;
-    constexpr int LDK = BK + VEC;
+    constexpr int LDK = L::LDK;
     constexpr int WPX = 4 / WCO;
     constexpr int WTCO = TCO / WCO, WTPX = TPX / WPX;
     constexpr int MT = WTCO / 16, NT = WTPX / 16;
@@ -70,8 +84,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_kernel(PatchParams p, 
     const int ty = t % p.tiles_y;
     const int n = t / p.tiles_y;
     const int y0 = ty * TR, x0 = tx * TC;
-    const T *xn = x + (size_t)n * p.H * p.W * p.ld_in;
-    const int ncc = p.Cin / BK;
+    const T *xn = x + (size_t)n * p.Hin * p.Win * p.ld_in;
+    const int ncc = p.Cin / BK, nit = ncc * 9;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -79,24 +93,27 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_kernel(PatchParams p, 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-    Vec16<T> rp[NP_V], ra[NA_V];
+    Vec16<T> rp[NP_V], wa[NA_V], wb[NA_V];
 
-    // addresses are fixed per workgroup up to a uniform (tap, channel-slab) term: compute them once
-    int poff[NP_V], woff[NA_V];          // element offsets, -1 = zero-fill
+    // global / LDS offsets are fixed per workgroup up to a uniform (tap, channel-slab) term: compute them once
+    int poff[NP_V], plds[NP_V], woff[NA_V], wlds[NA_V];      // element offsets, global -1 = zero-fill
 #pragma unroll
     for (int j = 0; j < NP_V; ++j) {
         const int e = tid + j * NTHREADS, q = e / CPR, ch = e % CPR;
         poff[j] = -1;
+        plds[j] = -1;
         if (q < npatch) {
             const int py = q / PW, px = q - py * PW;
-            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) poff[j] = (iy * p.W + ix) * p.ld_in + ch * VEC;
+            const int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px;
+            if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) poff[j] = (iy * p.Win + ix) * p.ld_in + ch * VEC;
+            plds[j] = L::off(q, ch);
         }
     }
 #pragma unroll
     for (int j = 0; j < NA_V; ++j) {
         const int e = tid + j * NTHREADS, row = e / CPR, ch = e % CPR;
         woff[j] = (row < TCO && co0 + row < p.Cout) ? (co0 + row) * p.Krow + ch * VEC : -1;
+        wlds[j] = row < TCO ? L::off(row, ch) : -1;
     }
 
     auto load_patch = [&](int cc) {
@@ -108,68 +125,80 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_kernel(PatchParams p, 
     };
     auto store_patch = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NP_V; ++j) {
-            const int e = tid + j * NTHREADS, q = e / CPR, ch = e % CPR;
-            if (q < npatch) rp[j].store(&Ps[buf][q * LDK + ch * VEC]);
-        }
+        for (int j = 0; j < NP_V; ++j)
+            if (plds[j] >= 0) rp[j].store(&Ps[buf][plds[j]]);
     };
-    auto load_w = [&](int cc, int tap) {
+    auto load_w = [&](Vec16<T> (&r)[NA_V], int it) {          // weight tile of global step `it` (= cc*9 + tap)
+        const int cc = it / 9, tap = it - cc * 9;
         const int u = tap * p.Cin + cc * BK;
 #pragma unroll
         for (int j = 0; j < NA_V; ++j) {
-            ra[j].zero();
-            if (woff[j] >= 0) ra[j].load(w + woff[j] + u);
+            r[j].zero();
+            if (woff[j] >= 0) r[j].load(w + woff[j] + u);
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](Vec16<T> (&r)[NA_V], int buf) {
 #pragma unroll
-        for (int j = 0; j < NA_V; ++j) {
-            const int e = tid + j * NTHREADS, row = e / CPR, ch = e % CPR;
-            if (row < TCO) ra[j].store(&Ws[buf][row * LDK + ch * VEC]);
-        }
+        for (int j = 0; j < NA_V; ++j)
+            if (wlds[j] >= 0) r[j].store(&Ws[buf][wlds[j]]);
     };
 
     const int wr = wave / WPX, wc = wave % WPX;
-    // patch element offset (in T) of the 16-pixel group j of this wave, lane's pixel included
-    int boff[NT];
+    int bpp[NT];                                 // patch pixel index of this lane's pixel in 16-pixel group j
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int q = wc * WTPX + 16 * j + (lane & 15);
-        boff[j] = ((q / TC) * PW + (q % TC)) * LDK;
+        bpp[j] = (q / TC) * PW + (q % TC);
     }
-    const int aoff = (wr * WTCO + (lane & 15)) * LDK;
+    const int arow = wr * WTCO + (lane & 15);
 
-    load_patch(0);
-    store_patch(0);
-    load_w(0, 0);
-    store_w(0);
-    __syncthreads();
-    const int nit = ncc * 9;
-    for (int it = 0; it < nit; ++it) {
-        const int cc = it / 9, tap = it - cc * 9;
-        const int kh = tap / 3, kw = tap - kh * 3;
-        if (tap == 0 && cc + 1 < ncc) load_patch(cc + 1);
-        if (it + 1 < nit) load_w(tap == 8 ? cc + 1 : cc, tap == 8 ? 0 : tap + 1);
-        {
-            const T *Wb = Ws[it & 1] + aoff;
-            const int shift = ((p.transposed ? 2 - kh : kh) * PW + (p.transposed ? 2 - kw : kw)) * LDK;
-            const T *Pb = Ps[cc & 1] + shift;
+    auto compute = [&](const T *Wt, const T *Pt, int shift) {
 #pragma unroll
-            for (int kk = 0; kk < Frag<T>::KSUB; ++kk) {
-                typename Frag<T>::type a[MT], b[NT];
+        for (int kk = 0; kk < L::KSUB; ++kk) {
+            typename L::frag a[MT], b[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = Frag<T>::ld(Wb + 16 * i * LDK, lane, kk);
+            for (int i = 0; i < MT; ++i) a[i] = L::ld(Wt, arow + 16 * i, lane, kk);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = Frag<T>::ld(Pb + boff[j], lane, kk);
+            for (int j = 0; j < NT; ++j) b[j] = L::ld(Pt, bpp[j] + shift, lane, kk);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(a[i], b[j], acc[i][j]);
-            }
+                for (int j = 0; j < NT; ++j) acc[i][j] = L::mma(a[i], b[j], acc[i][j]);
         }
-        if (it + 1 < nit) store_w((it + 1) & 1);
-        if (tap == 8 && cc + 1 < ncc) store_patch((cc + 1) & 1);
-        __syncthreads();
+    };
+
+    // ---- pipeline: weights two steps ahead (register sets wa / wb alternate), patch one slab ahead ------------
+    load_patch(0);
+    load_w(wa, 0);
+    store_patch(0);
+    store_w(wa, 0);
+    if (nit > 1) load_w(wa, 1);                  // wa holds step it+1 at even taps, wb at odd taps
+    __syncthreads();
+    for (int cc = 0; cc < ncc; ++cc) {
+        if (cc + 1 < ncc) load_patch(cc + 1);
+        const T *Pt = Ps[cc & 1];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int it = cc * 9 + tap;
+            const int kh = tap / 3, kw = tap % 3;
+            if (it + 2 < nit) {
+                if (tap & 1) load_w(wa, it + 2); else load_w(wb, it + 2);
+            }
+            const int shift = p.transposed ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
+            compute(Ws[it & 1], Pt, shift);
+            if (it + 1 < nit) {
+                if (tap & 1) store_w(wb, (it + 1) & 1); else store_w(wa, (it + 1) & 1);
+            }
+            if (tap == 8 && cc + 1 < ncc) store_patch((cc + 1) & 1);
+            __syncthreads();
+        }
+        // nine taps is odd: the two register sets have exchanged roles -- rename them back
+#pragma unroll
+        for (int j = 0; j < NA_V; ++j) {
+            Vec16<T> tmp = wa[j];
+            wa[j] = wb[j];
+            wb[j] = tmp;
+        }
     }
 
     // ---- epilogue (as conv_igemm.hip): 4 consecutive output channels per lane -------------------------------
@@ -245,10 +274,13 @@ void launch_T(const PatchParams &p, const void *x, const void *w, const float *b
 int rdfc_try_conv3x3_patch(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias,
                            void *out, hipStream_t st) {
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
-    if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->ph == 1 && d->pw == 1 && d->dh == 1 && d->dw == 1)) return 0;
-    if (Cin % BK != 0 || Cout <= 16 || d->Hi != d->Ho || d->Wi != d->Wo) return 0;
-    PatchParams p{d->N, d->Hi, d->Wi, Cin, Cout, transposed ? d->ldy : d->ldx, transposed ? d->ldx : d->ldy, transposed,
-                  d->act, d->slope, d->out_f32, 9 * Cin, 0, 0, 0, 0};
+    if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->ph == d->pw && d->ph <= 1 && d->dh == 1 && d->dw == 1)) return 0;
+    if (Cin % BK != 0 || Cout <= 16 || d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
+    const int pad = d->ph;
+    // forward: gather x (Hi x Wi) -> y (Ho x Wo), patch origin -pad; transposed: gather dy (Ho x Wo) -> dx (Hi x Wi), origin pad-2
+    PatchParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo,
+                  Cin, Cout, transposed ? d->ldy : d->ldx, transposed ? d->ldx : d->ldy, transposed,
+                  transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad, d->act, d->slope, d->out_f32, 9 * Cin, 0, 0, 0, 0};
     if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, in, w, bias, out, st);
     else launch_T<float>(p, in, w, bias, out, st);
     return 1;
