@@ -19,13 +19,13 @@ struct Map {       // geometry shared by the kernels
     int chunk;     // pixels per workgroup (host: chunk_pixels)
 };
 
-// Pixels per workgroup: ~8 rows per thread (4 independent 16-byte loads in flight per stream and
-// thread, two batches), so that a full-resolution map yields >= 2000 workgroups (8 per CU) and the
+// Pixels per workgroup: ~16 rows per thread (4 independent 16-byte loads in flight per stream and
+// thread, four batches), so that a full-resolution map yields >= 1000 workgroups (4 per CU) and the
 // small instance-norm maps still spread over the chip; capped at 4096 chunks per group.
 inline int chunk_pixels(int P, int C, int vec) {
     const int cvt = C / vec < NT ? (C / vec > 0 ? C / vec : 1) : NT;
     const int rpb = NT / cvt;
-    int chunk = 8 * rpb;
+    int chunk = 16 * rpb;
     const int lo = cdiv(P, 4096);
     if (chunk < lo) chunk = cdiv(lo, rpb) * rpb;
     return chunk;
@@ -125,26 +125,27 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
     block_reduce_store<T, 2>(cx, m, s, partial);
 }
 
-// fixed-order sum over the chunk partials of one (group, k, channel): 32 channels x 8 lanes per workgroup,
-// lane l adds chunks l, l+8, ... in f64, then the 8 lane sums are added in lane order (deterministic)
+// fixed-order sum over the chunk partials of one (group, k, channel): 32 channels x FL lanes per workgroup,
+// lane l adds chunks l, l+FL, ... in f64, then the FL lane sums are added in lane order (deterministic)
+constexpr int FL = 32, FNT = 32 * FL;
 __device__ inline double chunk_sum(const float *__restrict__ partial, int g, int K, int k, int C, int c, int nchunk,
-                                   double *red /* [8][32] */) {
+                                   double *red /* [FL][32] */) {
     const int lane = threadIdx.x >> 5, cl = threadIdx.x & 31;
     double s = 0;
     if (c < C)
-        for (int j = lane; j < nchunk; j += 8) s += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
+        for (int j = lane; j < nchunk; j += FL) s += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
     __syncthreads();
     red[lane * 32 + cl] = s;
     __syncthreads();
     double t = 0;
-    for (int l = 0; l < 8; ++l) t += red[l * 32 + cl];
+    for (int l = 0; l < FL; ++l) t += red[l * 32 + cl];
     return t;
 }
 
-__global__ __launch_bounds__(NT) void stats_finalize_kernel(Map m, int nchunk, const float *__restrict__ partial,
+__global__ __launch_bounds__(FNT) void stats_finalize_kernel(Map m, int nchunk, const float *__restrict__ partial,
                                                             float *__restrict__ mean, float *__restrict__ rstd, float eps,
                                                             float *run_mean, float *run_var, float momentum) {
-    __shared__ double red[8 * 32];
+    __shared__ double red[FL * 32];
     const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31);
     const double s1 = chunk_sum(partial, g, 2, 0, m.C, c, nchunk, red);
     const double s2 = chunk_sum(partial, g, 2, 1, m.C, c, nchunk, red);
@@ -245,9 +246,9 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
     block_reduce_store<T, 3>(cx, m, s, partial);
 }
 
-__global__ __launch_bounds__(NT) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
+__global__ __launch_bounds__(FNT) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
                                                           float *__restrict__ sums) {
-    __shared__ double red[8 * 32];
+    __shared__ double red[FL * 32];
     const int g = blockIdx.y / K, k = blockIdx.y % K, c = blockIdx.x * 32 + (threadIdx.x & 31);
     const double s = chunk_sum(partial, g, K, k, C, c, nchunk, red);
     if (threadIdx.x < 32 && c < C) sums[((size_t)g * K + k) * C + c] = (float)s;
@@ -486,7 +487,7 @@ extern "C" int rdfc_norm_finalize(const float *partial, float *mean, float *rstd
     RDFC_REQUIRE(G > 0 && P > 0 && C > 0, "rdfc_norm_finalize: non-positive size");
     RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_finalize: running statistics need G == 1 (batch norm)");
     Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(C, 32), G), dim3(NT), 0, (hipStream_t)stream, m, cdiv(P, m.chunk),
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(C, 32), G), dim3(FNT), 0, (hipStream_t)stream, m, cdiv(P, m.chunk),
                        partial, mean, rstd, eps, run_mean, run_var, momentum);
     RDFC_LAUNCH_CHECK("rdfc_norm_finalize");
     return 0;
@@ -518,7 +519,7 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
 }
 
 extern "C" int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, int dtype, void *stream) {
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), G * 3), dim3(NT), 0, (hipStream_t)stream, G, C, 3,
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), G * 3), dim3(FNT), 0, (hipStream_t)stream, G, C, 3,
                        cdiv(P, chunk_pixels(P, C, dtype == RDFC_BF16 ? 8 : 4)), partial, sums);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_finalize");
     return 0;
@@ -586,7 +587,7 @@ extern "C" int rdfc_channel_sum(const void *x, float *partial, float *out, int P
         dim3 grid(nchunk, 1, cdiv(C, NT));
         DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, chunk, (const T *)x, partial));
     }
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(NT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(FNT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out);
     RDFC_LAUNCH_CHECK("rdfc_channel_sum");
     return 0;
 }

@@ -126,7 +126,7 @@ class _ConvBlock(torch.autograd.Function):
             dy, g_res, sums = hip.norm_backward(dz, y, mean, rstd, gamma, beta, res, spec.act, spec.slope, prelu,
                                                 frozen=frozen, want_dres=res is not None and ctx.needs_input_grad[5])
             if gamma is not None:
-                g_gamma, g_beta = sums[0, 1].clone(), sums[0, 0].clone()
+                g_gamma, g_beta = sums[0, 1], sums[0, 0]
             if prelu is not None:
                 g_prelu = sums[:, 2].sum().view(1)
         else:

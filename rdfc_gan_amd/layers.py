@@ -27,6 +27,24 @@ def _act_of(m):
     return name, slope, (m.weight if name == 'prelu' else None)
 
 
+def _flush_batch_counter(module, prefix, keep_vars):
+    pending = module.__dict__.get('_rdfc_pending_batches', 0)
+    if pending:
+        module.num_batches_tracked += pending
+        module.__dict__['_rdfc_pending_batches'] = 0
+
+
+def _count_batch(norm, k):
+    """nn.BatchNorm2d.num_batches_tracked bookkeeping without a device op per layer and forward: counted on
+    the host, written into the buffer whenever a state_dict is taken (the value is only ever read there;
+    momentum is fixed, so it never enters the arithmetic)."""
+    d = norm.__dict__
+    if '_rdfc_pending_batches' not in d:
+        norm.register_state_dict_pre_hook(_flush_batch_counter)
+        d['_rdfc_pending_batches'] = 0
+    d['_rdfc_pending_batches'] += k
+
+
 def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
     """conv (nn.Conv2d | nn.ConvTranspose2d) [+ norm (BatchNorm2d | InstanceNorm2d)] [+ res] [+ act module]"""
     transposed = isinstance(conv, nn.ConvTranspose2d)
@@ -52,7 +70,7 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
         gamma, beta, rm, rv = norm.weight, norm.bias, norm.running_mean, norm.running_var
         training = norm.training
         if training and norm.num_batches_tracked is not None:
-            norm.num_batches_tracked += BN_STAT_REPEAT
+            _count_batch(norm, BN_STAT_REPEAT)
     return Fh.conv_block(x, conv.weight, conv.bias, gamma, beta, res, prelu, spec=spec, training=training,
                          run_mean=rm, run_var=rv)
 
