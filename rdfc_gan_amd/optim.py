@@ -86,16 +86,11 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.steps += 1
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        if self.flat.is_cuda:
-            hip.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
-                          g['eps'], self.steps, 1.0 / world)
-        else:   # host-side logic tests (gloo, no GPU): same arithmetic with torch ops
-            b1, b2 = g['betas']
-            gr = self.flat_grad / world
-            self.exp_avg.mul_(b1).add_(gr, alpha=1 - b1)
-            self.exp_avg_sq.mul_(b2).addcmul_(gr, gr, value=1 - b2)
-            bc1, bc2 = 1 - b1 ** self.steps, 1 - b2 ** self.steps
-            self.flat.addcdiv_(self.exp_avg, (self.exp_avg_sq.sqrt() / bc2 ** 0.5).add_(g['eps']), value=-g['lr'] / bc1)
+        if not self.flat.is_cuda:
+            raise RuntimeError('FlatAdam.step runs the HIP kernel rdfc_adam_step: parameters must live on the GPU '
+                               '(there is no CPU fallback)')
+        hip.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
+                      g['eps'], self.steps, 1.0 / world)
         Fh.invalidate_packed_weights()
 
     # ---- checkpoint format of torch.optim.Adam (lib/utils/checkpoint.py:21-58 stores optimizer.state_dict()) ----
