@@ -14,7 +14,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librdfc_hip.so')
+LIB_PATH = os.environ.get('RDFC_HIP_LIB', os.path.join(_HERE, 'librdfc_hip.so'))   # override: A/B builds of the kernels
 
 F32, BF16 = 0, 1
 # bench.py sets this to a list: every conv launch then appends (family, algorithmic flops, start, end) with
