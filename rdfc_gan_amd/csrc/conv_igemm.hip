@@ -34,7 +34,6 @@ struct IgemmParams {
 };
 
 constexpr int BK = 32;
-constexpr int NTHREADS = 256;
 constexpr int MAXTAPS = 64;
 
 template <typename T> struct Mma;
@@ -76,20 +75,21 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int TCO, int TPX, int WCO, bool VECLOAD>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p, const T *__restrict__ x,
+template <typename T, int TCO, int TPX, int WCO, bool VECLOAD, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS, NTHREADS == 512 && sizeof(T) == 2 ? 4 : 1) void igemm_kernel(IgemmParams p, const T *__restrict__ x,
                                                          const T *__restrict__ w, const float *__restrict__ bias,
                                                          void *__restrict__ yout) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int CPR = BK / VEC;                 // 16-byte chunks per tile row
     constexpr int LDK = BK + VEC;                 // padded row (elements)
-    constexpr int WPX = 4 / WCO;
+    constexpr int WPX = (NTHREADS / 64) / WCO;
     constexpr int WTCO = TCO / WCO, WTPX = TPX / WPX;
     constexpr int MT = WTCO / 16, NT = WTPX / 16;
     static_assert(MT >= 1 && NT >= 1, "tile");
     constexpr int NB_V = (TPX * CPR + NTHREADS - 1) / NTHREADS;   // vector loads / thread (pixels)
     constexpr int NA_V = (TCO * CPR + NTHREADS - 1) / NTHREADS;   // vector loads / thread (weights)
-    constexpr int NB_S = TPX / 8, NA_S = TCO / 8;                 // scalar loads / thread
+    constexpr int RSC = NTHREADS / 32;                           // rows covered per scalar-load pass
+    constexpr int NB_S = TPX / RSC, NA_S = TCO / RSC;             // scalar loads / thread
 
     __shared__ __attribute__((aligned(16))) T As[2][TCO * LDK];
     __shared__ __attribute__((aligned(16))) T Bs[2][TPX * LDK];
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p, const T 
             }
 #pragma unroll
             for (int j = 0; j < NB_S; ++j) {
-                const int row = r0 + 8 * j;
+                const int row = r0 + RSC * j;
                 T v = (T)0.0f;
                 const int nb = pxn[row], iy = pxy[row] + dy, ix = pxx[row] + dx;
                 if (kok && nb >= 0 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p, const T 
             }
 #pragma unroll
             for (int j = 0; j < NA_S; ++j) {
-                const int row = r0 + 8 * j;
+                const int row = r0 + RSC * j;
                 T v = (T)0.0f;
                 if (kok && co0 + row < p.Cout) v = w[(size_t)(co0 + row) * p.Krow + tw * p.Cin + ci];
                 sa[j] = v;
@@ -244,9 +244,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p, const T 
         } else {
             const int kk = tid & 31, r0 = tid >> 5;
 #pragma unroll
-            for (int j = 0; j < NB_S; ++j) Bs[buf][(r0 + 8 * j) * LDK + kk] = sb[j];
+            for (int j = 0; j < NB_S; ++j) Bs[buf][(r0 + RSC * j) * LDK + kk] = sb[j];
 #pragma unroll
-            for (int j = 0; j < NA_S; ++j) As[buf][(r0 + 8 * j) * LDK + kk] = sa[j];
+            for (int j = 0; j < NA_S; ++j) As[buf][(r0 + RSC * j) * LDK + kk] = sa[j];
         }
     };
 
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p, const T 
     }
 }
 
-template <typename T, int TCO, int TPX, int WCO>
+template <typename T, int TCO, int TPX, int WCO, int NTHREADS = 256>
 int launch_cfg(const IgemmParams &p, const void *x, const void *w, const float *bias, void *y, hipStream_t st) {
     int Pmax, nz = 1;
     if (!p.transposed) {
@@ -317,17 +317,17 @@ int launch_cfg(const IgemmParams &p, const void *x, const void *w, const float *
     }
     dim3 grid(cdiv(Pmax, TPX), cdiv(p.Cout, TCO), nz);
     if (p.Cin % BK == 0)
-        hipLaunchKernelGGL((igemm_kernel<T, TCO, TPX, WCO, true>), grid, dim3(NTHREADS), 0, st, p, (const T *)x,
+        hipLaunchKernelGGL((igemm_kernel<T, TCO, TPX, WCO, true, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, (const T *)x,
                            (const T *)w, bias, y);
     else
-        hipLaunchKernelGGL((igemm_kernel<T, TCO, TPX, WCO, false>), grid, dim3(NTHREADS), 0, st, p, (const T *)x,
+        hipLaunchKernelGGL((igemm_kernel<T, TCO, TPX, WCO, false, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, (const T *)x,
                            (const T *)w, bias, y);
     return 0;
 }
 
 template <typename T>
 int launch_T(const IgemmParams &p, const void *x, const void *w, const float *bias, void *y, hipStream_t st) {
-    if (p.Cout > 64) return launch_cfg<T, 128, 128, 2>(p, x, w, bias, y, st);
+    if (p.Cout > 64) return launch_cfg<T, 128, 128, 2, (sizeof(T) == 2 ? 512 : 256)>(p, x, w, bias, y, st);
     if (p.Cout > 32) return launch_cfg<T, 64, 256, 1>(p, x, w, bias, y, st);
     if (p.Cout > 16) return launch_cfg<T, 32, 256, 1>(p, x, w, bias, y, st);
     return launch_cfg<T, 16, 256, 1>(p, x, w, bias, y, st);
