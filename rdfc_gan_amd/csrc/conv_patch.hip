@@ -267,7 +267,8 @@ void launch_T(const PatchParams &p, const void *x, const void *w, const float *b
     constexpr int NTH = sizeof(T) == 2 ? 512 : 256;
     if (p.Cout > 64) launch_cfg<T, 128, 128, 2, NTH>(p, x, w, bias, y, st);
     else if (p.Cout > 32) launch_cfg<T, 64, 256, 1, 256>(p, x, w, bias, y, st);
-    else launch_cfg<T, 32, 256, 1, NTH>(p, x, w, bias, y, st);
+    else if (p.Cout > 16) launch_cfg<T, 32, 256, 1, NTH>(p, x, w, bias, y, st);
+    else launch_cfg<T, 16, 256, 1, 256>(p, x, w, bias, y, st);      // 1-channel heads: activation-traffic bound
 }
 
 }  // namespace
@@ -277,7 +278,7 @@ int rdfc_try_conv3x3_patch(const rdfc_conv_desc *d, int transposed, const void *
                            void *out, hipStream_t st) {
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->ph == d->pw && d->ph <= 1 && d->dh == 1 && d->dw == 1)) return 0;
-    if (Cin % BK != 0 || Cout <= 16 || d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
+    if (Cin % BK != 0 || d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
     const int pad = d->ph;
     // forward: gather x (Hi x Wi) -> y (Ho x Wo), patch origin -pad; transposed: gather dy (Ho x Wo) -> dx (Hi x Wi), origin pad-2
     PatchParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo,
