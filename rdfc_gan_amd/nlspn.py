@@ -36,10 +36,19 @@ class ModulatedDeformConvFunction(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         input, offset, mask, weight, bias = ctx.saved_tensors
-        gi, go, gm, gw, gb = DCN.modulated_deform_conv_backward(
-            input.contiguous(), weight, bias, offset, mask, grad_output, ctx.kernel_size[0], ctx.kernel_size[1],
-            ctx.stride[0], ctx.stride[1], ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1], ctx.groups,
-            ctx.deformable_groups, ctx.im2col_step)
+        # upstream's extension always computes all five gradients; NLSPN freezes w / b (nlspn_model.py:55-59) and
+        # detaches the offsets of the confidence gathers, so only the ones autograd asks for are launched
+        need = tuple(ctx.needs_input_grad[:5])
+        if all(need):
+            gi, go, gm, gw, gb = DCN.modulated_deform_conv_backward(
+                input.contiguous(), weight, bias, offset, mask, grad_output, ctx.kernel_size[0], ctx.kernel_size[1],
+                ctx.stride[0], ctx.stride[1], ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1], ctx.groups,
+                ctx.deformable_groups, ctx.im2col_step)
+        else:
+            from . import hip
+            gi, go, gm, gw, gb = hip.mdconv_backward(input.contiguous(), offset.contiguous(), mask.contiguous(), weight,
+                                                     grad_output.contiguous(), ctx.stride, ctx.padding, ctx.dilation,
+                                                     ctx.groups, ctx.deformable_groups, need=need)
         return gi, go, gm, gw, gb, None, None, None, None, None, None
 
 
