@@ -15,6 +15,8 @@
 // inner -- f32 accumulation, so results agree to rounding, not bitwise, with the generic kernel).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct PatchParams {
@@ -241,6 +243,169 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? (NTHREADS == 512 ? 4 : 2
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Slab-resident variant: per 32-channel slab the workgroup stages the halo patch AND the weights of all nine
+// taps ([tap][co][32 k], same swizzled rows) in LDS, then runs the nine taps back to back with no barrier
+// in between (144 MFMAs per wave on the 64x256 tile).  The next slab is prefetched into registers while the
+// current one is being consumed: two barriers per slab instead of nine, and a whole slab of MFMA time to
+// cover the global-load latency.
+template <typename T, int TCO, int TPX, int WCO, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? (NTHREADS == 512 ? 2 : 2) : 1) void conv3x3_slab_kernel(
+    PatchParams p, const T *__restrict__ x, const T *__restrict__ w, const float *__restrict__ bias, void *__restrict__ yout) {
+    typedef Lay<T> L;
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int CPR = BK / VEC;
+    constexpr int LDK = L::LDK;
+    constexpr int WPX = (NTHREADS / 64) / WCO;
+    constexpr int WTCO = TCO / WCO, WTPX = TPX / WPX;
+    constexpr int MT = WTCO / 16, NT = WTPX / 16;
+    constexpr int MAXPATCH = TPX + 2 * 64 + 2 * (TPX / 64) + 4;
+    constexpr int NP_V = (MAXPATCH * CPR + NTHREADS - 1) / NTHREADS;
+    constexpr int NW_V = (9 * TCO * CPR + NTHREADS - 1) / NTHREADS;
+
+    __shared__ __attribute__((aligned(16))) T Ws[9 * TCO * LDK];
+    __shared__ __attribute__((aligned(16))) T Ps[MAXPATCH * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.y * TCO;
+    const int TR = p.TR, TC = p.TC, PW = TC + 2, PH = TR + 2, npatch = PH * PW;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int n = t / p.tiles_y;
+    const int y0 = ty * TR, x0 = tx * TC;
+    const T *xn = x + (size_t)n * p.Hin * p.Win * p.ld_in;
+    const int ncc = p.Cin / BK;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    Vec16<T> rp[NP_V], rw[NW_V];
+    int poff[NP_V], plds[NP_V], woff[NW_V], wlds[NW_V];
+#pragma unroll
+    for (int j = 0; j < NP_V; ++j) {
+        const int e = tid + j * NTHREADS, q = e / CPR, ch = e % CPR;
+        poff[j] = -1;
+        plds[j] = -1;
+        if (q < npatch) {
+            const int py = (int)(((float)q + 0.5f) * (1.0f / (float)PW)), px = q - py * PW;
+            const int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px;
+            if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) poff[j] = (iy * p.Win + ix) * p.ld_in + ch * VEC;
+            plds[j] = L::off(q, ch);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NW_V; ++j) {        // entry e -> (tap, row, chunk)
+        const int e = tid + j * NTHREADS, ch = e % CPR, rr = e / CPR, tap = rr / TCO, row = rr - tap * TCO;
+        woff[j] = (tap < 9 && co0 + row < p.Cout) ? (co0 + row) * p.Krow + tap * p.Cin + ch * VEC : -1;
+        wlds[j] = tap < 9 ? tap * TCO * LDK + L::off(row, ch) : -1;
+    }
+    auto load_slab = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < NP_V; ++j) {
+            rp[j].zero();
+            if (poff[j] >= 0) rp[j].load(xn + poff[j] + cc * BK);
+        }
+#pragma unroll
+        for (int j = 0; j < NW_V; ++j) {
+            rw[j].zero();
+            if (woff[j] >= 0) rw[j].load(w + woff[j] + cc * BK);
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int j = 0; j < NP_V; ++j)
+            if (plds[j] >= 0) rp[j].store(&Ps[plds[j]]);
+#pragma unroll
+        for (int j = 0; j < NW_V; ++j)
+            if (wlds[j] >= 0) rw[j].store(&Ws[wlds[j]]);
+    };
+
+    const int wr = wave / WPX, wc = wave % WPX;
+    int bpp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int q = wc * WTPX + 16 * j + (lane & 15);
+        bpp[j] = (q / TC) * PW + (q % TC);
+    }
+    const int arow = wr * WTCO + (lane & 15);
+
+    load_slab(0);
+    store_slab();
+    __syncthreads();
+    for (int cc = 0; cc < ncc; ++cc) {
+        if (cc + 1 < ncc) load_slab(cc + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            const int shift = p.transposed ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
+            const T *Wt = Ws + tap * TCO * LDK;
+#pragma unroll
+            for (int kk = 0; kk < L::KSUB; ++kk) {
+                typename L::frag a[MT], b[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = L::ld(Wt, arow + 16 * i, lane, kk);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = L::ld(Ps, bpp[j] + shift, lane, kk);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = L::mma(a[i], b[j], acc[i][j]);
+            }
+        }
+        if (cc + 1 < ncc) {
+            __syncthreads();          // everyone is done reading this slab
+            store_slab();
+            __syncthreads();
+        }
+    }
+
+    const int q4 = (lane >> 4) * 4;
+    const bool vec_ok = (p.ld_out & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int q = wc * WTPX + 16 * j + (lane & 15);
+        const int oy = y0 + q / TC, ox = x0 + q % TC;
+        if (oy >= p.H || ox >= p.W) continue;
+        const size_t po = ((size_t)n * p.H + oy) * p.W + ox;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int co = co0 + wr * WTCO + 16 * i + q4;
+            if (co >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = acc[i][j][r];
+                if (bias != nullptr && co + r < p.Cout) u += bias[co + r];
+                v[r] = act_fwd(u, p.act, p.slope);
+            }
+            const size_t off = po * p.ld_out + co;
+            if (p.out_f32 || sizeof(T) == 4) {
+                float *y = reinterpret_cast<float *>(yout) + off;
+                if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                else
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.Cout) y[r] = v[r];
+            } else {
+                bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
+                if (vec_ok && co + 3 < p.Cout) {
+                    bf16x4 o;
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x4 *>(y) = o;
+                } else
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+            }
+        }
+    }
+}
+
+template <typename T, int TCO, int TPX, int WCO, int NTHREADS>
+void launch_slab(PatchParams p, const void *x, const void *w, const float *bias, void *y, hipStream_t st);
+
 // tile shape with the least padding waste for an H x W map
 void pick_tile(int H, int W, int TPX, int &TR, int &TC) {
     double best = -1;
@@ -260,10 +425,31 @@ void launch_cfg(PatchParams p, const void *x, const void *w, const float *bias, 
     hipLaunchKernelGGL((conv3x3_patch_kernel<T, TCO, TPX, WCO, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, (const T *)x, (const T *)w, bias, y);
 }
 
+template <typename T, int TCO, int TPX, int WCO, int NTHREADS>
+void launch_slab(PatchParams p, const void *x, const void *w, const float *bias, void *y, hipStream_t st) {
+    pick_tile(p.H, p.W, TPX, p.TR, p.TC);
+    p.tiles_x = cdiv(p.W, p.TC);
+    p.tiles_y = cdiv(p.H, p.TR);
+    dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
+    hipLaunchKernelGGL((conv3x3_slab_kernel<T, TCO, TPX, WCO, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, (const T *)x, (const T *)w, bias, y);
+}
+
 template <typename T>
 void launch_T(const PatchParams &p, const void *x, const void *w, const float *bias, void *y, hipStream_t st) {
     // bf16: 8 waves / workgroup (4 waves per SIMD at 2 workgroups per CU) where it measured faster in an
     // interleaved A/B on one device: +15-18 % on the 128x128 tile, +8 % on 32x256, -5..-13 % on 64x256 (spills)
+    // Variant choice from interleaved A/B runs on one device (tools/ab_env.sh): the slab-resident kernel wins for
+    // Cout <= 64 (+7..13 %, 1-channel heads +68 %) and for the 512-channel layers (+13 %); the per-tap kernel with
+    // 8-wave workgroups (2 workgroups / CU) wins for 128- and 256-channel outputs (+6..9 %).
+    static const int slab_env = getenv("RDFC_SLAB") ? atoi(getenv("RDFC_SLAB")) : -1;
+    const bool slab = slab_env >= 0 ? slab_env != 0 : (p.Cout <= 64 || p.Cin >= 512);
+    if constexpr (sizeof(T) == 2) if (slab) {
+        if (p.Cout > 64) launch_slab<T, 128, 256, 2, 512>(p, x, w, bias, y, st);
+        else if (p.Cout > 32) launch_slab<T, 64, 256, 1, 256>(p, x, w, bias, y, st);
+        else if (p.Cout > 16) launch_slab<T, 32, 256, 1, 256>(p, x, w, bias, y, st);
+        else launch_slab<T, 16, 256, 1, 256>(p, x, w, bias, y, st);
+        return;
+    }
     constexpr int NTH = sizeof(T) == 2 ? 512 : 256;
     if (p.Cout > 64) launch_cfg<T, 128, 128, 2, NTH>(p, x, w, bias, y, st);
     else if (p.Cout > 32) launch_cfg<T, 64, 256, 1, 256>(p, x, w, bias, y, st);
