@@ -11,6 +11,8 @@
 // 4-byte reads (f32 MFMA takes one k per lane).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct WgradParams {
@@ -248,6 +250,8 @@ void launch_T(const WgradParams &p, const void *x, const void *dy, float *dw, hi
 
 }  // namespace
 
+int rdfc_try_wgrad9(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad9.hip
+
 extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream) {
     RDFC_REQUIRE(d != nullptr, "rdfc_conv2d_wgrad: null descriptor");
     RDFC_REQUIRE(d->dtype == RDFC_F32 || d->dtype == RDFC_BF16, "rdfc_conv2d_wgrad: bad dtype %d", d->dtype);
@@ -260,7 +264,9 @@ extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const v
     WgradParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
                   d->ldx, d->ldy, d->N * d->Ho * d->Wo, 0};
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, dy, dw_packed, st);
+    static const bool w9 = getenv("RDFC_NO_WGRAD9") == nullptr;
+    if (w9 && rdfc_try_wgrad9(d, x, dy, dw_packed, st)) {
+    } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, dy, dw_packed, st);
     else launch_T<float>(p, x, dy, dw_packed, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_wgrad");
     return 0;
