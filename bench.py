@@ -178,25 +178,32 @@ def main():
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
         if prof:
-            fam = {}
-            for name, flops, e0, e1, _shape in prof:
-                d = fam.setdefault(name, [0.0, 0.0, 0])
-                d[0] += flops
-                d[1] += e0.elapsed_time(e1) * 1e-3
-                d[2] += 1
-            top = max(fam, key=lambda k: fam[k][1])
-            fl, sec, n = fam[top]
+            fam, sym = {}, {}
+            for name, flops, e0, e1, _shape, kernel in prof:
+                ms = e0.elapsed_time(e1)
+                for tab, key in ((fam, name), (sym, kernel)):
+                    d = tab.setdefault(key, [0.0, 0.0, 0])
+                    d[0] += flops
+                    d[1] += ms * 1e-3
+                    d[2] += 1
+            # the dominant kernel = the single kernel symbol (template instantiation, as rocprofv3 names it) with the
+            # largest summed duration over the timed region; algorithmic flops = 2*N*Ho*Wo*Co*Ci*KH*KW per launch
+            top = max(sym, key=lambda k: sym[k][1])
+            fl, sec, n = sym[top]
             peak = PEAK_TFLOPS[a.dtype]
             out['roofline'] = dict(bound='mfma', kernel=top, achieved=round(fl / sec / 1e12, 2), peak=peak, unit='TFLOP/s',
                                    frac=round(fl / sec / 1e12 / peak, 4), traffic=None, launches=n,
                                    avg_launch_us=round(1e6 * sec / n, 2),
                                    share_of_step=round(sec / (elapsed / 1.0), 4))
+            out['kernels'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), avg_launch_us=round(1e6 * v[1] / v[2], 2),
+                                      launches=v[2], share_of_step=round(v[1] / elapsed, 4))
+                              for k, v in sorted(sym.items(), key=lambda kv: -kv[1][1])[:8]}
             out['kernel_families'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), seconds=round(v[1], 4), launches=v[2],
                                               share_of_step=round(v[1] / elapsed, 4)) for k, v in sorted(fam.items())}
         if prof and a.by_shape:
             tab = {}
-            for name, flops, e0, e1, shp in prof:
-                d = tab.setdefault((name.split(' ')[0],) + shp, [0.0, 0.0, 0])
+            for name, flops, e0, e1, shp, kernel in prof:
+                d = tab.setdefault((kernel.replace(' ', ''),) + shp, [0.0, 0.0, 0])
                 d[0] += flops
                 d[1] += e0.elapsed_time(e1) * 1e-3
                 d[2] += 1
@@ -204,7 +211,7 @@ def main():
                 f.write('kernel N Hi Wi Ci Ho Wo Co K s | launches ms_total us_avg TFLOP/s\n')
                 for k, v in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                     f.write(' '.join(map(str, k)) + f' | {v[2]} {1e3 * v[1]:.2f} {1e6 * v[1] / v[2]:.1f} {v[0] / v[1] / 1e12:.1f}\n')
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:    # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(a.height, a.width, True)
         print(json.dumps(out))
     if world > 1:

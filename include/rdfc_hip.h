@@ -36,6 +36,10 @@ enum { RDFC_ACT_NONE = 0, RDFC_ACT_RELU = 1, RDFC_ACT_LRELU = 2, RDFC_ACT_TANH =
        RDFC_ACT_PRELU = 5 /* slope read from device memory */ };
 
 const char *rdfc_last_error(void);
+/* name of the kernel instantiation the calling thread's last rdfc_conv2d_* call launched (e.g.
+ * "conv3x3_slab_kernel<__bf16, 64, 128, 1, 256>"), matching the demangled symbol in a rocprofv3 kernel trace.
+ * Measurement aid only (bench.py's per-kernel roofline); no upstream counterpart. */
+const char *rdfc_last_kernel(void);
 int rdfc_version(void);
 
 /* ------------------------------------------------------------------------------

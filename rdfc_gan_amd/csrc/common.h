@@ -17,6 +17,10 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // ---- error plumbing -----------------------------------------------------------
 void rdfc_set_error(const char *fmt, ...);
+// name of the kernel instantiation the last conv entry point launched (rdfc_last_kernel(), used by bench.py to
+// attribute HIP-event times to one kernel symbol that can be matched against rocprofv3's kernel trace)
+void rdfc_note_kernel(const char *fmt, ...);
+template <typename T> inline const char *tname() { return sizeof(T) == 2 ? "__bf16" : "float"; }
 #define RDFC_REQUIRE(cond, ...)            \
     do {                                   \
         if (!(cond)) {                     \

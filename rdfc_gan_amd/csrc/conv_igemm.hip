@@ -316,6 +316,7 @@ int launch_cfg(const IgemmParams &p, const void *x, const void *w, const float *
         Pmax = p.N * ((p.Hout + p.sh - 1) / p.sh) * ((p.Wout + p.sw - 1) / p.sw);
     }
     dim3 grid(cdiv(Pmax, TPX), cdiv(p.Cout, TCO), nz);
+    rdfc_note_kernel("igemm_kernel<%s, %d, %d, %d, %s, %d>", tname<T>(), TCO, TPX, WCO, p.Cin % BK == 0 ? "true" : "false", NTHREADS);
     if (p.Cin % BK == 0)
         hipLaunchKernelGGL((igemm_kernel<T, TCO, TPX, WCO, true, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, (const T *)x,
                            (const T *)w, bias, y);

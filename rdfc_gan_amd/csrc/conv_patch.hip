@@ -422,6 +422,7 @@ void launch_cfg(PatchParams p, const void *x, const void *w, const float *bias, 
     p.tiles_x = cdiv(p.W, p.TC);
     p.tiles_y = cdiv(p.H, p.TR);
     dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
+    rdfc_note_kernel("conv3x3_patch_kernel<%s, %d, %d, %d, %d>", tname<T>(), TCO, TPX, WCO, NTHREADS);
     hipLaunchKernelGGL((conv3x3_patch_kernel<T, TCO, TPX, WCO, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, (const T *)x, (const T *)w, bias, y);
 }
 
@@ -431,6 +432,7 @@ void launch_slab(PatchParams p, const void *x, const void *w, const float *bias,
     p.tiles_x = cdiv(p.W, p.TC);
     p.tiles_y = cdiv(p.H, p.TR);
     dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
+    rdfc_note_kernel("conv3x3_slab_kernel<%s, %d, %d, %d, %d>", tname<T>(), TCO, TPX, WCO, NTHREADS);
     hipLaunchKernelGGL((conv3x3_slab_kernel<T, TCO, TPX, WCO, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, (const T *)x, (const T *)w, bias, y);
 }
 

@@ -234,6 +234,7 @@ void launch_cfg(const WgradParams &p0, const void *x, const void *dy, float *dw,
     constexpr int VEC = Elem<T>::VEC;
     const bool vy = (p.Co % VEC == 0) && (p.ldy % VEC == 0), vx = (p.Ci % VEC == 0) && (p.ldx % VEC == 0);
     const T *xp = (const T *)x, *yp = (const T *)dy;
+    rdfc_note_kernel("wgrad_kernel<%s, %d, %d, %d, %s, %s, %d>", tname<T>(), TCO, TCI, WCO, vy ? "true" : "false", vx ? "true" : "false", NTHREADS);
     if (vy && vx) hipLaunchKernelGGL((wgrad_kernel<T, TCO, TCI, WCO, true, true, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, xp, yp, dw);
     else if (vy) hipLaunchKernelGGL((wgrad_kernel<T, TCO, TCI, WCO, true, false, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, xp, yp, dw);
     else if (vx) hipLaunchKernelGGL((wgrad_kernel<T, TCO, TCI, WCO, false, true, NTHREADS>), grid, dim3(NTHREADS), 0, st, p, xp, yp, dw);

@@ -201,6 +201,7 @@ int rdfc_try_wgrad9(const rdfc_conv_desc *d, const void *x, const void *dy, floa
     p.segs_per_slice = cdiv(p.total_segs, slices);
     slices = cdiv(p.total_segs, p.segs_per_slice);
     dim3 grid(slices, tiles);
+    rdfc_note_kernel("wgrad9_kernel<%s>", d->dtype == RDFC_BF16 ? "__bf16" : "float");
     if (d->dtype == RDFC_BF16) hipLaunchKernelGGL(wgrad9_kernel<bf16_t>, grid, dim3(NTH), 0, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw);
     else hipLaunchKernelGGL(wgrad9_kernel<float>, grid, dim3(NTH), 0, st, p, (const float *)x, (const float *)dy, dw);
     return 1;

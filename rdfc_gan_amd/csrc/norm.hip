@@ -19,18 +19,28 @@ struct Map {       // geometry shared by the kernels
     int chunk;     // pixels per workgroup (host: chunk_pixels)
 };
 
-// Pixels per workgroup: ~16 rows per thread (4 independent 16-byte loads in flight per stream and
-// thread, four batches), so that a full-resolution map yields >= 1000 workgroups (4 per CU) and the
+// Pixels per workgroup: ~32 rows per thread (4 independent 16-byte loads in flight per stream and
+// thread, eight batches), so that a full-resolution map yields >= 500 workgroups (2 per CU) and the
 // small instance-norm maps still spread over the chip; capped at 4096 chunks per group.
 inline int chunk_pixels(int P, int C, int vec) {
     const int cvt = C / vec < NT ? (C / vec > 0 ? C / vec : 1) : NT;
     const int rpb = NT / cvt;
-    int chunk = 16 * rpb;
+    int chunk = 32 * rpb;
     const int lo = cdiv(P, 4096);
     if (chunk < lo) chunk = cdiv(lo, rpb) * rpb;
     return chunk;
 }
 inline Map make_map(int G, int P, int C, int vec) { return Map{G, P, C, chunk_pixels(P, C, vec)}; }
+// streaming (non-reducing) kernels: 8 rows per thread -> 4x more workgroups than the reductions
+inline Map make_map_stream(int G, int P, int C, int vec) {
+    Map m = make_map(G, P, C, vec);
+    int c = m.chunk / 4;
+    const int lo = cdiv(P, 8192);
+    if (c < lo) c = lo;
+    if (c < 1) c = 1;
+    m.chunk = c;
+    return m;
+}
 
 // body(p) for p = begin + r0, +RPB, ... < end, four rows per trip so four independent loads are in flight
 #define ROW_LOOP(cx, body)                                                          \
@@ -73,28 +83,58 @@ inline dim3 grid_for(const Map &m, int vec) {
     return dim3(cdiv(m.P, m.chunk), m.G, cdiv(m.C / vec, NT));
 }
 
-// block-level reduction of K*VEC per-thread sums over the RPB rows, then write partial[g][chunk][k][c]
+// block-level reduction of K*VEC per-thread sums over the RPB rows, then write partial[g][chunk][k][c].
+// When the channel-vector count CVT divides 64, rows that share a channel vector sit in the same wave at lane
+// stride CVT: butterfly over those lanes first (xor CVT, 2CVT, ...), then one LDS slot per wave -- instead of a
+// handful of threads serially adding up to 64 rows out of LDS (that tail used to cost more than the streaming part).
 template <typename T, int K>
 __device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K][Elem<T>::VEC], float *partial) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[K * NT * VEC];
     const int t = threadIdx.x;
+    const int CVT = min(m.C / VEC - (int)blockIdx.z * NT, NT);
+    const bool wave_tree = CVT < 64 && (64 % CVT) == 0;
+    if (wave_tree) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float a = cx.active ? s[k][v] : 0.f;
+                for (int off = CVT; off < 64; off <<= 1) a += __shfl_xor(a, off, 64);
+                s[k][v] = a;
+            }
+        const int lane = t & 63, wave = t >> 6;
+        if (lane < CVT) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) red[((k * 4 + wave) * 64 + lane) * VEC + v] = s[k][v];
+        }
+        __syncthreads();
+        if (t < CVT) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float a = 0.f;
+                    for (int w = 0; w < NT / 64; ++w) a += red[((k * 4 + w) * 64 + t) * VEC + v];
+                    partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + cx.c0 + v] = a;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) red[(k * NT + t) * VEC + v] = cx.active ? s[k][v] : 0.f;
     __syncthreads();
     if (cx.active && cx.r0 == 0) {
-        const int CVT = NT / cx.RPB >= 1 ? (NT / cx.RPB) : 1;
-        (void)CVT;
-        const int cvt = t;   // r0 == 0 -> t == cv - slab0
-        const int stride = min(m.C / VEC - (int)blockIdx.z * NT, NT);
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 float a = 0.f;
-                for (int r = 0; r < cx.RPB; ++r) a += red[(k * NT + r * stride + cvt) * VEC + v];
+                for (int r = 0; r < cx.RPB; ++r) a += red[(k * NT + r * CVT + t) * VEC + v];
                 partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + cx.c0 + v] = a;
             }
     }
@@ -131,9 +171,18 @@ constexpr int FL = 32, FNT = 32 * FL;
 __device__ inline double chunk_sum(const float *__restrict__ partial, int g, int K, int k, int C, int c, int nchunk,
                                    double *red /* [FL][32] */) {
     const int lane = threadIdx.x >> 5, cl = threadIdx.x & 31;
-    double s = 0;
-    if (c < C)
-        for (int j = lane; j < nchunk; j += FL) s += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;          // fixed association -> still deterministic, 4 loads in flight
+    if (c < C) {
+        int j = lane;
+        for (; j + 3 * FL < nchunk; j += 4 * FL) {
+            s0 += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
+            s1 += partial[(((size_t)g * nchunk + j + FL) * K + k) * C + c];
+            s2 += partial[(((size_t)g * nchunk + j + 2 * FL) * K + k) * C + c];
+            s3 += partial[(((size_t)g * nchunk + j + 3 * FL) * K + k) * C + c];
+        }
+        for (; j < nchunk; j += FL) s0 += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
+    }
+    const double s = (s0 + s1) + (s2 + s3);
     __syncthreads();
     red[lane * 32 + cl] = s;
     __syncthreads();
@@ -165,9 +214,12 @@ __global__ __launch_bounds__(FNT) void stats_finalize_kernel(Map m, int nchunk, 
 
 struct ApplyArgs {
     const float *mean, *rstd, *gamma, *beta, *prelu;
-    int act;
+    int act;            // none | relu | lrelu | prelu only: all piecewise linear -> act(u) = u > 0 ? u : u * neg_slope
     float slope;
 };
+__device__ inline float neg_slope_of(const ApplyArgs &a) {
+    return a.act == RDFC_ACT_NONE ? 1.f : (a.act == RDFC_ACT_RELU ? 0.f : (a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope));
+}
 
 template <typename T>
 __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *__restrict__ x, const T *__restrict__ res,
@@ -184,7 +236,7 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
         sc[v] = ga * r;
         sh[v] = be - mu * ga * r;
     }
-    const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
+    const float ns = neg_slope_of(a);
     const size_t gb = (size_t)cx.g * m.P;
     auto body = [&](int p) {
         Vec16<T> xv, rv, o;
@@ -194,7 +246,7 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
         for (int v = 0; v < VEC; ++v) {
             float u = sc[v] * xv.get(v) + sh[v];
             if (res) u += rv.get(v);
-            o.set(v, act_fwd(u, a.act, slope));
+            o.set(v, u > 0.f ? u : u * ns);
         }
         o.store(z + (gb + p) * ldz + cx.c0);
     };
@@ -222,7 +274,8 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
             sc[v] = ga * rs[v];                 // the forward's (apply_kernel) pre-activation, bit for bit,
             sh[v] = be - mu[v] * ga * rs[v];    // so the activation mask cannot disagree with the forward
         }
-        const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
+        const float ns = neg_slope_of(a);
+        const bool want_slope_grad = a.act == RDFC_ACT_PRELU;
         const size_t gb = (size_t)cx.g * m.P;
         auto body = [&](int p) {
             Vec16<T> dv, xv, rv;
@@ -231,14 +284,15 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
             if (res) rv.load(res + (gb + p) * ldr + cx.c0);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const float xh = (xv.get(v) - mu[v]) * rs[v];
-                float u = sc[v] * xv.get(v) + sh[v];
+                const float xv_ = xv.get(v);
+                const float xh = (xv_ - mu[v]) * rs[v];
+                float u = sc[v] * xv_ + sh[v];
                 if (res) u += rv.get(v);
                 const float d = dv.get(v);
-                const float du = d * act_grad_pre(u, a.act, slope);
+                const float du = u > 0.f ? d : d * ns;
                 s[0][v] += du;
                 s[1][v] += du * xh;
-                s[2][v] += d * fminf(u, 0.f);
+                if (want_slope_grad) s[2][v] += d * fminf(u, 0.f);
             }
         };
         ROW_LOOP(cx, body);
@@ -276,7 +330,7 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const
         m1[v] = frozen ? 0.f : sums[(cx.g * 3 + 0) * m.C + c] * invP;
         m2[v] = frozen ? 0.f : sums[(cx.g * 3 + 1) * m.C + c] * invP;
     }
-    const float slope = a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope;
+    const float ns = neg_slope_of(a);
     const size_t gb = (size_t)cx.g * m.P;
     auto body = [&](int p) {
         Vec16<T> dv, xv, rv, o, orr;
@@ -288,7 +342,8 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const
             const float xh = (xv.get(v) - mu[v]) * rs[v];
             float u = sc[v] * xv.get(v) + sh[v];
             if (res) u += rv.get(v);
-            const float du = dv.get(v) * act_grad_pre(u, a.act, slope);
+            const float d = dv.get(v);
+            const float du = u > 0.f ? d : d * ns;
             o.set(v, sc[v] * (du - m1[v] - xh * m2[v]));
             orr.set(v, du);
         }
@@ -498,7 +553,8 @@ extern "C" int rdfc_norm_apply(const void *x, const float *mean, const float *rs
                                int act, float slope, const float *prelu, void *stream) {
     if (int e = check_map("rdfc_norm_apply", G, P, C, dtype, {ldx, ldz})) return e;
     RDFC_REQUIRE(act != RDFC_ACT_PRELU || prelu != nullptr, "rdfc_norm_apply: PReLU needs the slope pointer");
-    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    RDFC_REQUIRE(act != RDFC_ACT_TANH && act != RDFC_ACT_SIGMOID, "rdfc_norm_apply: tanh / sigmoid never follow a norm on this path (conv epilogue only)");
+    Map m = make_map_stream(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)x, (const T *)res, (T *)z, ldx, ldr, ldz));
@@ -530,7 +586,7 @@ extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *m
                                    int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
                                    const float *prelu, int frozen_stats, void *stream) {
     if (int e = check_map("rdfc_norm_bwd_apply", G, P, C, dtype, {lddz, ldx, lddx})) return e;
-    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map_stream(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
@@ -543,7 +599,7 @@ extern "C" int rdfc_adain_apply(const void *x, const float *mean, const float *r
                                 int C, int ldx, int ldgb, int ldo, int dtype, void *stream) {
     if (int e = check_map("rdfc_adain_apply", N, P, C, dtype, {ldx, ldo})) return e;
     RDFC_REQUIRE(ldgb >= 2 * C, "rdfc_adain_apply: ldgb must cover 2C channels");
-    Map m = make_map(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map_stream(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
     DISPATCH(dtype, hipLaunchKernelGGL(adain_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, mean,
                                        rstd, (const T *)x, (const T *)gb, (T *)out, ldx, ldgb, ldo));
     RDFC_LAUNCH_CHECK("rdfc_adain_apply");
@@ -564,7 +620,7 @@ extern "C" int rdfc_adain_bwd_apply(const void *dout, const void *x, const float
                                     const float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx, int ldgb,
                                     int lddx, int lddgb, int dtype, void *stream) {
     if (int e = check_map("rdfc_adain_bwd_apply", N, P, C, dtype, {lddo, ldx, lddx})) return e;
-    Map m = make_map(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map_stream(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
     DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
                                        mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, sums, (T *)dx, (T *)dgb, lddo,
                                        ldx, ldgb, lddx, lddgb));

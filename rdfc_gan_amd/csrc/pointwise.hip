@@ -14,6 +14,14 @@ void rdfc_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" const char *rdfc_last_error(void) { return g_err; }
+static thread_local char g_kernel[128] = "";
+void rdfc_note_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof g_kernel, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *rdfc_last_kernel(void) { return g_kernel; }
 extern "C" int rdfc_version(void) { return 100; }
 
 namespace {

@@ -44,6 +44,7 @@ def lib():
                                '(there is no CPU or PyTorch fallback for the HIP kernels)')
         _lib = C.CDLL(LIB_PATH)
         _lib.rdfc_last_error.restype = C.c_char_p
+        _lib.rdfc_last_kernel.restype = C.c_char_p
     return _lib
 
 
@@ -130,8 +131,8 @@ class _Timed:
     def __init__(self, family, d):
         self.on = PROFILE is not None
         if self.on:
-            self.rec = (family, _conv_flops(d), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-                        (d.N, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.KH, d.sh))
+            self.rec = [family, _conv_flops(d), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+                        (d.N, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.KH, d.sh), None]
 
     def __enter__(self):
         if self.on:
@@ -140,6 +141,7 @@ class _Timed:
     def __exit__(self, *exc):
         if self.on:
             self.rec[3].record()
+            self.rec[5] = lib().rdfc_last_kernel().decode()
             PROFILE.append(self.rec)
 
 
