@@ -356,6 +356,8 @@ int check_desc(const rdfc_conv_desc *d, const char *who) {
 
 int rdfc_try_conv3x3_patch(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias,
                            void *out, hipStream_t st);   // conv_patch.hip
+int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
+                       hipStream_t st);                  // conv_thin.hip
 static bool patch_enabled() {
     static const bool on = getenv("RDFC_NO_PATCH") == nullptr;
     return on;
@@ -370,7 +372,8 @@ extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const
     IgemmParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
                   d->ldx, d->ldy, 0, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Ci};
     hipStream_t st = (hipStream_t)stream;
-    if (patch_enabled() && rdfc_try_conv3x3_patch(d, 0, x, w_fwd, bias, y, st)) {
+    if (rdfc_try_conv_thin(d, 0, x, w_fwd, bias, y, st)) {
+    } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 0, x, w_fwd, bias, y, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, w_fwd, bias, y, st);
     else launch_T<float>(p, x, w_fwd, bias, y, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_forward");
@@ -384,7 +387,8 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
     IgemmParams p{d->N, d->Ho, d->Wo, d->Co, d->Hi, d->Wi, d->Ci, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
                   d->ldy, d->ldx, 1, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Co};
     hipStream_t st = (hipStream_t)stream;
-    if (patch_enabled() && rdfc_try_conv3x3_patch(d, 1, dy, w_bwd, bias, dx, st)) {
+    if (rdfc_try_conv_thin(d, 1, dy, w_bwd, bias, dx, st)) {
+    } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, dy, w_bwd, bias, dx, st);
     else launch_T<float>(p, dy, w_bwd, bias, dx, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_dgrad");

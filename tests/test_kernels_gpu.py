@@ -65,6 +65,12 @@ CONV_CASES = [
     (2, 15, 19, 256, 512, 4, 1, 1),
     (3, 29, 38, 64, 64, 3, 1, 1),
     (2, 8, 8, 8, 24, 3, 1, 1),
+    # large enough maps for the thin-channel kernels (conv_thin.hip tile kernel, conv_wgrad_thin.hip)
+    (4, 130, 140, 1, 16, 3, 1, 1),
+    (4, 130, 140, 3, 48, 3, 1, 1),
+    (4, 130, 140, 96, 1, 3, 1, 1),
+    (4, 134, 146, 1, 64, 7, 1, 0),
+    (4, 134, 146, 64, 3, 7, 1, 0),
 ]
 
 
