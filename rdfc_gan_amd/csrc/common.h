@@ -84,6 +84,16 @@ __device__ inline float act_fwd(float u, int act, float slope) {
         default: return u;
     }
 }
+// Runs body(actf) with the activation chosen ONCE (a per-element switch inside a 64-value epilogue costs more than
+// its stores): piecewise-linear activations share u > 0 ? u : u * negative_slope.
+template <typename Body> __device__ inline void with_act(int act, float slope, Body &&body) {
+    if (act == RDFC_ACT_TANH) body([](float u) { return tanhf(u); });
+    else if (act == RDFC_ACT_SIGMOID) body([](float u) { return 1.f / (1.f + expf(-u)); });
+    else {
+        const float ns = act == RDFC_ACT_NONE ? 1.f : (act == RDFC_ACT_RELU ? 0.f : slope);
+        body([ns](float u) { return u > 0.f ? u : u * ns; });
+    }
+}
 // derivative given the pre-activation u
 __device__ inline float act_grad_pre(float u, int act, float slope) {
     switch (act) {

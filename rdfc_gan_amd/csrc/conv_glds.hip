@@ -1,0 +1,309 @@
+// conv_glds.hip -- 3x3 / stride-1 convolution (forward and input-gradient), bf16, staged by LDS-DMA.
+//
+// Same decomposition as conv_patch.hip (a 16x16 pixel tile per workgroup, the 18x18 halo patch of a 32-channel
+// slab in LDS, nine taps = nine LDS offsets) with a different pipeline.  PMC on the register-staged kernel
+// (256->256 @ 57x76, profiles/): 3 SALU + 2 VALU per MFMA (address generation, bounds tests, the ds_write pass),
+// SQ_WAIT_ANY 55 % of wave-cycles, matrix pipe busy 26 %.  Here
+//   * both operands go global -> LDS with global_load_lds_dwordx4: no staging registers, no ds_write pass;
+//     per-lane source pointers are computed once per workgroup, the per-step update is one uniform offset;
+//     the XOR bank swizzle of the LDS image is applied on the SOURCE side (LDS-DMA destinations are lane-linear);
+//     out-of-image and out-of-range pieces read a 64-byte zero page, so every wave issues the same number of
+//     DMAs and the vmcnt arithmetic below stays static;
+//   * the weights run through a ring of 4 tap slots filled three taps ahead, the patch is double buffered and
+//     its DMAs are spread over the first taps of the previous slab; loads stay in flight across the (raw)
+//     barrier: each phase waits with a counted s_waitcnt vmcnt(N) for exactly the DMAs it is about to read;
+//   * a wave owns 64 co x 64 px (16 MFMAs per phase against 8 fragment reads, half the LDS traffic per MFMA
+//     of the 64x32 wave tile).
+// One barrier per tap.  Workgroups are 4 waves: 128 co x (8x16) px or 64 co x (16x16) px; LDS 2 x 12 KB patch +
+// 4 x 8 KB weights = 56 KB, or 2 x 21 KB + 4 x 4 KB + 1 KB = 59 KB: two workgroups per CU, 2 waves per SIMD
+// with the whole register file (64 accumulators + 32 fragment registers per lane; at the 128-register cap of a
+// 4-waves-per-SIMD build the compiler spilled, and a scratch reload is a vmcnt(0) that drains the DMA queue).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+struct GParams {
+    int N, Hin, Win, H, W, Cin, Cout;
+    int ld_in, ld_out;
+    int transposed, oy0, ox0;
+    int act;
+    float slope;
+    int out_f32;
+    int tiles_x, tiles_y;
+};
+
+constexpr int BK = 32, TC = 16, PW = TC + 2;
+
+__device__ inline int lay_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 2)) << 3); }
+
+// one LDS-DMA instruction: 64 lanes x 16 B, lane l lands at lds_base + 16 l
+__device__ inline void glds16(const void *gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
+template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TCO, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
+                                                                  const float *__restrict__ bias, void *__restrict__ yout,
+                                                                  const bf16_t *__restrict__ zero) {
+    constexpr int NT = NW * 64;
+    constexpr int WCO = TCO / 64, WPX = NW / WCO;              // waves along co / along pixel rows (64 co x 4 rows x 16 px each)
+    constexpr int TR = 4 * WPX, PH = TR + 2, NPATCH = PH * PW; // tile rows, patch rows, patch pixels (180 / 324)
+    constexpr int NPIECE = NPATCH * 4;                         // 16-byte pieces per slab
+    constexpr int PATCH_BYTES = (NPIECE + 63) / 64 * 1024;     // whole DMA instructions (1 KB each): 12 KB / 21 KB
+    constexpr int NR = (NPIECE + NT - 1) / NT;                 // patch DMA rounds per slab (3 / 6)
+    constexpr int NWP = TCO * 4 / NT;                          // weight DMAs per thread and tap (2 / 1)
+    constexpr int WSLOT = TCO * BK * 2;                        // bytes per weight slot
+    constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + 4 * WSLOT;
+    static_assert(NR <= 6, "patch rounds must be issued at least three phases before the slab ends");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * TCO;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y, n = t / p.tiles_y;
+    const int y0 = ty * TR, x0 = tx * TC;
+    const int ncc = p.Cin / BK;
+
+    // ---- per-thread DMA sources (computed once) -------------------------------------------------------------
+    const bf16_t *psrc[NR];
+    int pstep[NR];
+    unsigned pdst[NR];                                           // wave-uniform LDS offset inside a patch buffer, or junk
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * NT + tid, q = e >> 2, slot = e & 3;
+        psrc[r] = zero;
+        pstep[r] = 0;
+        if (q < NPATCH) {
+            const int py = q / PW, px = q - py * PW;
+            const int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px;
+            if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
+                psrc[r] = x + ((size_t)(n * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
+                pstep[r] = BK;
+            }
+        }
+        const int wbase = (r * NT + wave * 64) * 16;             // this wave's 1 KB of the patch image
+        pdst[r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
+    }
+    const bf16_t *wsrc[NWP];
+    int wmul[NWP];
+#pragma unroll
+    for (int k = 0; k < NWP; ++k) {
+        const int e = k * NT + tid, row = e >> 2, slot = e & 3;
+        wsrc[k] = zero;
+        wmul[k] = 0;
+        if (co0 + row < p.Cout) {
+            wsrc[k] = w + (size_t)(co0 + row) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3);
+            wmul[k] = 1;
+        }
+    }
+    auto issue_w = [&](int it) {                                 // weights of global phase `it` -> ring slot it & 3
+        const int cc = it / 9, tap = it - cc * 9;
+        const int off = cc < ncc ? tap * p.Cin + cc * BK : 0;
+#pragma unroll
+        for (int k = 0; k < NWP; ++k)
+            glds16((cc < ncc ? wsrc[k] : zero) + off * wmul[k], lds0 + OFF_W + (it & 3) * WSLOT + (k * NT + wave * 64) * 16);
+    };
+    auto issue_p = [&](int r, int cc) {                          // round r of slab cc -> patch buffer cc & 1
+        const bool live = cc < ncc;
+        const unsigned dst = pdst[r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[r];
+        glds16(live ? psrc[r] + (size_t)cc * pstep[r] : zero, dst);
+    };
+
+    // ---- fragment coordinates ---------------------------------------------------------------------------------
+    const int wr = wave / WPX, wc = wave % WPX;
+    int bpp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bpp[j] = (4 * wc + j) * PW + (lane & 15);
+    const int arow = wr * 64 + (lane & 15), kg = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    // byte address of (row, 16-byte chunk kg) in a swizzled 64-byte-row image: (row*64 + kg*16) ^ ((row & 4) << 3)
+    const unsigned a_off = (unsigned)((arow << 6) | (kg << 4)) ^ (unsigned)((arow & 4) << 3);     // + i*1024: rows arow + 16 i share bit 2
+    auto compute = [&](int it, int cc, int tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        int shift = p.transposed ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
+#ifdef RDFC_GLDS_RECOMPUTE
+        asm volatile("" : "+s"(shift));                          // keep the nine taps' B addresses out of registers (recomputed per phase)
+#endif
+        const unsigned char *Wt = smem + OFF_W + (it & 3) * WSLOT + a_off;
+        const unsigned char *Pt = smem + (cc & 1) * PATCH_BYTES;
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = bpp[j] + shift;
+            b[j] = *reinterpret_cast<const bf16x8 *>(Pt + (((row << 6) | (kg << 4)) ^ ((row & 4) << 3)));
+        }
+#ifdef RDFC_GLDS_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#ifdef RDFC_GLDS_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+
+    // ---- prologue: slab 0 patch, weights of phases 0..2 -------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < NR; ++r) issue_p(r, 0);
+    issue_w(0);
+    issue_w(1);
+    issue_w(2);
+
+    // phase (cc, TAP): DMAs still allowed in flight at its wait = those issued in the two previous phases
+#define RDFC_GLDS_PHASE(TAP)                                                                                   \
+    {                                                                                                          \
+        constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
+        wait_vm<ALLOW>();                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        issue_w(it0 + TAP + 3);                                                                                \
+        if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
+        compute(it0 + TAP, cc, TAP);                                                                           \
+    }
+    for (int cc = 0; cc < ncc; ++cc) {
+        const int it0 = cc * 9;
+        RDFC_GLDS_PHASE(0)
+        RDFC_GLDS_PHASE(1)
+        RDFC_GLDS_PHASE(2)
+        RDFC_GLDS_PHASE(3)
+        RDFC_GLDS_PHASE(4)
+        RDFC_GLDS_PHASE(5)
+        RDFC_GLDS_PHASE(6)
+        RDFC_GLDS_PHASE(7)
+        RDFC_GLDS_PHASE(8)
+    }
+#undef RDFC_GLDS_PHASE
+    wait_vm<0>();
+
+    // ---- epilogue: bias + activation + store, 4 consecutive output channels per lane -------------------------------
+    // (the activation is selected once, outside the 64-value loop: a per-element switch costs more than the stores)
+    const int q4 = (lane >> 4) * 4;
+    const bool vec_ok = (p.ld_out & 3) == 0;
+    float bv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wr * 64 + 16 * i + q4 + r;
+            bv[i][r] = (bias != nullptr && co < p.Cout) ? bias[co] : 0.f;
+        }
+    auto store_all = [&](auto actf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oy = y0 + 4 * wc + j, ox = x0 + (lane & 15);
+            if (oy >= p.H || ox >= p.W) continue;
+            const size_t po = ((size_t)n * p.H + oy) * p.W + ox;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + wr * 64 + 16 * i + q4;
+                if (co >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = actf(acc[i][j][r] + bv[i][r]);
+                const size_t off = po * p.ld_out + co;
+                if (p.out_f32) {
+                    float *y = reinterpret_cast<float *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                    else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = v[r];
+                } else {
+                    bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) {
+                        bf16x4 o;
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        *reinterpret_cast<bf16x4 *>(y) = o;
+                    } else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                }
+            }
+        }
+    };
+    if (p.act == RDFC_ACT_TANH) store_all([](float u) { return tanhf(u); });
+    else if (p.act == RDFC_ACT_SIGMOID) store_all([](float u) { return 1.f / (1.f + expf(-u)); });
+    else {
+        const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
+        store_all([ns](float u) { return u > 0.f ? u : u * ns; });
+    }
+}
+
+// 64-byte page of zeros per device (source of every out-of-range DMA piece)
+const bf16_t *zero_page() {
+    static void *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (pages[dev] == nullptr) {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
+        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = ptr;
+    }
+    return (const bf16_t *)pages[dev];
+}
+
+template <int TCO, int NW>
+int launch(const GParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, hipStream_t st) {
+    constexpr int NT = NW * 64, TR = 4 * NW / (TCO / 64);
+    constexpr int NPIECE = (TR + 2) * PW * 4, PATCH = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;
+    constexpr int SMEM = 2 * PATCH + 4 * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
+    rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, NW);
+    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, NW>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero);
+    return 1;
+}
+
+}  // namespace
+
+// Called by conv_igemm.hip's entry points before the register-staged 3x3 kernels. Returns 1 if it took the launch.
+int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
+                          hipStream_t st) {
+    static const int mode = getenv("RDFC_GLDS") ? atoi(getenv("RDFC_GLDS")) : 1;
+    if (!mode || d->dtype != RDFC_BF16) return 0;
+    const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
+    if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->ph == d->pw && d->ph <= 1 && d->dh == 1 && d->dw == 1)) return 0;
+    if (Cin % BK != 0 || d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
+    const int ld_in = transposed ? d->ldy : d->ldx;
+    if (ld_in % 8 != 0 || Cout < 64) return 0;
+    const bf16_t *zero = zero_page();
+    if (zero == nullptr) return 0;
+    const int pad = d->ph;
+    GParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo,
+              Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
+              d->act, d->slope, d->out_f32, 0, 0};
+    p.tiles_x = cdiv(p.W, TC);
+    if (Cout > 64) {
+        p.tiles_y = cdiv(p.H, 8);
+        return launch<128, 4>(p, in, w, bias, out, zero, st);
+    }
+    if (mode == 2) {                                   // A/B switch: 2-wave workgroups (4 per CU) measured 1-4 % slower
+        p.tiles_y = cdiv(p.H, 8);
+        return launch<64, 2>(p, in, w, bias, out, zero, st);
+    }
+    p.tiles_y = cdiv(p.H, 16);
+    return launch<64, 4>(p, in, w, bias, out, zero, st);
+}

@@ -267,43 +267,45 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS == 512 && sizeof(T) == 2 ? 4 : 1
     // ---- epilogue: bias + activation + store (4 consecutive channels per lane) -----------------
     const int q4 = (lane >> 4) * 4, pr = lane & 15;
     const bool vec_ok = (p.ld_out & 3) == 0;
+    with_act(p.act, p.slope, [&](auto actf) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int po = pxo[wc * WTPX + 16 * j + pr];
-        if (po < 0) continue;
+        for (int j = 0; j < NT; ++j) {
+            const int po = pxo[wc * WTPX + 16 * j + pr];
+            if (po < 0) continue;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int co = co0 + wr * WTCO + 16 * i + q4;
-            if (co >= p.Cout) continue;
-            float v[4];
+            for (int i = 0; i < MT; ++i) {
+                const int co = co0 + wr * WTCO + 16 * i + q4;
+                if (co >= p.Cout) continue;
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float u = acc[i][j][r];
-                if (bias != nullptr && co + r < p.Cout) u += bias[co + r];
-                v[r] = act_fwd(u, p.act, p.slope);
-            }
-            const size_t off = (size_t)po * p.ld_out + co;
-            if (p.out_f32 || sizeof(T) == 4) {
-                float *y = reinterpret_cast<float *>(yout) + off;
-                if (vec_ok && co + 3 < p.Cout) {
-                    *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < p.Cout) y[r] = v[r];
+                for (int r = 0; r < 4; ++r) {
+                    float u = acc[i][j][r];
+                    if (bias != nullptr && co + r < p.Cout) u += bias[co + r];
+                    v[r] = actf(u);
                 }
-            } else {
-                bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
-                if (vec_ok && co + 3 < p.Cout) {
-                    bf16x4 o;
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                    *reinterpret_cast<bf16x4 *>(y) = o;
+                const size_t off = (size_t)po * p.ld_out + co;
+                if (p.out_f32 || sizeof(T) == 4) {
+                    float *y = reinterpret_cast<float *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) {
+                        *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = v[r];
+                    }
                 } else {
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                    bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) {
+                        bf16x4 o;
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        *reinterpret_cast<bf16x4 *>(y) = o;
+                    } else {
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                    }
                 }
             }
         }
-    }
+    });
 }
 
 template <typename T, int TCO, int TPX, int WCO, int NTHREADS = 256>
@@ -358,6 +360,8 @@ int rdfc_try_conv3x3_patch(const rdfc_conv_desc *d, int transposed, const void *
                            void *out, hipStream_t st);   // conv_patch.hip
 int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                        hipStream_t st);                  // conv_thin.hip
+int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
+                          hipStream_t st);               // conv_glds.hip
 static bool patch_enabled() {
     static const bool on = getenv("RDFC_NO_PATCH") == nullptr;
     return on;
@@ -373,6 +377,7 @@ extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const
                   d->ldx, d->ldy, 0, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Ci};
     hipStream_t st = (hipStream_t)stream;
     if (rdfc_try_conv_thin(d, 0, x, w_fwd, bias, y, st)) {
+    } else if (rdfc_try_conv3x3_glds(d, 0, x, w_fwd, bias, y, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 0, x, w_fwd, bias, y, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, w_fwd, bias, y, st);
     else launch_T<float>(p, x, w_fwd, bias, y, st);
@@ -388,6 +393,7 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
                   d->ldy, d->ldx, 1, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Co};
     hipStream_t st = (hipStream_t)stream;
     if (rdfc_try_conv_thin(d, 1, dy, w_bwd, bias, dx, st)) {
+    } else if (rdfc_try_conv3x3_glds(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, dy, w_bwd, bias, dx, st);
     else launch_T<float>(p, dy, w_bwd, bias, dx, st);

@@ -205,42 +205,44 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? (NTHREADS == 512 ? 4 : 2
     // ---- epilogue (as conv_igemm.hip): 4 consecutive output channels per lane -------------------------------
     const int q4 = (lane >> 4) * 4;
     const bool vec_ok = (p.ld_out & 3) == 0;
+    with_act(p.act, p.slope, [&](auto actf) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int q = wc * WTPX + 16 * j + (lane & 15);
-        const int oy = y0 + q / TC, ox = x0 + q % TC;
-        if (oy >= p.H || ox >= p.W) continue;
-        const size_t po = ((size_t)n * p.H + oy) * p.W + ox;
+        for (int j = 0; j < NT; ++j) {
+            const int q = wc * WTPX + 16 * j + (lane & 15);
+            const int oy = y0 + q / TC, ox = x0 + q % TC;
+            if (oy >= p.H || ox >= p.W) continue;
+            const size_t po = ((size_t)n * p.H + oy) * p.W + ox;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int co = co0 + wr * WTCO + 16 * i + q4;
-            if (co >= p.Cout) continue;
-            float v[4];
+            for (int i = 0; i < MT; ++i) {
+                const int co = co0 + wr * WTCO + 16 * i + q4;
+                if (co >= p.Cout) continue;
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float u = acc[i][j][r];
-                if (bias != nullptr && co + r < p.Cout) u += bias[co + r];
-                v[r] = act_fwd(u, p.act, p.slope);
-            }
-            const size_t off = po * p.ld_out + co;
-            if (p.out_f32 || sizeof(T) == 4) {
-                float *y = reinterpret_cast<float *>(yout) + off;
-                if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < p.Cout) y[r] = v[r];
-            } else {
-                bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
-                if (vec_ok && co + 3 < p.Cout) {
-                    bf16x4 o;
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                    *reinterpret_cast<bf16x4 *>(y) = o;
-                } else
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                for (int r = 0; r < 4; ++r) {
+                    float u = acc[i][j][r];
+                    if (bias != nullptr && co + r < p.Cout) u += bias[co + r];
+                    v[r] = actf(u);
+                }
+                const size_t off = po * p.ld_out + co;
+                if (p.out_f32 || sizeof(T) == 4) {
+                    float *y = reinterpret_cast<float *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                    else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = v[r];
+                } else {
+                    bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) {
+                        bf16x4 o;
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        *reinterpret_cast<bf16x4 *>(y) = o;
+                    } else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                }
             }
         }
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -365,42 +367,44 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? (NTHREADS == 512 ? 2 : 2
 
     const int q4 = (lane >> 4) * 4;
     const bool vec_ok = (p.ld_out & 3) == 0;
+    with_act(p.act, p.slope, [&](auto actf) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int q = wc * WTPX + 16 * j + (lane & 15);
-        const int oy = y0 + q / TC, ox = x0 + q % TC;
-        if (oy >= p.H || ox >= p.W) continue;
-        const size_t po = ((size_t)n * p.H + oy) * p.W + ox;
+        for (int j = 0; j < NT; ++j) {
+            const int q = wc * WTPX + 16 * j + (lane & 15);
+            const int oy = y0 + q / TC, ox = x0 + q % TC;
+            if (oy >= p.H || ox >= p.W) continue;
+            const size_t po = ((size_t)n * p.H + oy) * p.W + ox;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int co = co0 + wr * WTCO + 16 * i + q4;
-            if (co >= p.Cout) continue;
-            float v[4];
+            for (int i = 0; i < MT; ++i) {
+                const int co = co0 + wr * WTCO + 16 * i + q4;
+                if (co >= p.Cout) continue;
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float u = acc[i][j][r];
-                if (bias != nullptr && co + r < p.Cout) u += bias[co + r];
-                v[r] = act_fwd(u, p.act, p.slope);
-            }
-            const size_t off = po * p.ld_out + co;
-            if (p.out_f32 || sizeof(T) == 4) {
-                float *y = reinterpret_cast<float *>(yout) + off;
-                if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < p.Cout) y[r] = v[r];
-            } else {
-                bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
-                if (vec_ok && co + 3 < p.Cout) {
-                    bf16x4 o;
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                    *reinterpret_cast<bf16x4 *>(y) = o;
-                } else
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                for (int r = 0; r < 4; ++r) {
+                    float u = acc[i][j][r];
+                    if (bias != nullptr && co + r < p.Cout) u += bias[co + r];
+                    v[r] = actf(u);
+                }
+                const size_t off = po * p.ld_out + co;
+                if (p.out_f32 || sizeof(T) == 4) {
+                    float *y = reinterpret_cast<float *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                    else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = v[r];
+                } else {
+                    bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) {
+                        bf16x4 o;
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        *reinterpret_cast<bf16x4 *>(y) = o;
+                    } else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                }
             }
         }
-    }
+    });
 }
 
 template <typename T, int TCO, int TPX, int WCO, int NTHREADS>

@@ -1,0 +1,27 @@
+#!/bin/bash
+# usage: bash tools/pmc_conv.sh <tag> N H W Ci Co k s p fwd|dgrad|wgrad
+# Collects SQ counters for one conv shape (separate passes, kernel-trace only), prints per-kernel sums.
+tag=$1; shift
+root=$PWD
+cd /tmp && export TMPDIR=/tmp && cd $root
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_${tag}/p$i -- python3 tools/conv_bench.py "$@" 5 > /dev/null 2>&1
+done
+python3 - "$tag" <<'PY'
+import csv, glob, sys, collections
+tag = sys.argv[1]
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+for f in glob.glob(f'gpurun_out/pmc_{tag}/p*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'][:70]
+        if 'igemm' in k or 'patch' in k or 'slab' in k or 'wgrad' in k or 'thin' in k:
+            tot[k][r['Counter_Name']] += float(r['Counter_Value'])
+            cnt[(k, r['Counter_Name'])] += 1
+for k, d in tot.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f'   {c:28s} {v / cnt[(k, c)]:16.0f}  (per launch)')
+PY
