@@ -1,0 +1,236 @@
+// conv_wgrad_glds.hip -- weight gradient of 3x3 / stride-1 convolutions (bf16), staged by LDS-DMA.
+//
+//   dW[co][ky][kx][ci] += sum over pixels m of dY[m][co] * X[m + (ky, kx) - pad][ci]
+//
+// GEMM view: M = co, N = (kx, ci), K = pixels.  A workgroup owns one kernel row ky, a 128 (or 64) co x 64 ci tile
+// and a contiguous slice of the pixel range (split-K, f32 atomics at the end).  A k-step is a segment of 32
+// consecutive output pixels of one image row: dY [32 px][TCO] and the X row segment [34 px][64 ci] serve all three kx
+// (tap kx reads X rows kx .. kx+31), so dY is staged once per three taps instead of once per tap as in
+// conv_wgrad.hip.  Pipeline as in conv_glds.hip: global_load_lds_dwordx4 into a ring of four k-step slots filled
+// three steps ahead, one raw barrier per k-step, counted s_waitcnt vmcnt(N) -- every wave issues the same number
+// of DMAs per step (out-of-image pieces read a zero page).  Both images are pixel-major, the MFMA wants 8
+// consecutive k (pixels) per lane: fragments come from ds_read_b64_tr_b16.  LDS-DMA destinations are lane-linear,
+// so the bank swizzle is applied to the SOURCE chunk index: 32-byte channel pairs are XORed with row bits such that
+// the 8 rows a 32-lane group touches fall on 8 distinct bank octets (brute-forced: conflict-free for every kx).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+struct WGParams {
+    int N, Hi, Wi, Ci, Ho, Wo, Co, pad;
+    int ldx, ldy;
+    int segs_per_row, total_segs, segs_per_slice;
+    int tiles_ci;
+};
+
+constexpr int SEG = 32, XPX = SEG + 2, NT = 256;
+
+__device__ inline void glds16(const void *gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
+template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// swizzle of the 32-byte channel-pair index by image row (see header)
+template <int ROWB> __device__ inline int pair_swz(int row) {
+    if constexpr (ROWB == 256) return (row & 3) | (((row >> 3) & 1) << 2);
+    else return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+}
+
+// fragment: 16 channels [cbase, cbase+16) x 32 pixels (image rows row0 .. row0+31) -> 8 consecutive pixels per lane
+template <int ROWB> __device__ inline bf16x8 tr_frag(const unsigned char *img, int row0, int cbase, int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int r0 = row0 + 8 * g + q, r1 = r0 + 4, cp = cbase >> 4;
+    const unsigned char *a0 = img + r0 * ROWB + ((cp ^ pair_swz<ROWB>(r0)) << 5) + pp * 8;
+    const unsigned char *a1 = img + r1 * ROWB + ((cp ^ pair_swz<ROWB>(r1)) << 5) + pp * 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a1);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int TCO>
+__global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
+                                                           float *__restrict__ dw, const bf16_t *__restrict__ zero) {
+    constexpr int TCI = 64;
+    constexpr int YROW = TCO * 2, XROW = TCI * 2;               // bytes per pixel row of the two images
+    constexpr int YB = SEG * YROW;                              // 8 KB / 4 KB
+    constexpr int NY = YB / (NT * 16);                          // dY DMAs per thread and k-step (2 / 1)
+    constexpr int NX = 2;                                       // 34 px x 8 chunks = 272 pieces -> two rounds (second mostly zero page)
+    constexpr int XB = NX * NT * 16;                            // 8 KB region (4352 B used)
+    constexpr int SLOT = YB + XB;
+    constexpr int WCO = TCO / 64, WCI = 4 / WCO;                // waves along co / ci
+    constexpr int WTCO = 64, WTCI = TCI / WCI;                  // wave tile: 64 co x (32 | 16) ci
+    constexpr int MT = WTCO / 16, NTF = WTCI / 16;
+    constexpr int PER_STEP = NY + NX;                           // DMAs per wave and k-step
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.y;
+    const int ky = tile % 3;
+    tile /= 3;
+    const int ci0 = (tile % p.tiles_ci) * TCI, co0 = (tile / p.tiles_ci) * TCO;
+    const int seg0 = blockIdx.x * p.segs_per_slice;
+    int nseg = p.total_segs - seg0;
+    if (nseg > p.segs_per_slice) nseg = p.segs_per_slice;
+    if (nseg <= 0) return;
+
+    // ---- lane-constant parts of the DMA sources ---------------------------------------------------------------
+    // dY piece e = k*NT + tid: pixel e / (TCO/8), 16-byte slot e % (TCO/8); the slot holds source chunk slot ^ 2*swz(pixel)
+    int ypx[NY], yoff[NY];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+        const int e = k * NT + tid, px = e / (TCO / 8), slot = e % (TCO / 8);
+        ypx[k] = px;
+        yoff[k] = px * p.ldy + co0 + ((slot ^ (2 * pair_swz<YROW>(px))) << 3);
+    }
+    int xpx[NX], xoff[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int e = k * NT + tid, px = e / (TCI / 8), slot = e % (TCI / 8);
+        xpx[k] = px < XPX ? px : -(1 << 20);                    // pieces past the 34-pixel row: always the zero page
+        xoff[k] = px * p.ldx + ci0 + ((slot ^ (2 * pair_swz<XROW>(px))) << 3);
+    }
+
+    // uniform segment cursor of the NEXT k-step to issue
+    int cn = seg0 / (p.Ho * p.segs_per_row);
+    int rem = seg0 - cn * p.Ho * p.segs_per_row;
+    int coy = rem / p.segs_per_row, csx = rem - coy * p.segs_per_row;
+    auto issue = [&](int s) {                                   // DMAs of k-step s (s >= nseg: zero page only) into ring slot s & 3
+        const bool live = s < nseg;
+        const int ox0 = csx * SEG, iy = coy - p.pad + ky, ix0 = ox0 - p.pad;
+        const bool rowok = live && (unsigned)iy < (unsigned)p.Hi;
+        const bf16_t *yb = dy + ((size_t)(cn * p.Ho + coy) * p.Wo + ox0) * p.ldy;
+        const bf16_t *xb = x + ((long)(cn * p.Hi + iy) * p.Wi + ix0) * p.ldx;
+        const unsigned slot = lds0 + (s & 3) * SLOT;
+#pragma unroll
+        for (int k = 0; k < NY; ++k) {
+            const bool ok = live && ox0 + ypx[k] < p.Wo;
+            glds16(ok ? yb + yoff[k] : zero, slot + (k * NT + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const bool ok = rowok && (unsigned)(ix0 + xpx[k]) < (unsigned)p.Wi;
+            glds16(ok ? xb + xoff[k] : zero, slot + YB + (k * NT + wave * 64) * 16);
+        }
+        if (live) {
+            if (++csx == p.segs_per_row) {
+                csx = 0;
+                if (++coy == p.Ho) { coy = 0; ++cn; }
+            }
+        }
+    };
+
+    const int wr = wave / WCI, wc = wave % WCI;
+    f32x4 acc[3][MT][NTF];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTF; ++j) acc[t][i][j] = f32x4{0, 0, 0, 0};
+
+    issue(0);
+    issue(1);
+    issue(2);
+    for (int s = 0; s < nseg; ++s) {
+        wait_vm<2 * PER_STEP>();                                // k-steps s+1, s+2 may stay in flight
+        __builtin_amdgcn_s_barrier();
+        issue(s + 3);                                           // slot (s+3)&3 = (s-1)&3: every wave is past its reads (barrier)
+        const unsigned char *Ys = smem + (s & 3) * SLOT, *Xs = Ys + YB;
+        bf16x8 a[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = tr_frag<YROW>(Ys, 0, wr * WTCO + 16 * i, lane);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            bf16x8 b[NTF];
+#pragma unroll
+            for (int j = 0; j < NTF; ++j) b[j] = tr_frag<XROW>(Xs, t, wc * WTCI + 16 * j, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTF; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
+        }
+    }
+    wait_vm<0>();
+
+    // accumulate: row co = 4*(lane>>4)+r, col ci = lane&15
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTF; ++j) {
+                const int ci = ci0 + wc * WTCI + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wr * WTCO + 16 * i + 4 * (lane >> 4) + r;
+                    if (co < p.Co && ci < p.Ci) atomicAdd(&dw[((size_t)co * 9 + ky * 3 + t) * p.Ci + ci], acc[t][i][j][r]);
+                }
+            }
+}
+
+const bf16_t *zero_page() {
+    static void *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (pages[dev] == nullptr) {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
+        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = ptr;
+    }
+    return (const bf16_t *)pages[dev];
+}
+
+template <int TCO>
+int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
+    constexpr int SMEM = 4 * (SEG * TCO * 2 + 2 * NT * 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)wgrad_glds_kernel<TCO>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        attr_set = true;
+    }
+    p.tiles_ci = cdiv(p.Ci, 64);
+    const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * 3;
+    // Split-K factor: fill the chip's 512 workgroup slots (2 per CU) in ONE round -- 528 workgroups measured 1.3x slower
+    // than 480 -- within an atomic budget of 48 MB per launch (sweep on one device, 256->256 @ 57x76: 24 MB / 240
+    // workgroups 108 us, 48 MB / 480 workgroups 91 us; under-filling the chip costs more than the extra atomics).
+    static const double cap_mb = getenv("RDFC_WGRAD_ATOMIC_MB") ? atof(getenv("RDFC_WGRAD_ATOMIC_MB")) : 48.0;
+    int slices = 512 / tiles;
+    const int atomic_cap = (int)(cap_mb * 1.0e6 / (4.0 * p.Co * p.Ci * 9));
+    if (slices > atomic_cap) slices = atomic_cap;
+    if (slices > cdiv(p.total_segs, 8)) slices = cdiv(p.total_segs, 8);
+    if (slices < 1) slices = 1;
+    p.segs_per_slice = cdiv(p.total_segs, slices);
+    slices = cdiv(p.total_segs, p.segs_per_slice);
+    rdfc_note_kernel("wgrad_glds_kernel<%d>", TCO);
+    hipLaunchKernelGGL((wgrad_glds_kernel<TCO>), dim3(slices, tiles), dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw, zero);
+    return 1;
+}
+
+}  // namespace
+
+// Called by rdfc_conv2d_wgrad (conv_wgrad.hip) before the register-staged kernels; returns 1 if it took the launch.
+int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st) {
+    static const int mode = getenv("RDFC_WGRAD_GLDS") ? atoi(getenv("RDFC_WGRAD_GLDS")) : 1;
+    if (!mode || d->dtype != RDFC_BF16) return 0;
+    if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return 0;
+    if (d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
+    if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8) return 0;
+    const int spr = cdiv(d->Wo, SEG);
+    if ((double)d->Wo / (spr * SEG) < 0.55) return 0;              // too much padding per row segment
+    const bf16_t *zero = zero_page();
+    if (zero == nullptr) return 0;
+    WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0};
+    // 128-co tiles from 256 output channels up; below that the 64-co tile's larger grid wins (128->128: 82 vs 92 us)
+    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return launch<128>(p, x, dy, dw, zero, st);
+    return launch<64>(p, x, dy, dw, zero, st);
+}
