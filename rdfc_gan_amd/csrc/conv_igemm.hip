@@ -362,6 +362,8 @@ int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, 
                        hipStream_t st);                  // conv_thin.hip
 int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st);               // conv_glds.hip
+int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
+                        hipStream_t st);                 // conv_igemm_glds.hip
 static bool patch_enabled() {
     static const bool on = getenv("RDFC_NO_PATCH") == nullptr;
     return on;
@@ -378,6 +380,7 @@ extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const
     hipStream_t st = (hipStream_t)stream;
     if (rdfc_try_conv_thin(d, 0, x, w_fwd, bias, y, st)) {
     } else if (rdfc_try_conv3x3_glds(d, 0, x, w_fwd, bias, y, st)) {
+    } else if (rdfc_try_igemm_glds(d, 0, x, w_fwd, bias, y, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 0, x, w_fwd, bias, y, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, w_fwd, bias, y, st);
     else launch_T<float>(p, x, w_fwd, bias, y, st);
@@ -394,6 +397,7 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
     hipStream_t st = (hipStream_t)stream;
     if (rdfc_try_conv_thin(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_conv3x3_glds(d, 1, dy, w_bwd, bias, dx, st)) {
+    } else if (rdfc_try_igemm_glds(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, dy, w_bwd, bias, dx, st);
     else launch_T<float>(p, dy, w_bwd, bias, dx, st);

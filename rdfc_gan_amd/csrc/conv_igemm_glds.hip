@@ -1,0 +1,292 @@
+// conv_igemm_glds.hip -- generic implicit-GEMM convolution (forward and input-gradient), bf16, staged by LDS-DMA.
+//
+// conv_igemm.hip's decomposition -- flat tiles of 128 (or 256) output pixels x 128 (or 64) output channels, one
+// K-step per (tap, 32-channel slab), stride-parity classes for the transposed form -- with conv_glds.hip's
+// pipeline: both operand tiles go global -> LDS by global_load_lds_dwordx4 into a ring of four K-step slots filled
+// three steps ahead; one raw barrier and one counted s_waitcnt vmcnt(N) per K-step; a wave owns 64 co x 64 px.
+// The activation tile is a per-lane gather (every lane's source pixel moves with the tap), which LDS-DMA allows:
+// only its destination is lane-linear.  A lane's pixels are fixed for the whole kernel, so the bounds test and the
+// source pointer are recomputed once per tap and advanced by 32 channels per slab; out-of-image pixels read a zero
+// page, so every wave issues the same number of DMAs per step.  Unlike the 2-D patch kernels the flat pixel tiling
+// wastes nothing on small or odd-sized maps (PatchGAN's 27x37, the 15x19 / 29x38 encoder stages).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BK = 32, NT = 256, MAXTAPS = 64;
+
+struct IGParams {
+    int N, Hin, Win, Cin, Hout, Wout, Cout;
+    int KH, KW, sh, sw, ph, pw, dh, dw;
+    int ld_in, ld_out, transposed;
+    int act;
+    float slope;
+    int out_f32;
+};
+
+__device__ inline void glds16(const void *gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
+template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TCO>
+__global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
+                                                           const float *__restrict__ bias, void *__restrict__ yout,
+                                                           const bf16_t *__restrict__ zero) {
+    constexpr int TPX = TCO == 128 ? 128 : 256;                 // pixels per tile
+    constexpr int WCO = TCO / 64, WPX = 4 / WCO;                // waves along co / px: each 64 co x 64 px
+    constexpr int NA = TCO * 4 / NT, NB = TPX * 4 / NT;         // DMAs per thread and K-step: weights (2 / 1), pixels (2 / 4)
+    constexpr int AB = TCO * BK * 2, SLOT = AB + TPX * BK * 2;  // 16 KB / 20 KB
+    constexpr int RING = TCO == 128 ? 4 : 3, LOOK = RING - 1;   // 64 KB / 60 KB of ring: two workgroups per CU either way
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    __shared__ int tap_w[MAXTAPS], tap_dy[MAXTAPS], tap_dx[MAXTAPS], ntaps_s;
+    __shared__ int pxo[TPX];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * TCO;
+
+    // ---- pixel enumeration (as conv_igemm.hip) --------------------------------------------------------------------
+    int cy = 0, cx = 0, Ha = p.Hout, Wb = p.Wout;
+    if (p.transposed) {
+        cy = blockIdx.z / p.sw;
+        cx = blockIdx.z % p.sw;
+        Ha = cy < p.Hout ? (p.Hout - cy + p.sh - 1) / p.sh : 0;
+        Wb = cx < p.Wout ? (p.Wout - cx + p.sw - 1) / p.sw : 0;
+    }
+    const int Pc = p.N * Ha * Wb;
+    const int m0 = blockIdx.x * TPX;
+    if (m0 >= Pc) return;
+    if (tid == 0) {
+        int nt = 0;
+        const int ry = p.transposed ? (cy + p.ph) % p.sh : 0, rx = p.transposed ? (cx + p.pw) % p.sw : 0;
+        for (int kh = 0; kh < p.KH; ++kh)
+            for (int kw = 0; kw < p.KW; ++kw) {
+                if (!p.transposed) {
+                    tap_w[nt] = kh * p.KW + kw; tap_dy[nt] = kh * p.dh; tap_dx[nt] = kw * p.dw; ++nt;
+                } else {
+                    const int ey = ry - kh * p.dh, ex = rx - kw * p.dw;     // must be multiples of the stride
+                    if (ey % p.sh == 0 && ex % p.sw == 0) {
+                        tap_w[nt] = kh * p.KW + kw; tap_dy[nt] = ey / p.sh; tap_dx[nt] = ex / p.sw; ++nt;
+                    }
+                }
+            }
+        ntaps_s = nt;
+    }
+    // this thread's NB gathered pixels: tile rows (k * NT + tid) >> 2, 16-byte slot tid & 3
+    int pnb[NB], pyy[NB], pxx[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int row = (k * NT + tid) >> 2, m = m0 + row;
+        pnb[k] = -1;
+        pyy[k] = pxx[k] = 0;
+        int po = -1;
+        if (m < Pc) {
+            const int n = m / (Ha * Wb), r = m - n * (Ha * Wb);
+            const int a = r / Wb, b = r - a * Wb;
+            pnb[k] = n * p.Hin * p.Win;
+            if (!p.transposed) {
+                pyy[k] = a * p.sh - p.ph;
+                pxx[k] = b * p.sw - p.pw;
+                po = m;
+            } else {
+                const int oy = cy + a * p.sh, ox = cx + b * p.sw;
+                pyy[k] = (oy + p.ph) / p.sh;
+                pxx[k] = (ox + p.pw) / p.sw;
+                po = (n * p.Hout + oy) * p.Wout + ox;
+            }
+        }
+        if ((tid & 3) == 0) pxo[row] = po;
+    }
+    const int bslot = tid & 3;
+    const bf16_t *wsrc[NA];
+    int wmul[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int row = (k * NT + tid) >> 2;
+        wsrc[k] = zero;
+        wmul[k] = 0;
+        if (co0 + row < p.Cout) {
+            wsrc[k] = w + (size_t)(co0 + row) * (p.KH * p.KW) * p.Cin + ((bslot ^ ((row >> 1) & 2)) << 3);
+            wmul[k] = 1;
+        }
+    }
+    __syncthreads();
+    const int ntaps = ntaps_s, ncc = p.Cin / BK, G = ntaps * ncc;
+
+    // ---- issue side: K-step h = (tap ht, slab hc), slabs inner ----------------------------------------------------------
+    const bf16_t *bsrc[NB];
+    int bstep[NB];
+    int ht = 0, hc = 0, hw = 0;                                  // hw = weight tap index of ht
+    auto set_tap = [&](int t) {
+        const int dy = tap_dy[t], dx = tap_dx[t];
+        hw = tap_w[t];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int row = (k * NT + tid) >> 2;
+            const int iy = pyy[k] + dy, ix = pxx[k] + dx;
+            const bool ok = pnb[k] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            bsrc[k] = ok ? x + ((size_t)pnb[k] + (size_t)iy * p.Win + ix) * p.ld_in + ((bslot ^ ((row >> 1) & 2)) << 3) : zero;
+            bstep[k] = ok ? BK : 0;
+        }
+    };
+    auto issue = [&](int h) {
+        const bool live = h < G;
+        const unsigned slot = lds0 + (h % RING) * SLOT;
+        const int woff = live ? hw * p.Cin + hc * BK : 0;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) glds16((live ? wsrc[k] : zero) + woff * wmul[k], slot + (k * NT + wave * 64) * 16);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            glds16(live ? bsrc[k] : zero, slot + AB + (k * NT + wave * 64) * 16);
+            bsrc[k] += bstep[k];
+        }
+        if (live) {
+            if (++hc == ncc) {
+                hc = 0;
+                if (++ht < ntaps) set_tap(ht);
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int wr = wave / WPX, wc = wave % WPX;
+
+    if (G > 0) {
+        set_tap(0);
+#pragma unroll
+        for (int h = 0; h < LOOK; ++h) issue(h);
+        const int arow = wr * 64 + (lane & 15), brow = wc * 64 + (lane & 15), kg = lane >> 4;
+        const unsigned a_off = (unsigned)((arow << 6) | (kg << 4)) ^ (unsigned)((arow & 4) << 3);     // rows + 16 i share bit 2
+        const unsigned b_off = AB + ((unsigned)((brow << 6) | (kg << 4)) ^ (unsigned)((brow & 4) << 3));
+        for (int g = 0; g < G; ++g) {
+            wait_vm<(LOOK - 1) * (NA + NB)>();                  // the K-steps after g that are already issued may stay in flight
+            __builtin_amdgcn_s_barrier();
+            issue(g + LOOK);                                    // its slot was last read in step g - 1: every wave is past the barrier
+            const unsigned char *S = smem + (g % RING) * SLOT;
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(S + a_off + i * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(S + b_off + j * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        wait_vm<0>();
+    }
+
+    // ---- epilogue: bias + activation + store (4 consecutive channels per lane) -----------------------------------------
+    const int q4 = (lane >> 4) * 4;
+    const bool vec_ok = (p.ld_out & 3) == 0;
+    float bv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wr * 64 + 16 * i + q4 + r;
+            bv[i][r] = (bias != nullptr && co < p.Cout) ? bias[co] : 0.f;
+        }
+    with_act(p.act, p.slope, [&](auto actf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int po = pxo[wc * 64 + 16 * j + (lane & 15)];
+            if (po < 0) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + wr * 64 + 16 * i + q4;
+                if (co >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = actf(acc[i][j][r] + bv[i][r]);
+                const size_t off = (size_t)po * p.ld_out + co;
+                if (p.out_f32) {
+                    float *y = reinterpret_cast<float *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                    else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = v[r];
+                } else {
+                    bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
+                    if (vec_ok && co + 3 < p.Cout) {
+                        bf16x4 o;
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        *reinterpret_cast<bf16x4 *>(y) = o;
+                    } else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                }
+            }
+        }
+    });
+}
+
+const bf16_t *zero_page() {
+    static void *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (pages[dev] == nullptr) {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
+        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = ptr;
+    }
+    return (const bf16_t *)pages[dev];
+}
+
+template <int TCO>
+int launch(const IGParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, hipStream_t st) {
+    constexpr int TPX = TCO == 128 ? 128 : 256;
+    constexpr int SMEM = (TCO == 128 ? 4 : 3) * (TCO + TPX) * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)igemm_glds_kernel<TCO>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        attr_set = true;
+    }
+    int Pmax, nz = 1;
+    if (!p.transposed) {
+        Pmax = p.N * p.Hout * p.Wout;
+    } else {
+        nz = p.sh * p.sw;
+        Pmax = p.N * ((p.Hout + p.sh - 1) / p.sh) * ((p.Wout + p.sw - 1) / p.sw);
+    }
+    rdfc_note_kernel("igemm_glds_kernel<%d>", TCO);
+    hipLaunchKernelGGL((igemm_glds_kernel<TCO>), dim3(cdiv(Pmax, TPX), cdiv(p.Cout, TCO), nz), dim3(NT), SMEM, st, p, (const bf16_t *)x,
+                       (const bf16_t *)w, bias, y, zero);
+    return 1;
+}
+
+}  // namespace
+
+// Called by conv_igemm.hip's entry points after the 3x3 / stride-1 kernels. Returns 1 if it took the launch.
+int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
+                        hipStream_t st) {
+    static const int mode = getenv("RDFC_IGEMM_GLDS") ? atoi(getenv("RDFC_IGEMM_GLDS")) : 1;
+    if (!mode || d->dtype != RDFC_BF16) return 0;
+    const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
+    const int ld_in = transposed ? d->ldy : d->ldx;
+    if (Cin % BK != 0 || ld_in % 8 != 0 || Cout < 64 || d->KH * d->KW > MAXTAPS) return 0;
+    // K-steps per output tile.  Short reductions stay on the register-staged kernel, whose 4 waves per SIMD hide the
+    // pipeline fill better (A/B on one device: 1x1 192->384, 6 steps: 83 vs 69 us; 3x3/s2 64->128, 18 steps: 58 vs 53 us;
+    // from ~36 steps up this kernel wins: 4x4 256->512 61 vs 89 us, 3x3/s2 512->512 58 vs 96 us).
+    static const int min_steps = getenv("RDFC_IGEMM_GLDS_MINSTEPS") ? atoi(getenv("RDFC_IGEMM_GLDS_MINSTEPS")) : 32;
+    if (d->KH * d->KW * (Cin / BK) < min_steps) return 0;
+    const bf16_t *zero = zero_page();
+    if (zero == nullptr) return 0;
+    IGParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, Cin, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo, Cout,
+               d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw, ld_in, transposed ? d->ldx : d->ldy, transposed,
+               d->act, d->slope, d->out_f32};
+    if (Cout > 64 || mode == 3) return launch<128>(p, in, w, bias, out, zero, st);
+    return launch<64>(p, in, w, bias, out, zero, st);
+}

@@ -65,6 +65,11 @@ CONV_CASES = [
     (2, 15, 19, 256, 512, 4, 1, 1),
     (3, 29, 38, 64, 64, 3, 1, 1),
     (2, 8, 8, 8, 24, 3, 1, 1),
+    # tap-list gather kernel (conv_gather_glds.hip): 4x4 / s2 input-gradient classes, 1x1, odd sizes
+    (2, 16, 18, 64, 128, 4, 2, 1),
+    (2, 17, 21, 128, 64, 3, 2, 1),
+    (2, 10, 12, 192, 384, 1, 1, 0),
+    (1, 19, 23, 64, 64, 4, 1, 1),
     # large enough maps for the thin-channel kernels (conv_thin.hip tile kernel, conv_wgrad_thin.hip)
     (4, 130, 140, 1, 16, 3, 1, 1),
     (4, 130, 140, 3, 48, 3, 1, 1),
