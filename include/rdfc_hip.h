@@ -72,6 +72,10 @@ typedef struct rdfc_conv_desc {
  *   w_bwd [I][KH*KW][O]   rows of the input-gradient GEMM   (may be NULL)            */
 int rdfc_pack_weight(const float *w_oihw, void *w_fwd, void *w_bwd, int O, int I, int KH, int KW,
                      int dtype, float scale, void *stream);
+/* Same from master weights stored [O][KH][KW][I] (torch.channels_last: the layout rdfc_conv2d_wgrad produces, so that
+ * the weight gradient accumulates straight into the parameter's .grad and needs no unpack). */
+int rdfc_pack_weight_ohwi(const float *w_ohwi, void *w_fwd, void *w_bwd, int O, int I, int KH, int KW,
+                          int dtype, float scale, void *stream);
 /* dw_packed f32 [O][KH*KW][I] -> grad_oihw f32 [O][I][KH][KW] = scale * dw_packed (overwrite) */
 int rdfc_unpack_wgrad(const float *dw_packed, float *grad_oihw, int O, int I, int KH, int KW,
                       float scale, void *stream);

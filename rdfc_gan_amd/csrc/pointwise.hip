@@ -45,6 +45,20 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, T *__restrict__ 
     }
 }
 
+// same, from a source already stored [O][T][I] (torch.channels_last weights): wf is a cast, wb the [I][T][O] transpose
+template <typename T>
+__global__ void pack_weight_ohwi_kernel(const float *__restrict__ w, T *__restrict__ wf, T *__restrict__ wb, int O, int I, int Tn, float scale) {
+    const size_t total = (size_t)O * I * Tn;
+    GRID_STRIDE(i, total) {   // i indexes the OTI source: ((o*Tn + t)*I + c)
+        const int c = (int)(i % I);
+        const int t = (int)((i / I) % Tn);
+        const int o = (int)(i / ((size_t)Tn * I));
+        const float v = w[i] * scale;
+        if (wf) Elem<T>::st(wf + i, v);
+        if (wb) Elem<T>::st(wb + ((size_t)c * Tn + t) * O + o, v);
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float *__restrict__ dw, float *__restrict__ g, int O, int I, int Tn, float scale) {
     const size_t total = (size_t)O * I * Tn;
     GRID_STRIDE(i, total) {   // i indexes the OIHW destination
@@ -271,6 +285,16 @@ extern "C" int rdfc_pack_weight(const float *w, void *wf, void *wb, int O, int I
     DISPATCH(dtype, hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, w, (T *)wf,
                                        (T *)wb, O, I, KH * KW, scale));
     RDFC_LAUNCH_CHECK("rdfc_pack_weight");
+    return 0;
+}
+
+extern "C" int rdfc_pack_weight_ohwi(const float *w, void *wf, void *wb, int O, int I, int KH, int KW, int dtype, float scale, void *stream) {
+    CHECK_DTYPE("rdfc_pack_weight_ohwi", dtype);
+    RDFC_REQUIRE(O > 0 && I > 0 && KH > 0 && KW > 0, "rdfc_pack_weight_ohwi: bad shape");
+    const size_t total = (size_t)O * I * KH * KW;
+    DISPATCH(dtype, hipLaunchKernelGGL(pack_weight_ohwi_kernel<T>, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, w, (T *)wf,
+                                       (T *)wb, O, I, KH * KW, scale));
+    RDFC_LAUNCH_CHECK("rdfc_pack_weight_ohwi");
     return 0;
 }
 

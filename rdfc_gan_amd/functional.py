@@ -45,9 +45,29 @@ def _packed(weight, dtype, scale):
     key = (weight.data_ptr(), weight._version, _weights_epoch, dtype, scale)
     hit = _pack_cache.get(key)
     if hit is None:
-        hit = hip.pack_weight(weight.detach().contiguous(), dtype, scale)
+        w = weight.detach()
+        if hip.is_ohwi(w) and not w.is_contiguous():    # channels-last master weights (FlatAdam): no OIHW copy
+            hit = hip.pack_weight_ohwi(w, dtype, scale)
+        else:
+            hit = hip.pack_weight(w.contiguous(), dtype, scale)
         _pack_cache[key] = hit
     return hit
+
+
+def _wgrad(d, a, b, weight, O, I, k, scale):
+    """weight gradient of one conv; -> tensor for autograd, or None after accumulating into weight.grad in place.
+
+    rdfc_conv2d_wgrad produces [O][k*k][I], which IS the memory of a channels-last OIHW tensor.  When the parameter
+    and its persistent .grad are stored that way (FlatAdam does it) the kernel accumulates straight into .grad:
+    no zero-fill, no unpack, no autograd add."""
+    g = weight.grad
+    if scale == 1.0 and g is not None and g.dtype == torch.float32 and hip.is_ohwi(g) and not g.requires_grad:
+        hip.conv_wgrad(d, a, b, into=g)
+        return None
+    if scale == 1.0:
+        dw = hip.conv_wgrad(d, a, b)
+        return dw.view(O, k, k, I).permute(0, 3, 1, 2)
+    return hip.unpack_wgrad(hip.conv_wgrad(d, a, b), O, I, k, k, scale)
 
 
 class ConvSpec:
@@ -150,8 +170,7 @@ class _ConvBlock(torch.autograd.Function):
                 hip.conv_dgrad(d, dy, wb, None, g_x)
             if ctx.needs_input_grad[1]:
                 d.ldx = hip.ld(x)
-                dw = hip.conv_wgrad(d, x, dy)
-                g_w = hip.unpack_wgrad(dw, Cout, Cin, spec.k, spec.k, spec.wscale)
+                g_w = _wgrad(d, x, dy, weight, Cout, Cin, spec.k, spec.wscale)
         else:
             d = hip.conv_desc((N, Ho, Wo, Cout), Cin, spec.k, spec.stride, spec.pad, ldx=hip.ld(dy), ldy=Cin,
                               dtype=hip.dt(x), out_hw=(H, W))
@@ -160,8 +179,7 @@ class _ConvBlock(torch.autograd.Function):
                 hip.conv_forward(d, dy, wf, None, g_x)
             if ctx.needs_input_grad[1]:
                 d.ldy = hip.ld(x)
-                dw = hip.conv_wgrad(d, dy, x)           # [O = Cin][T][I = Cout]
-                g_w = hip.unpack_wgrad(dw, Cin, Cout, spec.k, spec.k, spec.wscale)
+                g_w = _wgrad(d, dy, x, weight, Cin, Cout, spec.k, spec.wscale)     # [O = Cin][T][I = Cout]
         return g_x, g_w, g_bias, g_gamma, g_beta, g_res, g_prelu, None, None, None, None
 
 

@@ -115,6 +115,23 @@ def pack_weight(w_oihw, dtype, scale=1.0, fwd=True, bwd=True):
     return wf, wb
 
 
+def is_ohwi(w):
+    """4-D tensor whose memory is [O][KH][KW][I] (torch.channels_last, dense)"""
+    return w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()
+
+
+def pack_weight_ohwi(w, dtype, scale=1.0, fwd=True, bwd=True):
+    """pack_weight for master weights stored channels-last (logical OIHW, memory [O][KH][KW][I])."""
+    O, I, KH, KW = w.shape
+    w = w.detach()
+    assert w.dtype == torch.float32 and is_ohwi(w)
+    wf = torch.empty(O, KH * KW, I, dtype=dtype, device=w.device) if fwd else None
+    wb = torch.empty(I, KH * KW, O, dtype=dtype, device=w.device) if bwd else None
+    _chk(lib().rdfc_pack_weight_ohwi(_p(w), _p(wf), _p(wb), O, I, KH, KW, dt(wf if fwd else wb), _f(scale), _st()),
+         'rdfc_pack_weight_ohwi')
+    return wf, wb
+
+
 def unpack_wgrad(dw_packed, O, I, KH, KW, scale=1.0):
     g = torch.empty(O, I, KH, KW, dtype=torch.float32, device=dw_packed.device)
     _chk(lib().rdfc_unpack_wgrad(_p(dw_packed), _p(g), O, I, KH, KW, _f(scale), _st()), 'rdfc_unpack_wgrad')
@@ -157,8 +174,9 @@ def conv_dgrad(d, dy, w_bwd, bias, dx):
     return dx
 
 
-def conv_wgrad(d, x, dy):
-    dw = torch.zeros(d.Co, d.KH * d.KW, d.Ci, dtype=torch.float32, device=x.device)
+def conv_wgrad(d, x, dy, into=None):
+    """into: f32 buffer [Co][KH*KW][Ci] to ACCUMULATE into (e.g. a channels-last .grad); default a fresh zeroed one"""
+    dw = into if into is not None else torch.zeros(d.Co, d.KH * d.KW, d.Ci, dtype=torch.float32, device=x.device)
     with _Timed('wgrad_kernel (conv weight grad)', d):
         _chk(lib().rdfc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _st()), 'rdfc_conv2d_wgrad')
     return dw

@@ -16,6 +16,16 @@ from . import functional as Fh
 from . import hip
 
 
+def _pview(buf, off, p):
+    """view of p's slice of a flat buffer with p's logical shape; conv weights (4-D) are stored channels-last
+    ([O][KH][KW][I] in memory), the layout the weight-gradient kernels write and the weight packer reads."""
+    k = p.numel()
+    if p.dim() == 4:
+        O, I, KH, KW = p.shape
+        return buf[off:off + k].view(O, KH, KW, I).permute(0, 3, 1, 2)
+    return buf[off:off + k].view(p.shape)
+
+
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-3, betas=(0.5, 0.999), eps=1e-8):
         params = [p for p in params]
@@ -32,9 +42,10 @@ class FlatAdam(torch.optim.Optimizer):
         with torch.no_grad():
             for p in params:
                 k = p.numel()
-                self.flat[off:off + k].copy_(p.detach().reshape(-1))
-                p.data = self.flat[off:off + k].view(p.shape)
-                p.grad = self.flat_grad[off:off + k].view(p.shape)
+                v = _pview(self.flat, off, p)
+                v.copy_(p.detach())
+                p.data = v
+                p.grad = _pview(self.flat_grad, off, p)
                 off += k
         self.steps = 0
         self._pending = None          # in-flight all-reduce (work handle, event)
@@ -53,9 +64,8 @@ class FlatAdam(torch.optim.Optimizer):
     def _rebind(self):
         off = 0
         for p in self._params:
-            k = p.numel()
-            p.grad = self.flat_grad[off:off + k].view(p.shape)
-            off += k
+            p.grad = _pview(self.flat_grad, off, p)
+            off += p.numel()
 
     # ---- data parallel: one bucket, side stream -------------------------------------------------
     def all_reduce_grads_async(self):
@@ -98,8 +108,9 @@ class FlatAdam(torch.optim.Optimizer):
         state, off = {}, 0
         for i, p in enumerate(self._params):
             k = p.numel()
-            state[i] = dict(step=torch.tensor(float(self.steps)), exp_avg=self.exp_avg[off:off + k].view(p.shape).clone(),
-                            exp_avg_sq=self.exp_avg_sq[off:off + k].view(p.shape).clone())
+            state[i] = dict(step=torch.tensor(float(self.steps)),
+                            exp_avg=_pview(self.exp_avg, off, p).clone(memory_format=torch.contiguous_format),
+                            exp_avg_sq=_pview(self.exp_avg_sq, off, p).clone(memory_format=torch.contiguous_format))
             off += k
         g = dict(self.param_groups[0])
         g['params'] = list(range(len(self._params)))
@@ -111,8 +122,8 @@ class FlatAdam(torch.optim.Optimizer):
             k = p.numel()
             st = sd['state'].get(i)
             if st is not None:
-                self.exp_avg[off:off + k].copy_(st['exp_avg'].reshape(-1))
-                self.exp_avg_sq[off:off + k].copy_(st['exp_avg_sq'].reshape(-1))
+                _pview(self.exp_avg, off, p).copy_(st['exp_avg'])
+                _pview(self.exp_avg_sq, off, p).copy_(st['exp_avg_sq'])
                 self.steps = int(st['step'])
             off += k
         for k_, v in sd['param_groups'][0].items():
