@@ -109,6 +109,7 @@ def main():
     ap.add_argument('--exact-schedule', action='store_true', help="run upstream's two dead forwards too")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch every kernel from the host each step instead of replaying the captured HIP graphs')
     ap.add_argument('--by-shape', default=None, help='write a per-conv-shape time / TFLOP/s table (debug aid) to this file')
     a = ap.parse_args()
 
@@ -138,23 +139,39 @@ def main():
         model.set_input(batches[i % len(batches)])
         return model.optimize_parameters(sync_losses=False)
 
+    # Warm-up: one eager step (lazy initialisation: kernel attributes, zero pages, weight packing), then, unless --eager,
+    # capture the step into HIP graphs (G step | D step | Adam; the data-parallel all-reduces stay eager between them).
+    graphed = not a.eager
     for i in range(a.warmup):
+        if graphed and i == 1:
+            model.enable_graph(True)
         one_step(i)
+    if graphed and a.warmup < 2:
+        model.enable_graph(True)
+        one_step(a.warmup)                 # capture + first replay (untimed)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if not a.no_kernel_events:
+    # Per-kernel HIP events (roofline): a replayed graph cannot carry torch events, so with graphs the LAST timed step runs
+    # eagerly with an event pair around every conv launch; in --eager mode every timed step carries them.
+    events = not a.no_kernel_events
+    if events and not graphed:
         hip.PROFILE = []
     t0 = time.perf_counter()
     for i in range(a.steps):
+        if graphed and events and i == a.steps - 1 and a.steps > 1:
+            model.enable_graph(False)
+            hip.PROFILE = []
         losses = one_step(i)
+    enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (== elapsed when launch-bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof, hip.PROFILE = hip.PROFILE, None
+    ev_steps = 1 if (graphed and a.steps > 1) else a.steps       # timed steps that carried per-kernel events
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,6 +192,7 @@ def main():
                                global_batch=world * a.batch, parallelism=f'dp{world}',
                                dead_forwards='executed' if a.exact_schedule else 'elided (result-identical, see DESIGN.md)',
                                step_gflop_per_pair=round(gflop_pair, 1)),
+                   host_enqueue_ms_per_step=round(1e3 * enqueue / a.steps, 3), launch='eager' if not graphed else 'hip graphs (3 per step)',
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
         if prof:
@@ -194,12 +212,13 @@ def main():
             out['roofline'] = dict(bound='mfma', kernel=top, achieved=round(fl / sec / 1e12, 2), peak=peak, unit='TFLOP/s',
                                    frac=round(fl / sec / 1e12 / peak, 4), traffic=None, launches=n,
                                    avg_launch_us=round(1e6 * sec / n, 2),
-                                   share_of_step=round(sec / (elapsed / 1.0), 4))
+                                   share_of_step=round(sec / (elapsed * ev_steps / a.steps), 4),
+                                   event_steps=ev_steps)
             out['kernels'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), avg_launch_us=round(1e6 * v[1] / v[2], 2),
-                                      launches=v[2], share_of_step=round(v[1] / elapsed, 4))
+                                      launches=v[2], share_of_step=round(v[1] / (elapsed * ev_steps / a.steps), 4))
                               for k, v in sorted(sym.items(), key=lambda kv: -kv[1][1])[:8]}
             out['kernel_families'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), seconds=round(v[1], 4), launches=v[2],
-                                              share_of_step=round(v[1] / elapsed, 4)) for k, v in sorted(fam.items())}
+                                              share_of_step=round(v[1] / (elapsed * ev_steps / a.steps), 4)) for k, v in sorted(fam.items())}
         if prof and a.by_shape:
             tab = {}
             for name, flops, e0, e1, shp, kernel in prof:

@@ -134,6 +134,10 @@ int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *mean, const
                          void *stream);
 /* sums[G][3][C] from the partials (fixed order => deterministic). */
 int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, int dtype, void *stream);
+/* Same; additionally dbeta_acc[C] += sum du and dgamma_acc[C] += sum du*xhat (either may be NULL; G must be 1):
+ * the affine gradients of a BatchNorm land in the parameters' persistent .grad without an autograd add each. */
+int rdfc_norm_bwd_finalize_acc(const float *partial, float *sums, int G, int P, int C, int dtype, float *dbeta_acc,
+                               float *dgamma_acc, void *stream);
 /* backward pass 2: dx = gamma*rstd*(du - S1/P - xhat*S2/P) (training) or gamma*rstd*du (frozen stats);
  * dres (may be NULL) = du. */
 int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
@@ -204,6 +208,10 @@ int rdfc_mdconv_backward(const rdfc_mdconv_desc *d, const float *input, const fl
  * ------------------------------------------------------------------------------ */
 int rdfc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
                    float lr, float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+/* Same update; lr and the (1-based) step count are read from device memory, hyper = {lr, step} (f32), so the launch
+ * can be captured into a HIP graph and replayed while the schedule advances. */
+int rdfc_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, const float *hyper,
+                       float beta1, float beta2, float eps, float grad_scale, void *stream);
 
 /* addPepperNoise (helper.py:384-402) given the host-drawn mask (0 keep, 1 -> +1, 2 -> -1), in place. */
 int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, int HW, void *stream);

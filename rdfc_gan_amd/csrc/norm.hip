@@ -301,11 +301,16 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
 }
 
 __global__ __launch_bounds__(FNT) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
-                                                          float *__restrict__ sums) {
+                                                          float *__restrict__ sums, float *__restrict__ acc0, float *__restrict__ acc1) {
     __shared__ double red[FL * 32];
     const int g = blockIdx.y / K, k = blockIdx.y % K, c = blockIdx.x * 32 + (threadIdx.x & 31);
     const double s = chunk_sum(partial, g, K, k, C, c, nchunk, red);
-    if (threadIdx.x < 32 && c < C) sums[((size_t)g * K + k) * C + c] = (float)s;
+    if (threadIdx.x < 32 && c < C) {
+        sums[((size_t)g * K + k) * C + c] = (float)s;
+        // optional in-place accumulation of sum 0 / sum 1 (d beta / d gamma of an affine norm with one group)
+        if (k == 0 && acc0 != nullptr) acc0[c] += (float)s;
+        if (k == 1 && acc1 != nullptr) acc1[c] += (float)s;
+    }
 }
 
 template <typename T>
@@ -574,11 +579,17 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
     return 0;
 }
 
-extern "C" int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, int dtype, void *stream) {
+extern "C" int rdfc_norm_bwd_finalize_acc(const float *partial, float *sums, int G, int P, int C, int dtype, float *dbeta_acc,
+                                          float *dgamma_acc, void *stream) {
+    RDFC_REQUIRE(G == 1 || (dbeta_acc == nullptr && dgamma_acc == nullptr),
+                 "rdfc_norm_bwd_finalize_acc: in-place affine gradients need one statistics group (batch norm)");
     hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), G * 3), dim3(FNT), 0, (hipStream_t)stream, G, C, 3,
-                       cdiv(P, chunk_pixels(P, C, dtype == RDFC_BF16 ? 8 : 4)), partial, sums);
+                       cdiv(P, chunk_pixels(P, C, dtype == RDFC_BF16 ? 8 : 4)), partial, sums, dbeta_acc, dgamma_acc);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_finalize");
     return 0;
+}
+extern "C" int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, int dtype, void *stream) {
+    return rdfc_norm_bwd_finalize_acc(partial, sums, G, P, C, dtype, nullptr, nullptr, stream);
 }
 
 extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
@@ -643,7 +654,7 @@ extern "C" int rdfc_channel_sum(const void *x, float *partial, float *out, int P
         dim3 grid(nchunk, 1, cdiv(C, NT));
         DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, chunk, (const T *)x, partial));
     }
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(FNT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(FNT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out, nullptr, nullptr);
     RDFC_LAUNCH_CHECK("rdfc_channel_sum");
     return 0;
 }

@@ -262,6 +262,24 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
+// same update with the learning rate and the step count read from device memory (hyper = {lr, step}), so that the
+// launch can sit in a captured HIP graph: nothing that changes between replays is a kernel argument
+__global__ void adam_dev_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                size_t n, const float *__restrict__ hyper, float b1, float b2, float eps, float gscale) {
+    const float lr = hyper[0];
+    const double t = (double)hyper[1];
+    const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    GRID_STRIDE(i, n) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
 __global__ void pepper_kernel(float *img, const uint8_t *mask, int C, int HW, size_t total) {
     GRID_STRIDE(i, total) {
         const size_t n = i / ((size_t)C * HW);
@@ -395,6 +413,15 @@ extern "C" int rdfc_adam_step(float *param, const float *grad, float *m, float *
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, m, v, n, lr, b1, b2, eps,
                        (float)bc1, (float)sqrt(bc2), gscale);
     RDFC_LAUNCH_CHECK("rdfc_adam_step");
+    return 0;
+}
+
+extern "C" int rdfc_adam_step_dev(float *param, const float *grad, float *m, float *v, size_t n, const float *hyper, float b1,
+                                  float b2, float eps, float gscale, void *stream) {
+    RDFC_REQUIRE(hyper != nullptr, "rdfc_adam_step_dev: null hyper-parameter buffer");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, m, v, n, hyper, b1, b2, eps,
+                       gscale);
+    RDFC_LAUNCH_CHECK("rdfc_adam_step_dev");
     return 0;
 }
 

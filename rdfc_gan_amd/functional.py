@@ -54,6 +54,10 @@ def _packed(weight, dtype, scale):
     return hit
 
 
+def _accumulable(g):
+    return g is not None and g.dtype == torch.float32 and g.is_contiguous() and not g.requires_grad
+
+
 def _wgrad(d, a, b, weight, O, I, k, scale):
     """weight gradient of one conv; -> tensor for autograd, or None after accumulating into weight.grad in place.
 
@@ -143,9 +147,13 @@ class _ConvBlock(torch.autograd.Function):
             x, weight, y, mean, rstd, gamma, beta, res, prelu = ctx.saved_tensors
             dz = dz if dz.dtype == x.dtype else dz.to(x.dtype)
             frozen = spec.norm == 'bn' and not ctx.training
+            # affine gradients straight into persistent .grad buffers (FlatAdam's) when there is one statistics group
+            direct = (gamma is not None and beta is not None and mean.shape[0] == 1 and ctx.needs_input_grad[3]
+                      and ctx.needs_input_grad[4] and _accumulable(gamma.grad) and _accumulable(beta.grad))
             dy, g_res, sums = hip.norm_backward(dz, y, mean, rstd, gamma, beta, res, spec.act, spec.slope, prelu,
-                                                frozen=frozen, want_dres=res is not None and ctx.needs_input_grad[5])
-            if gamma is not None:
+                                                frozen=frozen, want_dres=res is not None and ctx.needs_input_grad[5],
+                                                acc_beta=beta.grad if direct else None, acc_gamma=gamma.grad if direct else None)
+            if gamma is not None and not direct:
                 g_gamma, g_beta = sums[0, 1], sums[0, 0]
             if prelu is not None:
                 g_prelu = sums[:, 2].sum().view(1)

@@ -257,8 +257,9 @@ def norm_apply(x, mean, rstd, gamma, beta, res, z, act='none', slope=0.0, prelu=
 
 
 def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, prelu=None, frozen=False,
-                  want_dres=False):
-    """-> dx, dres (or None), sums[G,3,C] (sum du, sum du*xhat, sum dz*min(u,0))"""
+                  want_dres=False, acc_beta=None, acc_gamma=None):
+    """-> dx, dres (or None), sums[G,3,C] (sum du, sum du*xhat, sum dz*min(u,0)).
+    acc_beta / acc_gamma: f32[C] buffers that additionally receive += sums[0,0] / sums[0,1] (G == 1 only)."""
     N, H, W, Cc = x.shape
     G = mean.shape[0]
     P = N * H * W // G
@@ -268,7 +269,8 @@ def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, pr
     ldr = ld(res) if res is not None else 0
     _chk(lib().rdfc_norm_bwd_reduce(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(partial), G, P, Cc,
                                     ld(dz), ld(x), ldr, dt(x), ACT[act], _f(slope), _p(prelu), _st()), 'rdfc_norm_bwd_reduce')
-    _chk(lib().rdfc_norm_bwd_finalize(_p(partial), _p(sums), G, P, Cc, dt(x), _st()), 'rdfc_norm_bwd_finalize')
+    _chk(lib().rdfc_norm_bwd_finalize_acc(_p(partial), _p(sums), G, P, Cc, dt(x), _p(acc_beta), _p(acc_gamma), _st()),
+         'rdfc_norm_bwd_finalize_acc')
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
     dres = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device) if want_dres else None
     _chk(lib().rdfc_norm_bwd_apply(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(sums), _p(dx), _p(dres),
@@ -355,6 +357,12 @@ def weighted_loss(pred, target, weight, kind, want_grad=True, grad_scale=1.0):
 def adam_step(param, grad, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
     _chk(lib().rdfc_adam_step(_p(param), _p(grad), _p(m), _p(v), C.c_size_t(param.numel()), _f(lr), _f(b1), _f(b2), _f(eps),
                               int(step), _f(grad_scale), _st()), 'rdfc_adam_step')
+
+
+def adam_step_dev(param, grad, m, v, hyper, b1, b2, eps, grad_scale=1.0):
+    """hyper: device f32 tensor {lr, step}"""
+    _chk(lib().rdfc_adam_step_dev(_p(param), _p(grad), _p(m), _p(v), C.c_size_t(param.numel()), _p(hyper), _f(b1), _f(b2),
+                                  _f(eps), _f(grad_scale), _st()), 'rdfc_adam_step_dev')
 
 
 def apply_pepper(img, mask_u8):

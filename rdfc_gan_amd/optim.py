@@ -50,7 +50,24 @@ class FlatAdam(torch.optim.Optimizer):
         self.steps = 0
         self._pending = None          # in-flight all-reduce (work handle, event)
         self._comm_stream = None
+        self._hyper = None            # device {lr, step}: set by make_capturable(); the step then launches rdfc_adam_step_dev
+        self._hyper_lr = None
+        self.host_counts = True       # False while a captured graph replays step(): the caller advances self.steps
         Fh.invalidate_packed_weights()
+
+    def make_capturable(self):
+        """learning rate and step count move to device memory so that step() can be captured in a HIP graph"""
+        if self._hyper is None:
+            self._hyper_lr = float(self.param_groups[0]['lr'])
+            self._hyper = torch.tensor([self._hyper_lr, float(self.steps)], dtype=torch.float32, device=self.flat.device)
+
+    def sync_hyper(self):
+        """host -> device refresh of what a scheduler or load_state_dict may have changed (eager; call before a replay)"""
+        if self._hyper is not None:
+            lr = float(self.param_groups[0]['lr'])
+            if lr != self._hyper_lr:
+                self._hyper[0] = lr
+                self._hyper_lr = lr
 
     def zero_grad(self, set_to_none=False):
         self.wait_grads()
@@ -94,13 +111,20 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         self.wait_grads()
         g = self.param_groups[0]
-        self.steps += 1
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         if not self.flat.is_cuda:
             raise RuntimeError('FlatAdam.step runs the HIP kernel rdfc_adam_step: parameters must live on the GPU '
                                '(there is no CPU fallback)')
-        hip.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
-                      g['eps'], self.steps, 1.0 / world)
+        if self._hyper is not None:
+            self._hyper[1:2] += 1.0           # device-side step count (captured with the update)
+            hip.adam_step_dev(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._hyper, g['betas'][0],
+                              g['betas'][1], g['eps'], 1.0 / world)
+            if self.host_counts:
+                self.steps += 1
+        else:
+            self.steps += 1
+            hip.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
+                          g['eps'], self.steps, 1.0 / world)
         Fh.invalidate_packed_weights()
 
     # ---- checkpoint format of torch.optim.Adam (lib/utils/checkpoint.py:21-58 stores optimizer.state_dict()) ----
@@ -126,6 +150,8 @@ class FlatAdam(torch.optim.Optimizer):
                 _pview(self.exp_avg_sq, off, p).copy_(st['exp_avg_sq'])
                 self.steps = int(st['step'])
             off += k
+        if self._hyper is not None:
+            self._hyper[1] = float(self.steps)
         for k_, v in sd['param_groups'][0].items():
             if k_ != 'params':
                 self.param_groups[0][k_] = v

@@ -131,12 +131,36 @@ class RDFCGAN:
 
     # ---- data ------------------------------------------------------------------------------------
     def set_input(self, data):
+        if getattr(self, '_graph_mode', False):
+            return self._set_input_static(data)
         dev = self.device
         self.real_A, self.real_B = data['rgb'].to(dev), data['gt_depth'].to(dev)
         self.aux_A = data['raw_depth'].to(dev)
         self.gt_normal = data['gt_normal'].to(dev) if 'gt_normal' in data else None
         self.mask = data['depth_masks'].to(dev) if 'depth_masks' in data else torch.ones_like(self.real_B)
         self.image_loss_weight = self.mask / (self.mask.sum() + 1e-6)
+        self._batch = data
+
+    def _set_input_static(self, data):
+        """graph mode: the captured step reads its batch from fixed device buffers; a new batch is copied into them"""
+        dev = self.device
+        st = self.__dict__.setdefault('_static_in', {})
+        src = dict(real_A=data['rgb'], real_B=data['gt_depth'], aux_A=data['raw_depth'])
+        if 'gt_normal' in data:
+            src['gt_normal'] = data['gt_normal']
+        src['mask'] = data['depth_masks'] if 'depth_masks' in data else torch.ones_like(data['gt_depth'])
+        for k, v in src.items():
+            if k not in st or st[k].shape != v.shape:
+                st[k] = v.to(dev).clone()
+                self._graphs = None                      # shapes changed: capture again
+            else:
+                st[k].copy_(v, non_blocking=True)
+        self.real_A, self.real_B, self.aux_A, self.mask = st['real_A'], st['real_B'], st['aux_A'], st['mask']
+        self.gt_normal = st.get('gt_normal')
+        if 'image_loss_weight' not in st or st['image_loss_weight'].shape != self.mask.shape:
+            st['image_loss_weight'] = torch.empty(self.mask.shape, dtype=torch.float32, device=dev)
+        st['image_loss_weight'].copy_(self.mask / (self.mask.sum() + 1e-6))
+        self.image_loss_weight = st['image_loss_weight']
         self._batch = data
 
     def _normal(self, tag, img):
@@ -171,9 +195,13 @@ class RDFCGAN:
 
     def forward(self):
         self.fake_B = self.G_A2B(self.real_A, self.aux_A, self._normal('real_A', self.real_A))['pred_depth']
-        mask = draw_pepper_mask(self.fake_B.shape)
-        if mask is not None:
-            self.fake_B = _PepperNoise.apply(self.fake_B, torch.from_numpy(mask).to(self.device))
+        if getattr(self, '_graph_mode', False):
+            # host RNG draw happened before the replay (_draw_pepper_static); an all-zero mask is the "no noise" draw
+            self.fake_B = _PepperNoise.apply(self.fake_B, self._pepper_static)
+        else:
+            mask = draw_pepper_mask(self.fake_B.shape)
+            if mask is not None:
+                self.fake_B = _PepperNoise.apply(self.fake_B, torch.from_numpy(mask).to(self.device))
         if self.exact_schedule:
             with torch.no_grad():
                 self.G_B2A(self.fake_B)                                          # dead forward (:197)
@@ -220,7 +248,105 @@ class RDFCGAN:
         r, f, d = self.backward_D_basic(self.disc_B, self.real_A, self.fake_A)
         return dict(loss_D_B=d, loss_D_B_real=r, loss_D_B_fake=f)
 
+    # ---- HIP-graph mode: the step is captured once as three graphs (G step | D step | Adam) and replayed; the
+    #      data-parallel all-reduces stay eager between them, the host only draws the pepper mask and copies the batch in
+    def enable_graph(self, enabled=True):
+        self._graph_mode = bool(enabled)
+        self._graphs = None
+        if enabled:
+            for o in self.optimizers.values():
+                o.make_capturable()
+
+    def _draw_pepper_static(self):
+        shape = self.real_B.shape
+        buf = self.__dict__.get('_pepper_static')
+        if buf is None or buf.shape != (shape[0], 1, shape[2], shape[3]):
+            buf = self._pepper_static = torch.zeros(shape[0], 1, shape[2], shape[3], dtype=torch.uint8, device=self.device)
+            self._graphs = None
+        mask = draw_pepper_mask(shape)
+        if mask is None:
+            buf.zero_()
+        else:
+            buf.copy_(torch.from_numpy(mask), non_blocking=True)
+
+    def _seg_G(self):
+        self.forward()
+        self.set_requires_grad([self.disc_A, self.disc_B], False)
+        self.optimizer_G.zero_grad()
+        return self.backward_G()
+
+    def _seg_D(self):
+        self.set_requires_grad([self.disc_A, self.disc_B], True)
+        self.optimizer_D.zero_grad()
+        stats = self.backward_D_A2B()
+        stats.update(self.backward_D_B2A())
+        return stats
+
+    def _seg_adam(self):
+        self.optimizer_G.step()
+        self.optimizer_D.step()
+
+    def _bn_modules(self):
+        return [m for net in self.models.values() for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+
+    def _capture(self):
+        # Autograd nodes of an earlier eager step (AccumulateGrad is bound to the stream it was created on) must be gone
+        # before the capture stream builds its own: drop every tensor that still holds that step's graph.
+        import gc
+        self.fake_A = self.fake_B = self.fake_normal_fakeA = None
+        Fh.invalidate_packed_weights()
+        gc.collect()
+        bns = self._bn_modules()
+        before = [m.__dict__.get('_rdfc_pending_batches', 0) for m in bns]
+        for o in self.optimizers.values():
+            o.wait_grads()
+            o.host_counts = False
+        torch.cuda.synchronize()
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g1):
+                stats = self._seg_G()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                stats.update(self._seg_D())
+            with torch.cuda.graph(g3, pool=g1.pool()):
+                self._seg_adam()
+        finally:
+            for o in self.optimizers.values():
+                o.host_counts = True
+        # capture ran the host code once without executing anything: undo its host-side bookkeeping and remember the
+        # per-step BatchNorm batch counts so that every replay can re-apply them
+        self._bn_counts = []
+        for m, b in zip(bns, before):
+            now = m.__dict__.get('_rdfc_pending_batches', 0)
+            if now != b:
+                self._bn_counts.append((m, now - b))
+                m.__dict__['_rdfc_pending_batches'] = b
+        Fh.invalidate_packed_weights()
+        self._graphs = (g1, g2, g3, stats)
+
+    def _optimize_graphed(self, sync_losses):
+        self._draw_pepper_static()
+        for o in self.optimizers.values():
+            o.sync_hyper()
+        if self._graphs is None:
+            self._capture()
+        g1, g2, g3, stats = self._graphs
+        g1.replay()
+        self.optimizer_G.all_reduce_grads_async()
+        g2.replay()
+        self.optimizer_D.all_reduce_grads_async()
+        self.optimizer_G.wait_grads()
+        self.optimizer_D.wait_grads()
+        g3.replay()
+        for o in self.optimizers.values():
+            o.steps += 1
+        for m, k in self._bn_counts:
+            m.__dict__['_rdfc_pending_batches'] += k
+        return self.reduce_loss(stats) if sync_losses else stats
+
     def optimize_parameters(self, sync_losses=True):
+        if getattr(self, '_graph_mode', False):
+            return self._optimize_graphed(sync_losses)
         loss_stats = {}
         self.forward()
         self.set_requires_grad([self.disc_A, self.disc_B], False)

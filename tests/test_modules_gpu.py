@@ -242,3 +242,56 @@ def test_train_step_bf16_runs_and_tracks_f32():
         assert np.isfinite(v), k
         ref = out[torch.float32][k]
         assert abs(v - ref) <= 0.08 * abs(ref) + 0.02, f'{k}: bf16 {v} vs f32 {ref}'
+
+
+def _step_cfg(hp):
+    return dict(local_rank=0, lr=hp['lr'], beta1=0.5, beta2=0.999, gan_loss_type='lsgan',
+                model=dict(G_A2B=dict(type='RDFGenerator', pretrained_on_imagenet=False),
+                           G_B2A=dict(type='ResnetGenerator', input_channels=1, output_channels=3, ngf=64, norm_layer='IN2d'),
+                           D_A=dict(type='PatchGANDiscriminator', in_channels=1, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'),
+                           D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')))
+
+
+def test_graph_mode_matches_eager():
+    """RDFCGAN.enable_graph(): three captured HIP graphs (G step | D step | Adam) replayed per step must walk the
+    same trajectory as the eager step (same host RNG draws, device-side Adam step count, BatchNorm batch counters)."""
+    import random
+    from rdfc_gan_amd import functional as Fh
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    hp = STEP_HP
+    cfg = _step_cfg(hp)
+    setup_dtype(torch.float32)
+    runs = {}
+    for mode in ('eager', 'graph'):
+        m = RDFCGAN(torch.device(DEV), False, cfg, is_train=True)
+        for key, net in m.models.items():
+            net.load_state_dict(det_state_dict(net.state_dict(), 0))
+        Fh.invalidate_packed_weights()
+        m.train()
+        if mode == 'graph':
+            m.enable_graph(True)
+        losses = []
+        for it in range(3):
+            data, nA, _ = step_batch(it, hp['B'], hp['H'], hp['W'])
+            data['gt_normal'] = nA
+            random.seed(40 + it)
+            np.random.seed(40 + it)
+            m.set_input(data)
+            losses.append(m.optimize_parameters())
+        sd = {k: {n: v.detach().float().cpu().clone() for n, v in net.state_dict().items()} for k, net in m.models.items()}
+        runs[mode] = (losses, sd, [o.steps for o in m.optimizers.values()])
+    assert runs['eager'][2] == runs['graph'][2] == [3, 3]
+    for it in range(3):
+        for k, ref in runs['eager'][0][it].items():
+            v = runs['graph'][0][it][k]
+            assert abs(v - ref) <= 2e-3 * abs(ref) + 2e-4, f'step {it} {k}: graph {v} vs eager {ref}'
+    for key in runs['eager'][1]:
+        for n, ref in runs['eager'][1][key].items():
+            got = runs['graph'][1][key][n]
+            if n.endswith('num_batches_tracked'):
+                assert int(got) == int(ref), (key, n, int(got), int(ref))
+            else:
+                # split-K atomics make the gradient sums order-dependent at rounding level, and Adam's first steps move
+                # a weight by ~lr whatever the gradient's size: two eager runs differ by up to lr per step as well
+                d = (got - ref).abs().max().item()
+                assert d <= 3.5 * hp['lr'] + 2e-2 * ref.abs().max().item() + 1e-4, (key, n, d)
