@@ -67,7 +67,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.y * TCO;
+    // Workgroups are dealt to the 8 XCDs round-robin; renumber so that each XCD (own L2) gets a contiguous run of
+    // tiles: neighbouring tiles share halo rows and then hit in the same L2.
     int t = blockIdx.x;
+#ifndef RDFC_GLDS_NO_XCD
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = t & 7, k = t >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+#endif
     const int tx = t % p.tiles_x;
     t /= p.tiles_x;
     const int ty = t % p.tiles_y, n = t / p.tiles_y;

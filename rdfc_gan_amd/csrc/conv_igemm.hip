@@ -364,6 +364,8 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
                           hipStream_t st);               // conv_glds.hip
 int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                         hipStream_t st);                 // conv_igemm_glds.hip
+int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
+                          hipStream_t st);               // conv_thin_in.hip
 static bool patch_enabled() {
     static const bool on = getenv("RDFC_NO_PATCH") == nullptr;
     return on;
@@ -379,6 +381,7 @@ extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const
                   d->ldx, d->ldy, 0, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Ci};
     hipStream_t st = (hipStream_t)stream;
     if (rdfc_try_conv_thin(d, 0, x, w_fwd, bias, y, st)) {
+    } else if (rdfc_try_conv_thin_in(d, 0, x, w_fwd, bias, y, st)) {
     } else if (rdfc_try_conv3x3_glds(d, 0, x, w_fwd, bias, y, st)) {
     } else if (rdfc_try_igemm_glds(d, 0, x, w_fwd, bias, y, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 0, x, w_fwd, bias, y, st)) {
@@ -396,6 +399,7 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
                   d->ldy, d->ldx, 1, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Co};
     hipStream_t st = (hipStream_t)stream;
     if (rdfc_try_conv_thin(d, 1, dy, w_bwd, bias, dx, st)) {
+    } else if (rdfc_try_conv_thin_in(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_conv3x3_glds(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_igemm_glds(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 1, dy, w_bwd, bias, dx, st)) {

@@ -70,6 +70,10 @@ CONV_CASES = [
     (2, 17, 21, 128, 64, 3, 2, 1),
     (2, 10, 12, 192, 384, 1, 1, 0),
     (1, 19, 23, 64, 64, 4, 1, 1),
+    # thin-input MFMA kernel (conv_thin_in.hip): stride-2 4x4 stems, 128-channel heads' input gradient
+    (4, 66, 70, 3, 64, 4, 2, 1),
+    (4, 66, 70, 1, 64, 4, 2, 1),
+    (4, 60, 70, 128, 1, 3, 1, 1),
     # large enough maps for the thin-channel kernels (conv_thin.hip tile kernel, conv_wgrad_thin.hip)
     (4, 130, 140, 1, 16, 3, 1, 1),
     (4, 130, 140, 3, 48, 3, 1, 1),
