@@ -99,7 +99,7 @@ def cpu_baseline(H, W, exact_schedule, budget_s=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='pairs per GPU')
     ap.add_argument('--height', type=int, default=228)
