@@ -57,7 +57,9 @@ template <typename T> struct Vec16;
 template <> struct Vec16<float> {
     f32x4 v;
     __device__ void load(const float *p) { v = *reinterpret_cast<const f32x4 *>(p); }
+    __device__ void load_nt(const float *p) { v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p)); }
     __device__ void store(float *p) const { *reinterpret_cast<f32x4 *>(p) = v; }
+    __device__ void store_nt(float *p) const { __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); }
     __device__ void zero() { v = f32x4{0, 0, 0, 0}; }
     __device__ float get(int i) const { return v[i]; }
     __device__ void set(int i, float f) { v[i] = f; }
@@ -65,7 +67,9 @@ template <> struct Vec16<float> {
 template <> struct Vec16<bf16_t> {
     bf16x8 v;
     __device__ void load(const bf16_t *p) { v = *reinterpret_cast<const bf16x8 *>(p); }
+    __device__ void load_nt(const bf16_t *p) { v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(p)); }
     __device__ void store(bf16_t *p) const { *reinterpret_cast<bf16x8 *>(p) = v; }
+    __device__ void store_nt(bf16_t *p) const { __builtin_nontemporal_store(v, reinterpret_cast<bf16x8 *>(p)); }
     __device__ void zero() {
         for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.0f;
     }

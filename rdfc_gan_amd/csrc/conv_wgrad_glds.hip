@@ -55,27 +55,28 @@ template <int ROWB> __device__ inline bf16x8 tr_frag(const unsigned char *img, i
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int TCO>
+template <int TCO, int NKY>   // NKY = 1: one kernel row (3 taps) per workgroup; NKY = 3: all nine taps (64 x 64 tiles only)
 __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                            float *__restrict__ dw, const bf16_t *__restrict__ zero) {
     constexpr int TCI = 64;
     constexpr int YROW = TCO * 2, XROW = TCI * 2;               // bytes per pixel row of the two images
     constexpr int YB = SEG * YROW;                              // 8 KB / 4 KB
     constexpr int NY = YB / (NT * 16);                          // dY DMAs per thread and k-step (2 / 1)
-    constexpr int NX = 2;                                       // 34 px x 8 chunks = 272 pieces -> two rounds (second mostly zero page)
-    constexpr int XB = NX * NT * 16;                            // 8 KB region (4352 B used)
+    constexpr int NX = (NKY * XPX * (TCI / 8) + NT - 1) / NT;   // X DMAs per thread and k-step: 272 (816) pieces -> 2 (4) rounds
+    constexpr int XB = NX * NT * 16;                            // 8 KB (16 KB) region, 4352 B (13056 B) used
     constexpr int SLOT = YB + XB;
-    constexpr int WCO = TCO / 64, WCI = 4 / WCO;                // waves along co / ci
-    constexpr int WTCO = 64, WTCI = TCI / WCI;                  // wave tile: 64 co x (32 | 16) ci
-    constexpr int MT = WTCO / 16, NTF = WTCI / 16;
+    constexpr int WCO = NKY == 3 ? 2 : TCO / 64, WCI = 4 / WCO; // waves along co / ci
+    constexpr int WTCO = TCO / WCO, WTCI = TCI / WCI;           // wave tile: 64 co x (32 | 16) ci, or 32 x 32 with nine taps
+    constexpr int MT = WTCO / 16, NTF = WTCI / 16, NTAP = 3 * NKY;
+    static_assert(NKY == 1 || TCO == 64, "the nine-tap variant keeps 9 x 2 x 2 accumulators per wave");
     constexpr int PER_STEP = NY + NX;                           // DMAs per wave and k-step
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.y;
-    const int ky = tile % 3;
-    tile /= 3;
+    const int ky = NKY == 3 ? 0 : tile % 3;                     // first kernel row of this workgroup
+    if (NKY == 1) tile /= 3;
     const int ci0 = (tile % p.tiles_ci) * TCI, co0 = (tile / p.tiles_ci) * TCO;
     const int seg0 = blockIdx.x * p.segs_per_slice;
     int nseg = p.total_segs - seg0;
@@ -95,8 +96,10 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         const int e = k * NT + tid, px = e / (TCI / 8), slot = e % (TCI / 8);
-        xpx[k] = px < XPX ? px : -(1 << 20);                    // pieces past the 34-pixel row: always the zero page
-        xoff[k] = px * p.ldx + ci0 + ((slot ^ (2 * pair_swz<XROW>(px))) << 3);
+        // image row px = (patch row r, column c); pieces past the last row: always the zero page
+        const int r = px / XPX, c = px - r * XPX;
+        xpx[k] = px < NKY * XPX ? (r << 8 | c) : -1;
+        xoff[k] = (r * p.Wi + c) * p.ldx + ci0 + ((slot ^ (2 * pair_swz<XROW>(px))) << 3);
     }
 
     // uniform segment cursor of the NEXT k-step to issue
@@ -106,7 +109,6 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
     auto issue = [&](int s) {                                   // DMAs of k-step s (s >= nseg: zero page only) into ring slot s & 3
         const bool live = s < nseg;
         const int ox0 = csx * SEG, iy = coy - p.pad + ky, ix0 = ox0 - p.pad;
-        const bool rowok = live && (unsigned)iy < (unsigned)p.Hi;
         const bf16_t *yb = dy + ((size_t)(cn * p.Ho + coy) * p.Wo + ox0) * p.ldy;
         const bf16_t *xb = x + ((long)(cn * p.Hi + iy) * p.Wi + ix0) * p.ldx;
         const unsigned slot = lds0 + (s & 3) * SLOT;
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
         }
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-            const bool ok = rowok && (unsigned)(ix0 + xpx[k]) < (unsigned)p.Wi;
+            const int r = xpx[k] >> 8, c = xpx[k] & 255;
+            const bool ok = live && xpx[k] >= 0 && (unsigned)(iy + r) < (unsigned)p.Hi && (unsigned)(ix0 + c) < (unsigned)p.Wi;
             glds16(ok ? xb + xoff[k] : zero, slot + YB + (k * NT + wave * 64) * 16);
         }
         if (live) {
@@ -129,9 +132,9 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
     };
 
     const int wr = wave / WCI, wc = wave % WCI;
-    f32x4 acc[3][MT][NTF];
+    f32x4 acc[NTAP][MT][NTF];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -149,10 +152,10 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
 #pragma unroll
         for (int i = 0; i < MT; ++i) a[i] = tr_frag<YROW>(Ys, 0, wr * WTCO + 16 * i, lane);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NTAP; ++t) {
             bf16x8 b[NTF];
 #pragma unroll
-            for (int j = 0; j < NTF; ++j) b[j] = tr_frag<XROW>(Xs, t, wc * WTCI + 16 * j, lane);
+            for (int j = 0; j < NTF; ++j) b[j] = tr_frag<XROW>(Xs, (t / 3) * XPX + (t % 3), wc * WTCI + 16 * j, lane);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
 
     // accumulate: row co = 4*(lane>>4)+r, col ci = lane&15
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -190,16 +193,16 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO>
+template <int TCO, int NKY>
 int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
-    constexpr int SMEM = 4 * (SEG * TCO * 2 + 2 * NT * 16);
+    constexpr int SMEM = 4 * (SEG * TCO * 2 + ((NKY * XPX * 8 + NT - 1) / NT) * NT * 16);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wgrad_glds_kernel<TCO>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)wgrad_glds_kernel<TCO, NKY>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     p.tiles_ci = cdiv(p.Ci, 64);
-    const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * 3;
+    const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * (3 / NKY);
     // Split-K factor: fill the chip's 512 workgroup slots (2 per CU) in ONE round -- 528 workgroups measured 1.3x slower
     // than 480 -- within an atomic budget of 48 MB per launch (sweep on one device, 256->256 @ 57x76: 24 MB / 240
     // workgroups 108 us, 48 MB / 480 workgroups 91 us; under-filling the chip costs more than the extra atomics).
@@ -211,8 +214,8 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     if (slices < 1) slices = 1;
     p.segs_per_slice = cdiv(p.total_segs, slices);
     slices = cdiv(p.total_segs, p.segs_per_slice);
-    rdfc_note_kernel("wgrad_glds_kernel<%d>", TCO);
-    hipLaunchKernelGGL((wgrad_glds_kernel<TCO>), dim3(slices, tiles), dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw, zero);
+    rdfc_note_kernel("wgrad_glds_kernel<%d, %d>", TCO, NKY);
+    hipLaunchKernelGGL((wgrad_glds_kernel<TCO, NKY>), dim3(slices, tiles), dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw, zero);
     return 1;
 }
 
@@ -231,6 +234,11 @@ int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, 
     if (zero == nullptr) return 0;
     WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0};
     // 128-co tiles from 256 output channels up; below that the 64-co tile's larger grid wins (128->128: 82 vs 92 us)
-    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return launch<128>(p, x, dy, dw, zero, st);
-    return launch<64>(p, x, dy, dw, zero, st);
+    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return launch<128, 1>(p, x, dy, dw, zero, st);
+    // all nine taps per workgroup (dY and X staged once instead of once per kernel row): measured SLOWER on the
+    // full-resolution 64-channel layers (120 vs 97 us: 36 MFMAs against 40 transposing reads per k-step, 244 VGPRs), so
+    // L2 traffic is not what bounds them; kept behind RDFC_WGRAD_GLDS_NINE=1 for A/B runs
+    static const int nine = getenv("RDFC_WGRAD_GLDS_NINE") ? atoi(getenv("RDFC_WGRAD_GLDS_NINE")) : 0;
+    if (nine && d->Co * d->Ci <= 128 * 64) return launch<64, 3>(p, x, dy, dw, zero, st);
+    return launch<64, 1>(p, x, dy, dw, zero, st);
 }

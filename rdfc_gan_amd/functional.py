@@ -18,6 +18,12 @@ import torch
 
 from . import hip
 
+# Normalisation reductions: two-stage (per-workgroup partials + a fixed-order f64 finalize launch; bitwise reproducible)
+# by default.  RDFC_NORM_ONESTAGE=1 switches to f64 atomics into one accumulator per (group, channel), which drops the
+# finalize launches but measured SLOWER on MI355X: ~540 workgroups adding to the same address serialise at ~54 ns per
+# add (statistics kernels 1.6 -> 6.4 ms, backward reductions 4.4 -> 9.2 ms per step), far more than the 2.2 ms of
+# finalize launches it saves.
+_DETERMINISTIC = os.environ.get('RDFC_NORM_ONESTAGE', '0') != '1'
 _compute_dtype = torch.bfloat16
 _weights_epoch = 0
 _pack_cache = {}
@@ -129,11 +135,17 @@ class _ConvBlock(torch.autograd.Function):
         if spec.norm == 'bn' and not training:
             mean = run_mean.view(1, -1).float()
             rstd = torch.rsqrt(run_var.view(1, -1).float() + spec.eps)
+            z = torch.empty(N, Ho, Wo, Cout, dtype=dtype, device=x.device)
+            hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
         else:
             upd = spec.norm == 'bn' and run_mean is not None
-            mean, rstd = hip.norm_stats(y, G, spec.eps, run_mean if upd else None, run_var if upd else None, spec.momentum)
-        z = torch.empty(N, Ho, Wo, Cout, dtype=dtype, device=x.device)
-        hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
+            z = torch.empty(N, Ho, Wo, Cout, dtype=dtype, device=x.device)
+            if _DETERMINISTIC:
+                mean, rstd = hip.norm_stats(y, G, spec.eps, run_mean if upd else None, run_var if upd else None, spec.momentum)
+                hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
+            else:
+                mean, rstd = hip.norm_forward_onestage(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
+                                                       run_mean if upd else None, run_var if upd else None, spec.momentum)
         ctx.save_for_backward(x, weight, y, mean, rstd, gamma, beta, res, prelu)
         return z
 
@@ -150,9 +162,10 @@ class _ConvBlock(torch.autograd.Function):
             # affine gradients straight into persistent .grad buffers (FlatAdam's) when there is one statistics group
             direct = (gamma is not None and beta is not None and mean.shape[0] == 1 and ctx.needs_input_grad[3]
                       and ctx.needs_input_grad[4] and _accumulable(gamma.grad) and _accumulable(beta.grad))
-            dy, g_res, sums = hip.norm_backward(dz, y, mean, rstd, gamma, beta, res, spec.act, spec.slope, prelu,
-                                                frozen=frozen, want_dres=res is not None and ctx.needs_input_grad[5],
-                                                acc_beta=beta.grad if direct else None, acc_gamma=gamma.grad if direct else None)
+            nb = hip.norm_backward if _DETERMINISTIC else hip.norm_backward_onestage
+            dy, g_res, sums = nb(dz, y, mean, rstd, gamma, beta, res, spec.act, spec.slope, prelu,
+                              frozen=frozen, want_dres=res is not None and ctx.needs_input_grad[5],
+                              acc_beta=beta.grad if direct else None, acc_gamma=gamma.grad if direct else None)
             if gamma is not None and not direct:
                 g_gamma, g_beta = sums[0, 1], sums[0, 0]
             if prelu is not None:

@@ -194,6 +194,7 @@ class RDFCGAN:
                     p.requires_grad = requires_grad
 
     def forward(self):
+        hip.reset_sums(self.device)         # zeroed f64 scratch of the one-stage normalisation reductions: rewound per step
         self.fake_B = self.G_A2B(self.real_A, self.aux_A, self._normal('real_A', self.real_A))['pred_depth']
         if getattr(self, '_graph_mode', False):
             # host RNG draw happened before the replay (_draw_pepper_static); an all-zero mask is the "no noise" draw
