@@ -19,27 +19,30 @@ struct Map {       // geometry shared by the kernels
     int chunk;     // pixels per workgroup (host: chunk_pixels)
 };
 
-// Pixels per workgroup: ~32 rows per thread (4 independent 16-byte loads in flight per stream and
-// thread, eight batches), so that a full-resolution map yields >= 500 workgroups (2 per CU) and the
-// small instance-norm maps still spread over the chip; capped at 4096 chunks per group.
+// Pixels per workgroup.  Reductions: 32 rows per thread (4 independent 16-byte loads in flight per stream, eight
+// batches), halved down to 8 while the map would give fewer than 512 workgroups: the encoder's mid-size maps (128 ch @
+// 114x152, 256 ch @ 57x76) used to get 136-271 workgroups and ran at <= 2.7 TB/s (tools/norm_trace.sh).  Going
+// further (4 rows, ~1000 workgroups everywhere) measured 30 % SLOWER: every workgroup pays ~2 us of dependent
+// per-channel constant loads before it streams.  Capped at 4096 chunks per group.
 inline int chunk_pixels(int P, int C, int vec) {
     const int cvt = C / vec < NT ? (C / vec > 0 ? C / vec : 1) : NT;
     const int rpb = NT / cvt;
-    int chunk = 32 * rpb;
+    int rows = 32;
+    while (rows > 8 && P / (rows * rpb) < 512) rows >>= 1;
+    int chunk = rows * rpb;
     const int lo = cdiv(P, 4096);
     if (chunk < lo) chunk = cdiv(lo, rpb) * rpb;
     return chunk;
 }
 inline Map make_map(int G, int P, int C, int vec) { return Map{G, P, C, chunk_pixels(P, C, vec)}; }
-// streaming (non-reducing) kernels: 8 rows per thread -> 4x more workgroups than the reductions
+// streaming (non-reducing) kernels: 8 rows per thread -> ~2000 workgroups on a full-resolution map
 inline Map make_map_stream(int G, int P, int C, int vec) {
-    Map m = make_map(G, P, C, vec);
-    int c = m.chunk / 4;
+    const int cvt = C / vec < NT ? (C / vec > 0 ? C / vec : 1) : NT;
+    const int rpb = NT / cvt;
+    int c = 8 * rpb;
     const int lo = cdiv(P, 8192);
     if (c < lo) c = lo;
-    if (c < 1) c = 1;
-    m.chunk = c;
-    return m;
+    return Map{G, P, C, c};
 }
 
 // body(p) for p = begin + r0, +RPB, ... < end, four rows per trip so four independent loads are in flight

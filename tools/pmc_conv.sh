@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $root
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_${tag}/p$i -- python3 tools/conv_bench.py "$@" 5 > /dev/null 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_${tag}/p$i -- python3 tools/conv_bench.py "$@" 5 > /dev/null 2>&1
 done
 python3 - "$tag" <<'PY'
 import csv, glob, sys, collections
