@@ -83,6 +83,13 @@ int rdfc_unpack_wgrad(const float *dw_packed, float *grad_oihw, int O, int I, in
 /* y = act(conv(x, w_fwd) + bias).  bias: f32[Co] or NULL. */
 int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias,
                         void *y, void *stream);
+/* Forward convolution that also produces the per-tile partial statistics {sum, sum of squares}[G][nchunk][2][Co] of the
+ * values it stores, for the normalisation layer behind it (G = 1 batch norm, G = N instance norm): the separate
+ * rdfc_norm_stats pass over y disappears.  nchunk = rdfc_conv_stats_nchunk(d, G); 0 means no fused kernel covers the
+ * shape (call rdfc_conv2d_forward + rdfc_norm_stats instead).  Finalize with rdfc_norm_finalize_n. */
+int rdfc_conv_stats_nchunk(const rdfc_conv_desc *d, int G);
+int rdfc_conv2d_forward_stats(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                              float *partial, int G, void *stream);
 /* dx[N,Hi,Wi,Ci] = conv^T(dy[N,Ho,Wo,Co], w_bwd); ld of dy = d->ldy, ld of dx = d->ldx.
  * Also the forward of ConvTranspose2d (then bias/act apply to the result). */
 int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const float *bias,
@@ -121,6 +128,9 @@ int rdfc_norm_stats(const void *x, float *partial, int G, int P, int C, int ld, 
  * (momentum, unbiased variance) when run_mean != NULL. */
 int rdfc_norm_finalize(const float *partial, float *mean, float *rstd, int G, int P, int C, int dtype, float eps,
                        float *run_mean, float *run_var, float momentum, void *stream);
+/* rdfc_norm_finalize for partials with an explicit chunk count (rdfc_conv2d_forward_stats). */
+int rdfc_norm_finalize_n(const float *partial, int nchunk, float *mean, float *rstd, int G, int P, int C, float eps,
+                         float *run_mean, float *run_var, float momentum, void *stream);
 /* z = act(gamma*(x-mean)*rstd + beta + res).  gamma/beta f32[C] or NULL (1/0); res may be NULL.
  * prelu: device pointer to the slope when act == RDFC_ACT_PRELU. */
 int rdfc_norm_apply(const void *x, const float *mean, const float *rstd, const float *gamma, const float *beta,

@@ -361,7 +361,8 @@ int rdfc_try_conv3x3_patch(const rdfc_conv_desc *d, int transposed, const void *
 int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                        hipStream_t st);                  // conv_thin.hip
 int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
-                          hipStream_t st);               // conv_glds.hip
+                          hipStream_t st, float *stats = nullptr, int G = 0);               // conv_glds.hip
+int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G);
 int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                         hipStream_t st);                 // conv_igemm_glds.hip
 int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
@@ -388,6 +389,26 @@ extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, w_fwd, bias, y, st);
     else launch_T<float>(p, x, w_fwd, bias, y, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_forward");
+    return 0;
+}
+
+extern "C" int rdfc_conv_stats_nchunk(const rdfc_conv_desc *d, int G) {
+    if (d == nullptr || G < 1) return 0;
+    // Opt-in (RDFC_FUSED_STATS=1): measured neutral inside the train step -- the statistics pass it removes (0.8 ms) is
+    // paid back by the longer conv epilogue (+0.5 ms) and a finalize over 2-4x more partial rows (+0.5 ms).
+    static const bool on = getenv("RDFC_FUSED_STATS") != nullptr;
+    return on ? rdfc_conv3x3_glds_stats_nchunk(d, G) : 0;
+}
+
+extern "C" int rdfc_conv2d_forward_stats(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                                         float *partial, int G, void *stream) {
+    if (int e = check_desc(d, "rdfc_conv2d_forward_stats")) return e;
+    RDFC_REQUIRE(partial != nullptr, "rdfc_conv2d_forward_stats: null statistics buffer");
+    RDFC_REQUIRE(rdfc_conv_stats_nchunk(d, G) > 0, "rdfc_conv2d_forward_stats: shape not covered by a fused-statistics kernel "
+                 "(ask rdfc_conv_stats_nchunk first)");
+    RDFC_REQUIRE(rdfc_try_conv3x3_glds(d, 0, x, w_fwd, bias, y, (hipStream_t)stream, partial, G),
+                 "rdfc_conv2d_forward_stats: launch refused");
+    RDFC_LAUNCH_CHECK("rdfc_conv2d_forward_stats");
     return 0;
 }
 

@@ -623,6 +623,17 @@ extern "C" int rdfc_norm_finalize(const float *partial, float *mean, float *rstd
     return 0;
 }
 
+extern "C" int rdfc_norm_finalize_n(const float *partial, int nchunk, float *mean, float *rstd, int G, int P, int C, float eps,
+                                    float *run_mean, float *run_var, float momentum, void *stream) {
+    RDFC_REQUIRE(G > 0 && P > 0 && C > 0 && nchunk > 0, "rdfc_norm_finalize_n: non-positive size");
+    RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_finalize_n: running statistics need G == 1 (batch norm)");
+    Map m{G, P, C, 0};
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(C, 32), G), dim3(FNT), 0, (hipStream_t)stream, m, nchunk, partial, mean, rstd,
+                       eps, run_mean, run_var, momentum);
+    RDFC_LAUNCH_CHECK("rdfc_norm_finalize_n");
+    return 0;
+}
+
 extern "C" int rdfc_norm_apply(const void *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
                                const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype,
                                int act, float slope, const float *prelu, void *stream) {

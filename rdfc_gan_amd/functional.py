@@ -118,10 +118,18 @@ class _ConvBlock(torch.autograd.Function):
         epi_act = 'none' if has_norm else spec.act
         out_f32 = spec.out_f32 and not has_norm
         y = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32 if out_f32 else dtype, device=x.device)
+        fused = None                # (mean, rstd) when the conv's epilogue produced the normalisation statistics
+        live_stats = has_norm and not (spec.norm == 'bn' and not training)
         if not spec.transposed:
             d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
                               act=epi_act, slope=spec.slope, out_f32=out_f32)
-            hip.conv_forward(d, x, wf, bias, y)
+            G_ = N if spec.norm == 'in' else 1
+            if live_stats and _DETERMINISTIC and hip.conv_stats_nchunk(d, G_) > 0:
+                upd = spec.norm == 'bn' and run_mean is not None
+                fused = hip.conv_forward_stats(d, x, wf, bias, y, G_, spec.eps, run_mean if upd else None,
+                                               run_var if upd else None, spec.momentum)
+            else:
+                hip.conv_forward(d, x, wf, bias, y)
         else:   # equivalent conv maps the (larger) output map onto x
             d = hip.conv_desc((N, Ho, Wo, Cout), Cin, spec.k, spec.stride, spec.pad, ldx=Cout, ldy=hip.ld(x),
                               dtype=hip.dt(x), act=epi_act, slope=spec.slope, out_f32=out_f32, out_hw=(H, W))
@@ -140,7 +148,10 @@ class _ConvBlock(torch.autograd.Function):
         else:
             upd = spec.norm == 'bn' and run_mean is not None
             z = torch.empty(N, Ho, Wo, Cout, dtype=dtype, device=x.device)
-            if _DETERMINISTIC:
+            if fused is not None:
+                mean, rstd = fused
+                hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
+            elif _DETERMINISTIC:
                 mean, rstd = hip.norm_stats(y, G, spec.eps, run_mean if upd else None, run_var if upd else None, spec.momentum)
                 hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
             else:

@@ -168,6 +168,27 @@ def conv_forward(d, x, w_fwd, bias, y):
     return y
 
 
+def conv_stats_nchunk(d, G):
+    return lib().rdfc_conv_stats_nchunk(C.byref(d), int(G))
+
+
+def conv_forward_stats(d, x, w_fwd, bias, y, G, eps, run_mean=None, run_var=None, momentum=0.1):
+    """conv forward with the normalisation statistics fused into its epilogue (conv_stats_nchunk(d, G) must be > 0).
+    -> mean[G,Co], rstd[G,Co]"""
+    n = conv_stats_nchunk(d, G)
+    assert n > 0
+    partial = torch.empty(G * n * 2 * d.Co, dtype=torch.float32, device=x.device)
+    with _Timed('igemm_kernel (conv fwd / dgrad)', d):
+        _chk(lib().rdfc_conv2d_forward_stats(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial), int(G), _st()),
+             'rdfc_conv2d_forward_stats')
+    mean = torch.empty(G, d.Co, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(G, d.Co, dtype=torch.float32, device=x.device)
+    P = d.N * d.Ho * d.Wo // G
+    _chk(lib().rdfc_norm_finalize_n(_p(partial), n, _p(mean), _p(rstd), int(G), P, d.Co, _f(eps), _p(run_mean), _p(run_var),
+                                    _f(momentum), _st()), 'rdfc_norm_finalize_n')
+    return mean, rstd
+
+
 def conv_dgrad(d, dy, w_bwd, bias, dx):
     with _Timed('igemm_kernel (conv fwd / dgrad)', d):
         _chk(lib().rdfc_conv2d_dgrad(C.byref(d), _p(dy), _p(w_bwd), _p(bias), _p(dx), _st()), 'rdfc_conv2d_dgrad')

@@ -304,12 +304,14 @@ class RDFCGAN:
             o.host_counts = False
         torch.cuda.synchronize()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls belong to the graph
+        mode = dict(capture_error_mode='thread_local')
         try:
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, **mode):
                 stats = self._seg_G()
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with torch.cuda.graph(g2, pool=g1.pool(), **mode):
                 stats.update(self._seg_D())
-            with torch.cuda.graph(g3, pool=g1.pool()):
+            with torch.cuda.graph(g3, pool=g1.pool(), **mode):
                 self._seg_adam()
         finally:
             for o in self.optimizers.values():
@@ -330,7 +332,15 @@ class RDFCGAN:
         for o in self.optimizers.values():
             o.sync_hyper()
         if self._graphs is None:
-            self._capture()
+            try:
+                self._capture()
+            except Exception as e:              # capture is an optimisation: a failed one must not take the run down
+                import warnings
+                warnings.warn(f'HIP graph capture failed ({type(e).__name__}: {e}); continuing with eager launches')
+                torch.cuda.synchronize()
+                self._graph_mode, self._graphs = False, None
+                self.set_input(self._batch)
+                return self.optimize_parameters(sync_losses)
         g1, g2, g3, stats = self._graphs
         g1.replay()
         self.optimizer_G.all_reduce_grads_async()

@@ -210,6 +210,38 @@ def test_norm_fwd_bwd(dtype, mode, act, res):
         assert rel_err(sums[:, 2].sum(), ar.grad.sum()) < t, 'dslope'
 
 
+@pytest.mark.parametrize('case', [(3, 21, 37, 64, 64, 1), (2, 19, 23, 64, 128, 0), (4, 18, 20, 96, 256, 1)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_fused_statistics(case, monkeypatch):
+    """rdfc_conv2d_forward_stats (opt-in, RDFC_FUSED_STATS=1): the conv epilogue's per-tile statistics + rdfc_norm_finalize_n against the separate
+    rdfc_norm_stats pass over the stored map, batch-norm (G = 1, with running statistics) and instance-norm (G = N)."""
+    h = hip()
+    N, H, W, Ci, Co, pad = case
+    dtype = torch.bfloat16
+    if h.conv_stats_nchunk(h.conv_desc((N, H, W, Ci), Co, 3, 1, pad, ldx=Ci, ldy=Co, dtype=h.dt(torch.empty(0, dtype=dtype))), 1) == 0:
+        pytest.skip('fused statistics are opt-in: run with RDFC_FUSED_STATS=1')
+    x = to_pm(rnd(N, Ci, H, W, seed=1), dtype)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=(Ci * 9) ** -0.5).to(DEV)
+    b = rnd(Co, seed=3, scale=0.1).to(DEV)
+    wf, _ = h.pack_weight(w, dtype)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    d = h.conv_desc(x.shape, Co, 3, 1, pad, ldx=h.ld(x), ldy=Co, dtype=h.dt(x))
+    for G in (1, N):
+        assert h.conv_stats_nchunk(d, G) > 0
+        y_ref = torch.empty(N, Ho, Wo, Co, dtype=dtype, device=DEV)
+        h.conv_forward(d, x, wf, b, y_ref)
+        rm1, rv1 = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        rm2, rv2 = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        upd = G == 1
+        mean_ref, rstd_ref = h.norm_stats(y_ref, G, 1e-5, rm1 if upd else None, rv1 if upd else None, 0.1)
+        y = torch.empty_like(y_ref)
+        mean, rstd = h.conv_forward_stats(d, x, wf, b, y, G, 1e-5, rm2 if upd else None, rv2 if upd else None, 0.1)
+        assert torch.equal(y, y_ref)
+        assert rel_err(mean, mean_ref) < 2e-5 and rel_err(rstd, rstd_ref) < 2e-5
+        if upd:
+            assert rel_err(rm2, rm1) < 2e-5 and rel_err(rv2, rv1) < 2e-5
+
+
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
 def test_norm_onestage_matches_twostage(dtype):
     """rdfc_norm_*_acc / *_sums (f64 atomics, no finalize launch) against the two-stage fixed-order path"""
