@@ -109,7 +109,9 @@ def main():
     ap.add_argument('--exact-schedule', action='store_true', help="run upstream's two dead forwards too")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='launch every kernel from the host each step instead of replaying the captured HIP graphs')
+    ap.add_argument('--graph', action='store_true', help='capture the step into HIP graphs and replay them (single stream; on ROCm 7.2 the '
+                    'replay costs about as much per node as an eager launch, so the multi-stream eager step is faster)')
+    ap.add_argument('--event-every', type=int, default=4, help='per-kernel HIP events on every n-th timed step (eager mode)')
     ap.add_argument('--by-shape', default=None, help='write a per-conv-shape time / TFLOP/s table (debug aid) to this file')
     a = ap.parse_args()
 
@@ -139,9 +141,10 @@ def main():
         model.set_input(batches[i % len(batches)])
         return model.optimize_parameters(sync_losses=False)
 
-    # Warm-up: one eager step (lazy initialisation: kernel attributes, zero pages, weight packing), then, unless --eager,
-    # capture the step into HIP graphs (G step | D step | Adam; the data-parallel all-reduces stay eager between them).
-    graphed = not a.eager
+    # Default: eager launches spread over four HIP streams (main, RDFGenerator's depth branch, the B->A half of the G step,
+    # weight gradients).  --graph: after one eager warm-up step the step is captured into three HIP graphs (G step | D step |
+    # Adam; the data-parallel all-reduces stay eager between them) and replayed.
+    graphed = a.graph
     for i in range(a.warmup):
         if graphed and i == 1:
             model.enable_graph(True)
@@ -153,16 +156,21 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # Per-kernel HIP events (roofline): a replayed graph cannot carry torch events, so with graphs the LAST timed step runs
-    # eagerly with an event pair around every conv launch; in --eager mode every timed step carries them.
+    # Per-kernel HIP events (roofline), inside the timed region: an event pair around every conv launch of every
+    # --event-every-th timed step (each pair costs ~3 us of host time; the step is launch-bound, so they are sampled).
+    # A replayed graph cannot carry torch events: with --graph the LAST timed step runs eagerly with them instead.
     events = not a.no_kernel_events
-    if events and not graphed:
-        hip.PROFILE = []
+    prof_all, ev_steps = [], 0
     t0 = time.perf_counter()
     for i in range(a.steps):
-        if graphed and events and i == a.steps - 1 and a.steps > 1:
-            model.enable_graph(False)
-            hip.PROFILE = []
+        with_ev = events and (i == a.steps - 1 if graphed else i % max(1, a.event_every) == 0)
+        if with_ev:
+            if graphed:
+                model.enable_graph(False)
+            hip.PROFILE = prof_all
+            ev_steps += 1
+        else:
+            hip.PROFILE = None
         losses = one_step(i)
     enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (== elapsed when launch-bound)
     torch.cuda.synchronize()
@@ -170,8 +178,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof, hip.PROFILE = hip.PROFILE, None
-    ev_steps = 1 if (graphed and a.steps > 1) else a.steps       # timed steps that carried per-kernel events
+    prof, hip.PROFILE = prof_all, None
+    ev_steps = max(1, ev_steps)                                   # timed steps that carried per-kernel events
+    # Untimed extra step on ONE stream with the same events: in the timed steps a kernel shares the chip with the other
+    # streams' kernels, so its duration there (what rocprofv3 of this command shows too) understates what it does alone.
+    iso = []
+    if events and rank == 0:
+        if graphed:
+            model.enable_graph(False)
+        Fh.set_multi_stream(False)
+        hip.PROFILE = iso
+        one_step(a.steps)
+        torch.cuda.synchronize()
+        hip.PROFILE = None
+        Fh.set_multi_stream(True)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -192,7 +212,7 @@ def main():
                                global_batch=world * a.batch, parallelism=f'dp{world}',
                                dead_forwards='executed' if a.exact_schedule else 'elided (result-identical, see DESIGN.md)',
                                step_gflop_per_pair=round(gflop_pair, 1)),
-                   host_enqueue_ms_per_step=round(1e3 * enqueue / a.steps, 3), launch='eager' if not graphed else 'hip graphs (3 per step)',
+                   host_enqueue_ms_per_step=round(1e3 * enqueue / a.steps, 3), launch='eager, 4 streams' if not graphed else 'hip graphs (3 per step)',
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
         if prof:
@@ -214,6 +234,14 @@ def main():
                                    avg_launch_us=round(1e6 * sec / n, 2),
                                    share_of_step=round(sec / (elapsed * ev_steps / a.steps), 4),
                                    event_steps=ev_steps)
+            if iso:
+                ifl = sum(r[1] for r in iso if r[5] == top)
+                isec = sum(r[2].elapsed_time(r[3]) * 1e-3 for r in iso if r[5] == top)
+                inum = sum(1 for r in iso if r[5] == top)
+                if inum:
+                    out['roofline']['isolated'] = dict(achieved=round(ifl / isec / 1e12, 2), frac=round(ifl / isec / 1e12 / peak, 4),
+                                                       avg_launch_us=round(1e6 * isec / inum, 2), launches=inum,
+                                                       note='same kernel, one extra untimed step on a single stream')
             out['kernels'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), avg_launch_us=round(1e6 * v[1] / v[2], 2),
                                       launches=v[2], share_of_step=round(v[1] / (elapsed * ev_steps / a.steps), 4))
                               for k, v in sorted(sym.items(), key=lambda kv: -kv[1][1])[:8]}

@@ -64,6 +64,69 @@ def _accumulable(g):
     return g is not None and g.dtype == torch.float32 and g.is_contiguous() and not g.requires_grad
 
 
+# ---- weight gradients on a side stream ----------------------------------------------------------------------------
+# A weight gradient that accumulates straight into .grad has no consumer before the optimizer step, so it does not
+# have to sit in the backward chain: it is launched on a second HIP stream (forked behind the kernel that produced dy)
+# and the MFMA-bound split-K GEMM overlaps the HBM-bound normalisation kernels of the layers below.  join_side_stream()
+# brings the streams back together; FlatAdam calls it before it touches the gradients.  RDFC_WGRAD_STREAM=0 disables it.
+_WGRAD_STREAM = os.environ.get('RDFC_WGRAD_STREAM', '1') != '0'
+_multi_stream = True        # False while a step is captured into / replayed from HIP graphs (single-stream capture)
+
+
+def set_multi_stream(enabled):
+    """helper streams (weight gradients, RDFGenerator's depth branch, the B->A half of the G step) on / off"""
+    global _multi_stream
+    join_side_stream()
+    _multi_stream = bool(enabled)
+
+
+def multi_stream():
+    return _multi_stream
+_side = {}          # device -> [stream, list of tensors the pending launches still read]
+
+
+def _side_stream(device):
+    s = _side.get(device)
+    if s is None:
+        s = _side[device] = [torch.cuda.Stream(device=device), []]
+    return s
+
+
+_branch = {}
+
+
+def branch_stream(device):
+    """second compute stream for an independent branch of a network (RDFGenerator's depth branch)"""
+    s = _branch.get(device)
+    if s is None:
+        s = _branch[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+_net = {}
+
+
+def net_stream(device):
+    """third compute stream: the half of the train step that does not depend on the other (RDFCGAN: the B->A chain)"""
+    s = _net.get(device)
+    if s is None:
+        s = _net[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_side_stream():
+    """make the current stream wait for everything launched on the helper streams (weight gradients on the side stream,
+    the branch / net streams they may have been forked from); release the tensors kept alive for them"""
+    for dev, (stream, keep) in _side.items():
+        cur = torch.cuda.current_stream(dev)
+        for extra in (_branch.get(dev), _net.get(dev)):
+            if extra is not None and extra != cur:
+                cur.wait_stream(extra)
+        if keep:
+            cur.wait_stream(stream)
+            keep.clear()
+
+
 def _wgrad(d, a, b, weight, O, I, k, scale):
     """weight gradient of one conv; -> tensor for autograd, or None after accumulating into weight.grad in place.
 
@@ -72,7 +135,14 @@ def _wgrad(d, a, b, weight, O, I, k, scale):
     no zero-fill, no unpack, no autograd add."""
     g = weight.grad
     if scale == 1.0 and g is not None and g.dtype == torch.float32 and hip.is_ohwi(g) and not g.requires_grad:
-        hip.conv_wgrad(d, a, b, into=g)
+        if _WGRAD_STREAM and _multi_stream and a.is_cuda:
+            stream, keep = _side_stream(a.device)
+            stream.wait_stream(torch.cuda.current_stream(a.device))
+            with torch.cuda.stream(stream):
+                hip.conv_wgrad(d, a, b, into=g)
+            keep.append((a, b))         # their memory must not be recycled before the join
+        else:
+            hip.conv_wgrad(d, a, b, into=g)
         return None
     if scale == 1.0:
         dw = hip.conv_wgrad(d, a, b)

@@ -9,6 +9,9 @@ build_generator  <- the git-ignored lib/models/generator/build_generator.py (cal
 Inputs / outputs are upstream's NCHW f32 tensors; inside, maps are pixel-major in the
 compute dtype (functional.set_compute_dtype).
 """
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 
@@ -84,6 +87,10 @@ class _ConvSigmoid(nn.Sequential):
         return run_conv(x, self[0], None, self[1], out_f32=True)
 
 
+# RDFC_BRANCH_STREAMS=0: single-stream RDFGenerator (A/B: 55.9 -> 51.5 ms per train step with the second stream)
+_BRANCH_STREAMS = os.environ.get('RDFC_BRANCH_STREAMS', '1') != '0'
+
+
 class RDFGenerator(nn.Module):
     def __init__(self, encoder_rgb='resnet18', encoder_depth='resnet18', pretrained_on_imagenet=True,
                  semantic_channels_in=3, fuse_depth_in_rgb_decoder='WAdaIN', bn=True,
@@ -135,26 +142,43 @@ class RDFGenerator(nn.Module):
         cat = Fh.crop_cat
         nrm = Fh.to_pm(normal)                    # `rgb` is accepted but never read (rdf_generator.py:282)
         dep = Fh.to_pm(depth)
+        # The depth branch is independent of the RGB branch (the RGB decoder only READS its features): it runs on a second
+        # HIP stream so that one branch's HBM-bound normalisation kernels overlap the other's MFMA-bound convolutions.
+        # Autograd replays each node on the stream of its forward, so the backward overlaps the same way.
+        two = _BRANCH_STREAMS and Fh.multi_stream() and nrm.is_cuda
+        main = torch.cuda.current_stream(nrm.device) if two else None
+        side = Fh.branch_stream(nrm.device) if two else None
+        if two:
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
+            d1 = Fh.cat(self.depth_branch_en1_rgb(nrm), self.depth_branch_en1_depth(dep))
+            d = [None, d1]
+            for idx in range(2, 7):
+                d.append(D.forward_encoder_layer(d[-1], idx))
+            dfs = [d[6]]                          # depth-decoder features, one per fusion level
+            for lvl in (5, 4, 3, 2):
+                dfs.append(cat(D.forward_decoder_layer(dfs[-1], layer_idx=lvl), d[lvl]))
+            df = dfs[-1]
+            pred_init = self._head(self.id_dec0, cat(self.id_dec1(df), d1), 'tanh')
+            confidence = self.cf_dec0(cat(self.cf_dec1(df), d1))
+            if self.use_nlspn_refine:
+                guide = self.gd_dec0(cat(self.gd_dec1(df), d1))
+                depth_map_2 = self.nlspn_refine_module(pred_init, guide, confidence, depth)
+            else:
+                depth_map_2 = pred_init
         r1 = self.rgb_branch_en1(nrm)
-        d1 = Fh.cat(self.depth_branch_en1_rgb(nrm), self.depth_branch_en1_depth(dep))
-        r, d = [None, r1], [None, d1]
+        r = [None, r1]
         for idx in range(2, 7):
             r.append(R.forward_encoder_layer(r[-1], idx))
-            d.append(D.forward_encoder_layer(d[-1], idx))
-        rf, df = r[6], d[6]
-        for lvl, fuse in zip((5, 4, 3, 2), (self.fuse_layer1, self.fuse_layer2, self.fuse_layer3, self.fuse_layer4)):
-            rf_next = cat(R.forward_decoder_layer(fuse(rf, df), layer_idx=lvl), r[lvl])
-            df = cat(D.forward_decoder_layer(df, layer_idx=lvl), d[lvl])
-            rf = rf_next
+        if two:
+            main.wait_stream(side)                # (coarse: the whole depth branch; its features feed every fusion level)
+            for t in dfs + [depth_map_2, confidence]:
+                t.record_stream(main)             # allocated on the side stream, read on the main one
+        rf = r[6]
+        for k, (lvl, fuse) in enumerate(zip((5, 4, 3, 2), (self.fuse_layer1, self.fuse_layer2, self.fuse_layer3, self.fuse_layer4))):
+            rf = cat(R.forward_decoder_layer(fuse(rf, dfs[k]), layer_idx=lvl), r[lvl])
         depth_map_1 = self._head(self.rgb_pred_dec0, cat(self.rgb_pred_dec1(rf), r1), 'tanh')
         confidence_map_1 = self.rgb_conf_dec0(cat(self.rgb_conf_dec1(rf), r1))
-        pred_init = self._head(self.id_dec0, cat(self.id_dec1(df), d1), 'tanh')
-        confidence = self.cf_dec0(cat(self.cf_dec1(df), d1))
-        if self.use_nlspn_refine:
-            guide = self.gd_dec0(cat(self.gd_dec1(df), d1))
-            depth_map_2 = self.nlspn_refine_module(pred_init, guide, confidence, depth)
-        else:
-            depth_map_2 = pred_init
         depth_map_2, pred = Fh.fusion_head(depth_map_1, confidence_map_1, depth_map_2, confidence)
         nchw = Fh.to_nchw
         return dict(depth_map_1=nchw(depth_map_1), confidence_map_1=nchw(confidence_map_1), depth_map_2=nchw(depth_map_2),

@@ -70,6 +70,7 @@ class FlatAdam(torch.optim.Optimizer):
                 self._hyper_lr = lr
 
     def zero_grad(self, set_to_none=False):
+        Fh.join_side_stream()
         self.wait_grads()
         self.flat_grad.zero_()
         for p in self._params:        # autograd may have replaced a view when grads were None
@@ -88,6 +89,7 @@ class FlatAdam(torch.optim.Optimizer):
     def all_reduce_grads_async(self):
         """start sum-all-reduce of the flat gradient on a side stream (RCCL over xGMI); the
         1/world_size is folded into the Adam kernel.  No-op when not distributed."""
+        Fh.join_side_stream()             # weight gradients still in flight on the side stream
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         if self.flat_grad.is_cuda:
@@ -109,6 +111,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        Fh.join_side_stream()
         self.wait_grads()
         g = self.param_groups[0]
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
