@@ -429,8 +429,11 @@ class RDFCGAN:
         self.optimizer_G.all_reduce_grads_async()
         self.set_requires_grad([self.disc_A, self.disc_B], True)
         self.optimizer_D.zero_grad()
+        with self._net_stream_ctx():                  # the two discriminators are independent: D_B's step on the second stream
+            stats_DB = self.backward_D_B2A()
         loss_stats.update(self.backward_D_A2B())
-        loss_stats.update(self.backward_D_B2A())
+        self._join_net_stream(tuple(stats_DB.values()))
+        loss_stats.update(stats_DB)
         self.optimizer_D.all_reduce_grads_async()
         self.optimizer_G.step()
         self.optimizer_D.step()
