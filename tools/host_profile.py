@@ -19,4 +19,4 @@ torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
 for i in range(3): step(i)
 pr.disable(); torch.cuda.synchronize()
-s = io.StringIO(); ps = pstats.Stats(pr, stream=s).sort_stats('tottime'); ps.print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); ps = pstats.Stats(pr, stream=s).sort_stats('cumulative'); ps.print_stats(60); print(s.getvalue()[:9000])
