@@ -253,6 +253,7 @@ void launch_T(const WgradParams &p, const void *x, const void *dy, float *dw, hi
 
 int rdfc_try_wgrad9(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad9.hip
 int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad_glds.hip
+int rdfc_try_wgrad_gather_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad_gather_glds.hip
 int rdfc_try_wgrad_thin(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad_thin.hip
 
 extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream) {
@@ -270,6 +271,7 @@ extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const v
     static const bool w9 = getenv("RDFC_NO_WGRAD9") == nullptr;
     if (rdfc_try_wgrad_thin(d, x, dy, dw_packed, st)) {
     } else if (rdfc_try_wgrad_glds(d, x, dy, dw_packed, st)) {
+    } else if (rdfc_try_wgrad_gather_glds(d, x, dy, dw_packed, st)) {
     } else if (w9 && rdfc_try_wgrad9(d, x, dy, dw_packed, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, dy, dw_packed, st);
     else launch_T<float>(p, x, dy, dw_packed, st);

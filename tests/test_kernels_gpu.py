@@ -70,6 +70,14 @@ CONV_CASES = [
     (2, 17, 21, 128, 64, 3, 2, 1),
     (2, 10, 12, 192, 384, 1, 1, 0),
     (1, 19, 23, 64, 64, 4, 1, 1),
+    # gather-based LDS-DMA weight gradient (conv_wgrad_gather_glds.hip) needs rows of >= ~18 output pixels
+    (2, 30, 76, 64, 128, 3, 2, 1),
+    (2, 32, 128, 64, 128, 4, 2, 1),
+    (1, 20, 60, 128, 256, 4, 1, 1),
+    (2, 10, 64, 192, 128, 1, 1, 0),
+    (2, 20, 128, 64, 128, 1, 2, 0),
+    (1, 12, 200, 64, 128, 3, 2, 1),      # Wo = 100: the default dispatch takes this one
+    (1, 10, 104, 192, 128, 1, 1, 0),
     # thin-input MFMA kernel (conv_thin_in.hip): stride-2 4x4 stems, 128-channel heads' input gradient
     (4, 66, 70, 3, 64, 4, 2, 1),
     (4, 66, 70, 1, 64, 4, 2, 1),
