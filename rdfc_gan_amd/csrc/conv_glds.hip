@@ -395,7 +395,13 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
               d->act, d->slope, d->out_f32, 0, 0, stats != nullptr ? G : 0};
     p.tiles_x = cdiv(p.W, TC);
     if (Cout > 64) {
-        if (mode == 3 && stats == nullptr) {           // A/B switch: 8 waves on 128 co x (16x16) px, one workgroup per CU
+        // 8 waves on 128 co x (16x16) px, one workgroup per CU: 43 % fewer DMA instructions per MFMA (the weights of a tap
+        // serve twice the pixels).  Faster when its grid is one partial round or many rounds (512 ch @ 29x38, 192
+        // workgroups: 692 vs 634 TFLOP/s; 64->128 @ 228x304, 2280: 602 vs 559), slower when it ends in a short second round
+        // (256 ch @ 57x76, 320 workgroups on 256 CUs: 633 vs 688).  Choosing it by grid size gained nothing inside the
+        // multi-stream step (178 vs 181 pairs/s: a one-workgroup-per-CU kernel shares the chip worse), so it stays an A/B
+        // switch: RDFC_GLDS=3.
+        if (stats == nullptr && mode == 3) {
             p.tiles_y = cdiv(p.H, 16);
             return launch<128, 8>(p, in, w, bias, out, zero, stats, st);
         }
