@@ -183,7 +183,7 @@ def main():
     # Untimed extra step on ONE stream with the same events: in the timed steps a kernel shares the chip with the other
     # streams' kernels, so its duration there (what rocprofv3 of this command shows too) understates what it does alone.
     iso = []
-    if events and rank == 0:
+    if events:                          # on every rank: the step contains collectives
         if graphed:
             model.enable_graph(False)
         Fh.set_multi_stream(False)
