@@ -36,6 +36,13 @@ struct GParams {
 };
 
 constexpr int BK = 32, TC = 16, PW = TC + 2;
+// weight ring: WRING tap slots filled WRING-1 phases ahead.  RDFC_GLDS_DEEP: one more slot, and the fragments of phase p+1 are
+// read from LDS while phase p's MFMAs run (their data is complete one barrier earlier), so no MFMA waits on an LDS read
+#ifdef RDFC_GLDS_DEEP
+constexpr int WRING = 5;
+#else
+constexpr int WRING = 4;
+#endif
 
 __device__ inline int lay_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 2)) << 3); }
 
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
     constexpr int NR = (NPIECE + NT - 1) / NT;                 // patch DMA rounds per slab (3 / 6)
     constexpr int NWP = TCO * 4 / NT;                          // weight DMAs per thread and tap (2 / 1)
     constexpr int WSLOT = TCO * BK * 2;                        // bytes per weight slot
-    constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + 4 * WSLOT;
+    constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + WRING * WSLOT;
     static_assert(NR <= 6, "patch rounds must be issued at least three phases before the slab ends");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
         const int off = cc < ncc ? tap * p.Cin + cc * BK : 0;
 #pragma unroll
         for (int k = 0; k < NWP; ++k)
-            glds16((cc < ncc ? wsrc[k] : zero) + off * wmul[k], lds0 + OFF_W + (it & 3) * WSLOT + (k * NT + wave * 64) * 16);
+            glds16((cc < ncc ? wsrc[k] : zero) + off * wmul[k], lds0 + OFF_W + (it % WRING) * WSLOT + (k * NT + wave * 64) * 16);
     };
     auto issue_p = [&](int r, int cc) {                          // round r of slab cc -> patch buffer cc & 1
         const bool live = cc < ncc;
@@ -144,15 +151,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
 
     // byte address of (row, 16-byte chunk kg) in a swizzled 64-byte-row image: (row*64 + kg*16) ^ ((row & 4) << 3)
     const unsigned a_off = (unsigned)((arow << 6) | (kg << 4)) ^ (unsigned)((arow & 4) << 3);     // + i*1024: rows arow + 16 i share bit 2
-    auto compute = [&](int it, int cc, int tap) {
+    auto read_frags = [&](int it, int cc, int tap, bf16x8 (&a)[4], bf16x8 (&b)[4]) {
         const int kh = tap / 3, kw = tap - kh * 3;
         int shift = p.transposed ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
 #ifdef RDFC_GLDS_RECOMPUTE
         asm volatile("" : "+s"(shift));                          // keep the nine taps' B addresses out of registers (recomputed per phase)
 #endif
-        const unsigned char *Wt = smem + OFF_W + (it & 3) * WSLOT + a_off;
+        const unsigned char *Wt = smem + OFF_W + (it % WRING) * WSLOT + a_off;
         const unsigned char *Pt = smem + (cc & 1) * PATCH_BYTES;
-        bf16x8 a[4], b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
 #pragma unroll
@@ -160,45 +166,57 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
             const int row = bpp[j] + shift;
             b[j] = *reinterpret_cast<const bf16x8 *>(Pt + (((row << 6) | (kg << 4)) ^ ((row & 4) << 3)));
         }
-#ifdef RDFC_GLDS_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
+    };
+    auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-#ifdef RDFC_GLDS_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
+    };
+    auto compute = [&](int it, int cc, int tap) {
+        bf16x8 a[4], b[4];
+        read_frags(it, cc, tap, a, b);
+        mma(a, b);
     };
 
-    // ---- prologue: slab 0 patch, weights of phases 0..2 -------------------------------------------------------------
+    // ---- prologue: slab 0 patch, weights of the first WRING-1 phases -------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < NR; ++r) issue_p(r, 0);
-    issue_w(0);
-    issue_w(1);
-    issue_w(2);
+#pragma unroll
+    for (int h = 0; h < WRING - 1; ++h) issue_w(h);
 
-    // DMA issue costs the issuing wave 60-185 cycles per instruction (MI355X_MICROARCH.md): RDFC_GLDS_DMA_LAST puts it
-    // behind the phase's MFMAs (queued matrix work drains meanwhile) instead of in front of the fragment reads
-#ifdef RDFC_GLDS_DMA_LAST
-#define RDFC_GLDS_ISSUE_FIRST(...)
-#define RDFC_GLDS_ISSUE_LAST(...) __VA_ARGS__
-#else
-#define RDFC_GLDS_ISSUE_FIRST(...) __VA_ARGS__
-#define RDFC_GLDS_ISSUE_LAST(...)
-#endif
     // phase (cc, TAP): DMAs still allowed in flight at its wait = those issued in the two previous phases
+#ifndef RDFC_GLDS_DEEP
 #define RDFC_GLDS_PHASE(TAP)                                                                                   \
     {                                                                                                          \
         constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
         wait_vm<ALLOW>();                                                                                      \
         __builtin_amdgcn_s_barrier();                                                                          \
-        RDFC_GLDS_ISSUE_FIRST(issue_w(it0 + TAP + 3); if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);)      \
+        issue_w(it0 + TAP + 3);                                                                                \
+        if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
         compute(it0 + TAP, cc, TAP);                                                                           \
-        RDFC_GLDS_ISSUE_LAST(__builtin_amdgcn_sched_barrier(0); issue_w(it0 + TAP + 3);                        \
-                             if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);)                               \
     }
+#else
+    // deep variant: the wait of phase p retires the DMAs of phase p+1 (issued four phases ahead), the barrier publishes them,
+    // and phase p+1's fragments are read while phase p's MFMAs (operands read one phase ago) execute
+    bf16x8 fa[4], fb[4];
+    wait_vm<(WRING - 2) * NWP>();                               // patch 0 and weights 0 are in
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0, fa, fb);
+#define RDFC_GLDS_PHASE(TAP)                                                                                   \
+    {                                                                                                          \
+        constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
+        wait_vm<ALLOW>();                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        issue_w(it0 + TAP + 4);                                                                                \
+        if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
+        bf16x8 na[4], nb[4];                                                                                   \
+        read_frags(it0 + TAP + 1, TAP == 8 ? cc + 1 : cc, (TAP + 1) % 9, na, nb);                              \
+        mma(fa, fb);                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) { fa[q] = na[q]; fb[q] = nb[q]; }                        \
+    }
+#endif
     for (int cc = 0; cc < ncc; ++cc) {
         const int it0 = cc * 9;
         RDFC_GLDS_PHASE(0)
@@ -347,7 +365,7 @@ template <int TCO, int NW>
 int launch(const GParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, float *stats, hipStream_t st) {
     constexpr int NT = NW * 64, TR = 4 * NW / (TCO / 64);
     constexpr int NPIECE = (TR + 2) * PW * 4, PATCH = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;
-    constexpr int SMEM = 2 * PATCH + 4 * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
+    constexpr int SMEM = 2 * PATCH + WRING * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;

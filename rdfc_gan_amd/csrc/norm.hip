@@ -362,8 +362,9 @@ __global__ __launch_bounds__(FNT) void sum_finalize_kernel(int G, int C, int K, 
     if (threadIdx.x < 32 && c < C) {
         sums[((size_t)g * K + k) * C + c] = (float)s;
         // optional in-place accumulation of sum 0 / sum 1 (d beta / d gamma of an affine norm with one group)
-        if (k == 0 && acc0 != nullptr) acc0[c] += (float)s;
-        if (k == 1 && acc1 != nullptr) acc1[c] += (float)s;
+        // (atomic: the same parameter's two uses per step run their backward on different streams)
+        if (k == 0 && acc0 != nullptr) atomicAdd(&acc0[c], (float)s);
+        if (k == 1 && acc1 != nullptr) atomicAdd(&acc1[c], (float)s);
     }
 }
 
@@ -401,8 +402,8 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const
                 sums_out[(cx.g * 3 + 1) * m.C + c] = S2;
                 sums_out[(cx.g * 3 + 2) * m.C + c] = (float)sums64[((size_t)cx.g * 3 + 2) * m.C + c];
             }
-            if (dbeta_acc != nullptr) dbeta_acc[c] += S1;
-            if (dgamma_acc != nullptr) dgamma_acc[c] += S2;
+            if (dbeta_acc != nullptr) atomicAdd(&dbeta_acc[c], S1);
+            if (dgamma_acc != nullptr) atomicAdd(&dgamma_acc[c], S2);
         }
     }
     const float ns = neg_slope_of(a);
