@@ -70,7 +70,8 @@ class FlatAdam(torch.optim.Optimizer):
                 self._hyper_lr = lr
 
     def zero_grad(self, set_to_none=False):
-        Fh.join_side_stream()
+        # (no join of the helper streams here: step() / the all-reduce joined them before they read the gradients, and the
+        # other optimizer's weight gradients may keep running under this one's backward)
         self.wait_grads()
         self.flat_grad.zero_()
         for p in self._params:        # autograd may have replaced a view when grads were None
@@ -89,9 +90,9 @@ class FlatAdam(torch.optim.Optimizer):
     def all_reduce_grads_async(self):
         """start sum-all-reduce of the flat gradient on a side stream (RCCL over xGMI); the
         1/world_size is folded into the Adam kernel.  No-op when not distributed."""
-        Fh.join_side_stream()             # weight gradients still in flight on the side stream
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
+        Fh.join_side_stream()             # weight gradients still in flight on the side stream
         if self.flat_grad.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
