@@ -45,7 +45,40 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.rdfc_last_error.restype = C.c_char_p
         _lib.rdfc_last_kernel.restype = C.c_char_p
+        _declare_argtypes(_lib)
     return _lib
+
+
+def _declare_argtypes(lib_):
+    """argtypes for every `int rdfc_*(...)` prototype of include/rdfc_hip.h, parsed from the header that ships next to the
+    library: with them ctypes converts plain Python ints / floats itself (no c_void_p / c_float objects per argument,
+    ~1 800 launches x ~15 arguments per train step) and rejects a wrong argument count."""
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'rdfc_hip.h')
+    if not os.path.exists(hdr):
+        return
+    text = re.sub(r'/\*.*?\*/', ' ', open(hdr).read(), flags=re.S)
+    for m in re.finditer(r'\bint\s+(rdfc_\w+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        if not hasattr(lib_, name):
+            continue
+        types = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = ' '.join(a.split())
+                if '*' in a:
+                    types.append(C.c_void_p)
+                elif re.match(r'^(const )?float\b', a):
+                    types.append(C.c_float)
+                elif re.match(r'^(const )?double\b', a):
+                    types.append(C.c_double)
+                elif re.match(r'^(const )?size_t\b', a):
+                    types.append(C.c_size_t)
+                else:
+                    types.append(C.c_int)
+        fn = getattr(lib_, name)
+        fn.argtypes = types
+        fn.restype = C.c_int
 
 
 def _chk(rc, name):
@@ -62,14 +95,14 @@ def _st():
     global _dev_index
     if _dev_index is None:
         _dev_index = torch.cuda.current_device()
-    return C.c_void_p(torch._C._cuda_getCurrentRawStream(_dev_index))
+    return torch._C._cuda_getCurrentRawStream(_dev_index)
 
 
 def _p(t):
     if t is None:
-        return C.c_void_p(0)
+        return None
     assert t.is_cuda, 'HIP kernels need device tensors'
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def dt(t):
@@ -91,7 +124,7 @@ def ld(t):
 
 
 def _f(x):
-    return C.c_float(float(x))
+    return float(x)
 
 
 # --------------------------------------------------------------------------- convolution
