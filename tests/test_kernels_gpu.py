@@ -395,12 +395,14 @@ def test_fusion_head_losses_adam_pepper():
 
 
 MD_CASES = [dict(B=2, C=1, H=9, W=11, Co=1, k=3, s=1, p=1, g=1, dg=1),
+            dict(B=2, C=1, H=21, W=150, Co=1, k=3, s=1, p=1, g=1, dg=1),      # several 8x64 tiles of the LDS-window backward
+            dict(B=1, C=1, H=19, W=70, Co=1, k=1, s=1, p=0, g=1, dg=1),
             dict(B=2, C=1, H=9, W=11, Co=1, k=1, s=1, p=0, g=1, dg=1),
             dict(B=2, C=4, H=7, W=9, Co=6, k=3, s=1, p=1, g=2, dg=2),
             dict(B=1, C=4, H=8, W=8, Co=4, k=3, s=2, p=1, g=1, dg=1)]
 
 
-@pytest.mark.parametrize('c', MD_CASES, ids=lambda c: f"C{c['C']}k{c['k']}s{c['s']}g{c['g']}")
+@pytest.mark.parametrize('c', MD_CASES, ids=lambda c: f"C{c['C']}k{c['k']}s{c['s']}g{c['g']}W{c['W']}")
 def test_mdconv_against_oracle(c):
     """rdfc_mdconv_* against the C oracle (which restates upstream's CUDA kernels)."""
     from oracle import mdconv as om
