@@ -155,9 +155,15 @@ class RDFGenerator(nn.Module):
             d = [None, d1]
             for idx in range(2, 7):
                 d.append(D.forward_encoder_layer(d[-1], idx))
-            dfs = [d[6]]                          # depth-decoder features, one per fusion level
+            dfs, ready = [d[6]], []               # depth-decoder features, one per fusion level (+ an event each)
+            if two:
+                ready.append(torch.cuda.Event())
+                ready[-1].record(side)
             for lvl in (5, 4, 3, 2):
                 dfs.append(cat(D.forward_decoder_layer(dfs[-1], layer_idx=lvl), d[lvl]))
+                if two:
+                    ready.append(torch.cuda.Event())
+                    ready[-1].record(side)
             df = dfs[-1]
             pred_init = self._head(self.id_dec0, cat(self.id_dec1(df), d1), 'tanh')
             confidence = self.cf_dec0(cat(self.cf_dec1(df), d1))
@@ -171,14 +177,17 @@ class RDFGenerator(nn.Module):
         for idx in range(2, 7):
             r.append(R.forward_encoder_layer(r[-1], idx))
         if two:
-            main.wait_stream(side)                # (coarse: the whole depth branch; its features feed every fusion level)
             for t in dfs + [depth_map_2, confidence]:
                 t.record_stream(main)             # allocated on the side stream, read on the main one
         rf = r[6]
         for k, (lvl, fuse) in enumerate(zip((5, 4, 3, 2), (self.fuse_layer1, self.fuse_layer2, self.fuse_layer3, self.fuse_layer4))):
+            if two:
+                main.wait_event(ready[k])         # the RGB decoder trails the depth decoder by one level
             rf = cat(R.forward_decoder_layer(fuse(rf, dfs[k]), layer_idx=lvl), r[lvl])
         depth_map_1 = self._head(self.rgb_pred_dec0, cat(self.rgb_pred_dec1(rf), r1), 'tanh')
         confidence_map_1 = self.rgb_conf_dec0(cat(self.rgb_conf_dec1(rf), r1))
+        if two:
+            main.wait_stream(side)                # depth heads (and NLSPN) done
         depth_map_2, pred = Fh.fusion_head(depth_map_1, confidence_map_1, depth_map_2, confidence)
         nchw = Fh.to_nchw
         return dict(depth_map_1=nchw(depth_map_1), confidence_map_1=nchw(confidence_map_1), depth_map_2=nchw(depth_map_2),
