@@ -135,12 +135,17 @@ def _wgrad(d, a, b, weight, O, I, k, scale):
     no zero-fill, no unpack, no autograd add."""
     g = weight.grad
     if scale == 1.0 and g is not None and g.dtype == torch.float32 and hip.is_ohwi(g) and not g.requires_grad:
-        if _WGRAD_STREAM and _multi_stream and a.is_cuda:
+        if _WGRAD_STREAM and _multi_stream and a.is_cuda and hip.PROFILE is None:
             stream, keep = _side_stream(a.device)
             stream.wait_stream(torch.cuda.current_stream(a.device))
-            with torch.cuda.stream(stream):
-                hip.conv_wgrad(d, a, b, into=g)
+            hip.conv_wgrad(d, a, b, into=g, stream=stream.cuda_stream)      # launched straight onto the side stream
             keep.append((a, b))         # their memory must not be recycled before the join
+        elif _WGRAD_STREAM and _multi_stream and a.is_cuda:
+            stream, keep = _side_stream(a.device)
+            stream.wait_stream(torch.cuda.current_stream(a.device))
+            with torch.cuda.stream(stream):                                 # (per-kernel events record on the current stream)
+                hip.conv_wgrad(d, a, b, into=g)
+            keep.append((a, b))
         else:
             hip.conv_wgrad(d, a, b, into=g)
         return None
@@ -266,21 +271,22 @@ class _ConvBlock(torch.autograd.Function):
         wf, wb = _packed(weight, x.dtype, spec.wscale)
         g_x = g_w = None
         if not spec.transposed:
-            d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, ldx=Cin, ldy=hip.ld(dy), dtype=hip.dt(x))
             if ctx.needs_input_grad[0]:
+                d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, ldx=Cin, ldy=hip.ld(dy), dtype=hip.dt(x))
                 g_x = torch.empty(N, H, W, Cin, dtype=x.dtype, device=x.device)
                 hip.conv_dgrad(d, dy, wb, None, g_x)
             if ctx.needs_input_grad[1]:
-                d.ldx = hip.ld(x)
+                d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, ldx=hip.ld(x), ldy=hip.ld(dy), dtype=hip.dt(x))
                 g_w = _wgrad(d, x, dy, weight, Cout, Cin, spec.k, spec.wscale)
         else:
-            d = hip.conv_desc((N, Ho, Wo, Cout), Cin, spec.k, spec.stride, spec.pad, ldx=hip.ld(dy), ldy=Cin,
-                              dtype=hip.dt(x), out_hw=(H, W))
             if ctx.needs_input_grad[0]:
+                d = hip.conv_desc((N, Ho, Wo, Cout), Cin, spec.k, spec.stride, spec.pad, ldx=hip.ld(dy), ldy=Cin,
+                                  dtype=hip.dt(x), out_hw=(H, W))
                 g_x = torch.empty(N, H, W, Cin, dtype=x.dtype, device=x.device)
                 hip.conv_forward(d, dy, wf, None, g_x)
             if ctx.needs_input_grad[1]:
-                d.ldy = hip.ld(x)
+                d = hip.conv_desc((N, Ho, Wo, Cout), Cin, spec.k, spec.stride, spec.pad, ldx=hip.ld(dy), ldy=hip.ld(x),
+                                  dtype=hip.dt(x), out_hw=(H, W))
                 g_w = _wgrad(d, dy, x, weight, Cin, Cout, spec.k, spec.wscale)     # [O = Cin][T][I = Cout]
         return g_x, g_w, g_bias, g_gamma, g_beta, g_res, g_prelu, None, None, None, None
 
@@ -321,7 +327,7 @@ class _WAdaIN(torch.autograd.Function):
         d = hip.conv_desc(style.shape, 2 * C, 1, 1, 0, ldx=Cs, ldy=2 * C, dtype=hip.dt(x))
         dstyle = torch.empty(N, H, W, Cs, dtype=x.dtype, device=x.device)
         hip.conv_dgrad(d, dgb, wb, None, dstyle)
-        d.ldx = hip.ld(style)
+        d = hip.conv_desc(style.shape, 2 * C, 1, 1, 0, ldx=hip.ld(style), ldy=2 * C, dtype=hip.dt(x))
         dw = hip.conv_wgrad(d, style, dgb)
         g_w = hip.unpack_wgrad(dw, 2 * C, Cs, 1, 1, ctx.scale).view(2 * C, Cs)
         return dx, dstyle, g_w, hip.channel_sum(dgb)

@@ -115,6 +115,8 @@ def dt(t):
 
 def ld(t):
     """pixel stride of a pixel-major map [N,H,W,C]"""
+    if t.is_contiguous():
+        return t.shape[3]
     N, H, W, Cc = t.shape
     l = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else (t.stride(0) if N > 1 else Cc))
     assert t.stride(3) == 1 or Cc == 1, 'channel dim must be contiguous'
@@ -128,8 +130,23 @@ def _f(x):
 
 
 # --------------------------------------------------------------------------- convolution
+_desc_cache = {}
+
+
 def conv_desc(x_shape, Co, k, stride, pad, dil=1, *, ldx, ldy, dtype, act='none', slope=0.0, out_f32=False,
               out_hw=None):
+    """descriptor of the forward convolution; cached (a train step builds the same ~200 descriptors again and again) --
+    treat the returned object as read-only"""
+    key = (tuple(x_shape), Co, k, stride, pad, dil, ldx, ldy, dtype, act, slope, out_f32, out_hw)
+    d = _desc_cache.get(key)
+    if d is None:
+        d = _desc_cache[key] = _conv_desc(x_shape, Co, k, stride, pad, dil, ldx=ldx, ldy=ldy, dtype=dtype, act=act, slope=slope,
+                                          out_f32=out_f32, out_hw=out_hw)
+    return d
+
+
+def _conv_desc(x_shape, Co, k, stride, pad, dil=1, *, ldx, ldy, dtype, act='none', slope=0.0, out_f32=False,
+               out_hw=None):
     N, Hi, Wi, Ci = x_shape
     kh, kw = (k, k) if isinstance(k, int) else k
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
@@ -236,11 +253,15 @@ def conv_dgrad(d, dy, w_bwd, bias, dx):
     return dx
 
 
-def conv_wgrad(d, x, dy, into=None):
-    """into: f32 buffer [Co][KH*KW][Ci] to ACCUMULATE into (e.g. a channels-last .grad); default a fresh zeroed one"""
+def conv_wgrad(d, x, dy, into=None, stream=None):
+    """into: f32 buffer [Co][KH*KW][Ci] to ACCUMULATE into (e.g. a channels-last .grad); default a fresh zeroed one.
+    stream: raw HIP stream handle to launch on (default: the current stream)"""
     dw = into if into is not None else torch.zeros(d.Co, d.KH * d.KW, d.Ci, dtype=torch.float32, device=x.device)
+    if stream is not None and PROFILE is None:
+        _chk(lib().rdfc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), stream), 'rdfc_conv2d_wgrad')
+        return dw
     with _Timed('wgrad_kernel (conv weight grad)', d):
-        _chk(lib().rdfc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _st()), 'rdfc_conv2d_wgrad')
+        _chk(lib().rdfc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _st() if stream is None else stream), 'rdfc_conv2d_wgrad')
     return dw
 
 

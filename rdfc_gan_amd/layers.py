@@ -45,8 +45,26 @@ def _count_batch(norm, k):
     d['_rdfc_pending_batches'] += k
 
 
+_spec_cache = {}
+
+
 def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
     """conv (nn.Conv2d | nn.ConvTranspose2d) [+ norm (BatchNorm2d | InstanceNorm2d)] [+ res] [+ act module]"""
+    # the static description of the block is the same on every call of the same modules: cache it (a train step runs
+    # ~180 blocks, each used to rebuild its ConvSpec from a dozen attribute lookups)
+    key = (id(conv), id(norm), id(act), out_f32, BN_STAT_REPEAT, getattr(act, 'negative_slope', None))
+    hit = _spec_cache.get(key)
+    if hit is not None and hit[0] is conv and hit[1] is norm and hit[2] is act:
+        _c, _n, _a, spec, nname, prelu = hit
+        gamma = beta = rm = rv = None
+        training = True
+        if nname == 'bn':
+            gamma, beta, rm, rv = norm.weight, norm.bias, norm.running_mean, norm.running_var
+            training = norm.training
+            if training and norm.num_batches_tracked is not None:
+                _count_batch(norm, BN_STAT_REPEAT)
+        return Fh.conv_block(x, conv.weight, conv.bias, gamma, beta, res, prelu, spec=spec, training=training,
+                             run_mean=rm, run_var=rv)
     transposed = isinstance(conv, nn.ConvTranspose2d)
     aname, slope, prelu = _act_of(act)
     if norm is None:
@@ -71,6 +89,7 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
         training = norm.training
         if training and norm.num_batches_tracked is not None:
             _count_batch(norm, BN_STAT_REPEAT)
+    _spec_cache[key] = (conv, norm, act, spec, nname, prelu)
     return Fh.conv_block(x, conv.weight, conv.bias, gamma, beta, res, prelu, spec=spec, training=training,
                          run_mean=rm, run_var=rv)
 
