@@ -186,7 +186,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
     for (int h = 0; h < WRING - 1; ++h) issue_w(h);
 
     // phase (cc, TAP): DMAs still allowed in flight at its wait = those issued in the two previous phases
-#ifndef RDFC_GLDS_DEEP
+#if defined(RDFC_GLDS_EXP_NODMA)      /* timing experiment only (wrong results): no DMA in the main loop */
+#define RDFC_GLDS_PHASE(TAP)                                                                                   \
+    {                                                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        compute(it0 + TAP, cc, TAP);                                                                           \
+    }
+#elif defined(RDFC_GLDS_EXP_NOBARRIER)  /* timing experiment only (races): DMA but no barrier */
+#define RDFC_GLDS_PHASE(TAP)                                                                                   \
+    {                                                                                                          \
+        constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
+        wait_vm<ALLOW>();                                                                                      \
+        issue_w(it0 + TAP + 3);                                                                                \
+        if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
+        compute(it0 + TAP, cc, TAP);                                                                           \
+    }
+#elif !defined(RDFC_GLDS_DEEP)
 #define RDFC_GLDS_PHASE(TAP)                                                                                   \
     {                                                                                                          \
         constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
