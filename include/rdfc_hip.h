@@ -243,6 +243,14 @@ int rdfc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_a
 int rdfc_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, const float *hyper,
                        float beta1, float beta2, float eps, float grad_scale, void *stream);
 
+/* Eval path: per-image RMSE, MAE, iRMSE, iMAE, REL, delta^1, delta^2, delta^3 of
+ * RDFGANMetric.evaluate_all (lib/metrics/rdf_gan_metric.py:59-151) -> out[N][8] (f32), computed from the NORMALISED
+ * maps gt_norm / pred_norm [N][HW] with the evaluator's de-normalisation x * std + mean folded in
+ * (lib/evaluator/evaluator.py:28-29); valid pixels: gt > t_valid (and evaluate_mask != 0 when given, u8 [N][HW]).
+ * The caller averages over images (rdf_gan_metric.py:139-140). */
+int rdfc_depth_metrics(const float *gt_norm, const float *pred_norm, const uint8_t *evaluate_mask, int N, int HW, float std,
+                       float mean, float t_valid, float *out, void *stream);
+
 /* addPepperNoise (helper.py:384-402) given the host-drawn mask (0 keep, 1 -> +1, 2 -> -1), in place. */
 int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, int HW, void *stream);
 

@@ -280,6 +280,67 @@ __global__ void adam_dev_kernel(float *__restrict__ p, const float *__restrict__
     }
 }
 
+// ---- evaluation metrics (eval path): one workgroup per image, one pass over (gt, pred[, mask]) ------------------------------
+// per image: RMSE, MAE, iRMSE, iMAE, REL, delta^1..3 over the pixels with gt > t_valid (& evaluate_mask); inputs are the
+// normalised maps, de-normalised on the fly (x * std + mean).  f64 accumulation, fixed order -> reproducible.
+constexpr int MNT = 1024;
+__global__ __launch_bounds__(MNT) void depth_metrics_kernel(const float *__restrict__ gt_n, const float *__restrict__ pd_n,
+                                                            const uint8_t *__restrict__ emask, int HW, float stdv, float meanv,
+                                                            float t_valid, float *__restrict__ out) {
+// separately rounded multiply and add like the reference's x * std + mean: a contracted fma changes a prediction next to zero
+// (x ~ -1) by many ulps and 1/pred with it, and one such pixel can carry most of an image's iRMSE
+#pragma clang fp contract(off)
+    __shared__ double red[9][MNT / 64];
+    const int n = blockIdx.x;
+    const float *g = gt_n + (size_t)n * HW, *p = pd_n + (size_t)n * HW;
+    const uint8_t *m = emask ? emask + (size_t)n * HW : nullptr;
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    const float t1 = 1.25f, t2 = (float)(1.25 * 1.25), t3 = (float)(1.25 * 1.25 * 1.25);
+    for (int i = threadIdx.x; i < HW; i += MNT) {
+        const float gt = g[i] * stdv + meanv, pd = p[i] * stdv + meanv;
+        if (!(gt > t_valid) || (m && !m[i])) continue;
+        const float pi = pd <= t_valid ? 0.f : 1.f / (pd + 1e-8f), gi = 1.f / (gt + 1e-8f);
+        const float d = pd - gt, di = pi - gi;
+        const float ratio = fmaxf(gt / (pd + 1e-8f), pd / (gt + 1e-8f));
+        acc[0] += 1.0;
+        acc[1] += (double)(d * d);
+        acc[2] += (double)fabsf(d);
+        acc[3] += (double)(di * di);
+        acc[4] += (double)fabsf(di);
+        acc[5] += (double)(fabsf(d) / (gt + 1e-8f));
+        acc[6] += ratio < t1 ? 1.0 : 0.0;
+        acc[7] += ratio < t2 ? 1.0 : 0.0;
+        acc[8] += ratio < t3 ? 1.0 : 0.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s[9];
+        for (int k = 0; k < 9; ++k) {
+            s[k] = 0.0;
+            for (int w = 0; w < MNT / 64; ++w) s[k] += red[k][w];
+        }
+        const double nv = s[0] + 1e-8;
+        float *o = out + (size_t)n * 8;
+        o[0] = (float)sqrt(s[1] / nv);
+        o[1] = (float)(s[2] / nv);
+        o[2] = (float)sqrt(s[3] / nv);
+        o[3] = (float)(s[4] / nv);
+        o[4] = (float)(s[5] / nv);
+        o[5] = (float)(s[6] / nv);
+        o[6] = (float)(s[7] / nv);
+        o[7] = (float)(s[8] / nv);
+    }
+}
+
 __global__ void pepper_kernel(float *img, const uint8_t *mask, int C, int HW, size_t total) {
     GRID_STRIDE(i, total) {
         const size_t n = i / ((size_t)C * HW);
@@ -422,6 +483,16 @@ extern "C" int rdfc_adam_step_dev(float *param, const float *grad, float *m, flo
     hipLaunchKernelGGL(adam_dev_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, m, v, n, hyper, b1, b2, eps,
                        gscale);
     RDFC_LAUNCH_CHECK("rdfc_adam_step_dev");
+    return 0;
+}
+
+extern "C" int rdfc_depth_metrics(const float *gt_norm, const float *pred_norm, const uint8_t *evaluate_mask, int N, int HW, float std,
+                                  float mean, float t_valid, float *out, void *stream) {
+    RDFC_REQUIRE(gt_norm != nullptr && pred_norm != nullptr && out != nullptr, "rdfc_depth_metrics: null pointer");
+    RDFC_REQUIRE(N > 0 && HW > 0, "rdfc_depth_metrics: empty input");
+    hipLaunchKernelGGL(depth_metrics_kernel, dim3(N), dim3(MNT), 0, (hipStream_t)stream, gt_norm, pred_norm, evaluate_mask, HW, std,
+                       mean, t_valid, out);
+    RDFC_LAUNCH_CHECK("rdfc_depth_metrics");
     return 0;
 }
 

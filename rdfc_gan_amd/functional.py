@@ -70,6 +70,8 @@ def _accumulable(g):
 # and the MFMA-bound split-K GEMM overlaps the HBM-bound normalisation kernels of the layers below.  join_side_stream()
 # brings the streams back together; FlatAdam calls it before it touches the gradients.  RDFC_WGRAD_STREAM=0 disables it.
 _WGRAD_STREAM = os.environ.get('RDFC_WGRAD_STREAM', '1') != '0'
+_PRIO_HELPER = int(os.environ.get('RDFC_PRIO_HELPER', '0'))     # HIP stream priorities (lower = more urgent) for experiments
+_PRIO_WGRAD = int(os.environ.get('RDFC_PRIO_WGRAD', '0'))
 _multi_stream = True        # False while a step is captured into / replayed from HIP graphs (single-stream capture)
 
 
@@ -88,7 +90,7 @@ _side = {}          # device -> [stream, list of tensors the pending launches st
 def _side_stream(device):
     s = _side.get(device)
     if s is None:
-        s = _side[device] = [torch.cuda.Stream(device=device), []]
+        s = _side[device] = [torch.cuda.Stream(device=device, priority=_PRIO_WGRAD), []]
     return s
 
 
@@ -99,7 +101,7 @@ def branch_stream(device):
     """second compute stream for an independent branch of a network (RDFGenerator's depth branch)"""
     s = _branch.get(device)
     if s is None:
-        s = _branch[device] = torch.cuda.Stream(device=device)
+        s = _branch[device] = torch.cuda.Stream(device=device, priority=_PRIO_HELPER)
     return s
 
 
@@ -110,7 +112,7 @@ def net_stream(device):
     """third compute stream: the half of the train step that does not depend on the other (RDFCGAN: the B->A chain)"""
     s = _net.get(device)
     if s is None:
-        s = _net[device] = torch.cuda.Stream(device=device)
+        s = _net[device] = torch.cuda.Stream(device=device, priority=_PRIO_HELPER)
     return s
 
 

@@ -510,6 +510,21 @@ def adam_step_dev(param, grad, m, v, hyper, b1, b2, eps, grad_scale=1.0):
                                   _f(eps), _f(grad_scale), _st()), 'rdfc_adam_step_dev')
 
 
+def depth_metrics(gt_norm, pred_norm, evaluate_mask=None, std=5.0, mean=5.0, t_valid=1e-4):
+    """normalised (N,1,H,W) | (N,H,W) f32 maps -> per-image metrics [N,8] (RMSE, MAE, iRMSE, iMAE, REL, d1, d2, d3)"""
+    g, p_ = gt_norm.contiguous().float(), pred_norm.contiguous().float()
+    N = g.shape[0]
+    HW = g.numel() // N
+    assert p_.numel() == g.numel()
+    m = None
+    if evaluate_mask is not None:
+        m = evaluate_mask.contiguous().to(torch.uint8)
+        assert m.numel() == g.numel()
+    out = torch.empty(N, 8, dtype=torch.float32, device=g.device)
+    _chk(lib().rdfc_depth_metrics(_p(g), _p(p_), _p(m), N, HW, _f(std), _f(mean), _f(t_valid), _p(out), _st()), 'rdfc_depth_metrics')
+    return out
+
+
 def apply_pepper(img, mask_u8):
     N, Cc, H, W = img.shape
     _chk(lib().rdfc_apply_pepper(_p(img), _p(mask_u8), N, Cc, H * W, _st()), 'rdfc_apply_pepper')

@@ -90,3 +90,16 @@ def noise_driven(net_key, param_key):
     updates, upstream included -- their trajectories are not comparable between implementations
     (and they cannot influence any output)."""
     return net_key == 'G_B2A' and param_key.endswith('.bias') and param_key != 'model.23.bias'
+
+
+def metric_case(B=3, H=40, W=52, seed=77):
+    """normalised prediction / ground truth in [-1, 1] as the evaluator sees them (evaluator.py:17-46 de-normalises with
+    std = mean = 5), with invalid ground-truth pixels (0 m -> -1 after normalisation) and an evaluate_mask"""
+    g = torch.Generator().manual_seed(seed)
+    gt_m = (torch.rand(B, 1, H, W, generator=g) * 9.0 + 0.7)
+    hole = torch.rand(B, 1, H, W, generator=g) < 0.2
+    gt_m[hole] = 0.0
+    pred_m = (gt_m + torch.randn(B, 1, H, W, generator=g) * 0.4).clamp_min(0.0)
+    pred_m[torch.rand(B, 1, H, W, generator=g) < 0.05] = 0.0        # predictions at / below t_valid exercise the inverse-depth rule
+    ev = torch.rand(B, 1, H, W, generator=g) < 0.9
+    return (gt_m - 5.0) / 5.0, (pred_m - 5.0) / 5.0, ev

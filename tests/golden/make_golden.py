@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_harness as rh                                   # noqa: E402
 from detweights import det_state_dict, det_tensor          # noqa: E402
-from cases import NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP   # noqa: E402
+from cases import NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP, metric_case   # noqa: E402
 
 
 def save(name, **arrs):
@@ -185,6 +185,28 @@ def step_trace(nsteps=2):
     save('step_trace', **res)
 
 
+def metric():
+    """RDFGANMetric.evaluate_all (lib/metrics/rdf_gan_metric.py:59-151) on results built the way Eval.inference builds them
+    (lib/evaluator/evaluator.py:17-46: x * std + mean with std = mean = 5, squeeze, one dict per image)."""
+    rh.install()
+    from lib.metrics.rdf_gan_metric import RDFGANMetric
+    gt_n, pd_n, ev = metric_case()
+    std = mean = 5.0
+    real, fake = gt_n * std + mean, pd_n * std + mean
+    plain = [dict(gt=real[k].squeeze(), pd=fake[k].squeeze()) for k in range(len(real))]
+    masked = [dict(gt=real[k].squeeze(), pd=fake[k].squeeze(), evaluate_mask=ev[k].squeeze()) for k in range(len(real))]
+    m = RDFGANMetric()
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = m.evaluate_all(plain)
+        b = m.evaluate_all(masked)
+        per_image = [m.evaluate_all([r]) for r in masked]
+    names = m.metric_name
+    save('metric', names=np.array(names), plain=np.array([a[n] for n in names], dtype=np.float64),
+         masked=np.array([b[n] for n in names], dtype=np.float64),
+         per_image=np.array([[r[n] for n in names] for r in per_image], dtype=np.float64))
+
+
 JOBS = {
     'g_a2b_small': lambda: g_a2b(False, 2, 60, 76, 'g_a2b_small'),
     'g_a2b_nlspn_small': lambda: g_a2b(True, 2, 60, 76, 'g_a2b_nlspn_small'),
@@ -195,6 +217,7 @@ JOBS = {
     'wadain': wadain,
     'losses': losses,
     'step_trace': step_trace,
+    'metric': metric,
 }
 
 if __name__ == '__main__':

@@ -424,3 +424,27 @@ def test_mdconv_against_oracle(c):
     gots = h.mdconv_backward(*dv, go.to(DEV), (s, s), (p, p), (1, 1), c['g'], c['dg'])
     for name, a, r in zip(('input', 'offset', 'mask', 'weight', 'bias'), gots, refs):
         assert rel_err(a, r) < 2e-5, name
+
+
+def test_depth_metrics_against_oracle_and_golden(golden):
+    """rdfc_depth_metrics / rdfc_gan_amd.metrics.RDFGANMetric against the CPU oracle and the reference's own numbers"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    from cases import metric_case
+    from oracle import metrics as om
+    from rdfc_gan_amd.metrics import RDFGANMetric
+    g = golden('metric')
+    gt_n, pd_n, ev = metric_case()
+    m = RDFGANMetric()
+    per = m.evaluate_normalised(gt_n.to(DEV), pd_n.to(DEV), ev.to(DEV)).double().cpu().numpy()
+    np.testing.assert_allclose(per, g['per_image'], rtol=2e-5, atol=1e-6)
+    real, fake = om.denormalise(gt_n.numpy()), om.denormalise(pd_n.numpy())
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        plain = m.evaluate_all([dict(gt=real[k].squeeze(), pd=fake[k].squeeze()) for k in range(len(real))])
+    np.testing.assert_allclose([plain[n] for n in m.metric_name], g['plain'], rtol=2e-5, atol=1e-6)
+    # full NYUv2-sized batch: HIP against the oracle
+    gt2, pd2, ev2 = metric_case(B=8, H=228, W=304, seed=5)
+    got = m.evaluate_normalised(gt2.to(DEV), pd2.to(DEV), None).double().cpu().numpy()
+    ref = np.stack([om.image_metrics(om.denormalise(gt2[k].numpy()), om.denormalise(pd2[k].numpy()), acc=np.float64) for k in range(8)])
+    np.testing.assert_allclose(got, ref, rtol=5e-5, atol=1e-6)

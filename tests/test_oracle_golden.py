@@ -178,3 +178,18 @@ def test_step_trace(golden):
             got = np.array([float(sd[k].double().norm()) for k in g[f'sd_names.{key}']])
             np.testing.assert_allclose(got[keep], g[f'sd_summary.{key}.{it}'][keep, 1], rtol=2e-3, atol=1e-4,
                                        err_msg=f'step {it} {key}')
+
+
+def test_metric_matches_upstream(golden):
+    """oracle.metrics (rdf_gan_metric.py:59-151 + evaluator.py:28-29) against the reference's RDFGANMetric.evaluate_all"""
+    from oracle import metrics as om
+    from cases import metric_case
+    g = golden('metric')
+    gt_n, pd_n, ev = metric_case()
+    real, fake = om.denormalise(gt_n.numpy()), om.denormalise(pd_n.numpy())
+    plain, _ = om.evaluate_all([dict(gt=real[k], pd=fake[k]) for k in range(len(real))])
+    masked, per = om.evaluate_all([dict(gt=real[k], pd=fake[k], evaluate_mask=ev[k].numpy()) for k in range(len(real))])
+    assert [str(n) for n in g['names']] == list(om.NAMES)
+    np.testing.assert_allclose([plain[n] for n in om.NAMES], g['plain'], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose([masked[n] for n in om.NAMES], g['masked'], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(per, g['per_image'], rtol=2e-6, atol=1e-7)
