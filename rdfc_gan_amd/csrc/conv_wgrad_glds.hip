@@ -22,6 +22,7 @@ struct WGParams {
     int N, Hi, Wi, Ci, Ho, Wo, Co, pad;
     int ldx, ldy;
     int segs_per_row, total_segs, segs_per_slice;
+    int tiles, xcd_group;
     int tiles_ci;
 };
 
@@ -74,11 +75,19 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = blockIdx.y;
+    // Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2.  All the tiles of one pixel slice (the
+    // kernel rows, ci tiles and co tiles that re-read the same dY / X pixels) are numbered onto ONE XCD, eight slices
+    // side by side: id = (slice group * tiles + tile) * 8 + slice % 8.  (p.xcd_group == 0: plain (slice, tile) grid.)
+    int tile = blockIdx.y, slice = blockIdx.x;
+    if (p.xcd_group) {
+        const int k = blockIdx.x >> 3;
+        tile = k % p.tiles;
+        slice = (k / p.tiles) * 8 + (blockIdx.x & 7);
+    }
     const int ky = NKY == 3 ? 0 : tile % 3;                     // first kernel row of this workgroup
     if (NKY == 1) tile /= 3;
     const int ci0 = (tile % p.tiles_ci) * TCI, co0 = (tile / p.tiles_ci) * TCO;
-    const int seg0 = blockIdx.x * p.segs_per_slice;
+    const int seg0 = slice * p.segs_per_slice;
     int nseg = p.total_segs - seg0;
     if (nseg > p.segs_per_slice) nseg = p.segs_per_slice;
     if (nseg <= 0) return;
@@ -215,7 +224,14 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     p.segs_per_slice = cdiv(p.total_segs, slices);
     slices = cdiv(p.total_segs, p.segs_per_slice);
     rdfc_note_kernel("wgrad_glds_kernel<%d, %d>", TCO, NKY);
-    hipLaunchKernelGGL((wgrad_glds_kernel<TCO, NKY>), dim3(slices, tiles), dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw, zero);
+    static const bool xcd_group = !(getenv("RDFC_WGRAD_XCD") && atoi(getenv("RDFC_WGRAD_XCD")) == 0);
+    p.tiles = tiles;
+    // measured (tools/wgrad_xcd_ab.sh): 64->64 @ 228x304 (3 tiles) 95 -> 89 us; with 12-24 tiles per slice the slice count
+    // (512 / tiles) is no multiple of 8 and the XCDs end up unevenly loaded: 256->256 @ 57x76 88 -> 123 us.  FETCH_SIZE
+    // shows the re-reads (3x on the 64-channel layers) either way; the Infinity Cache serves them at full rate.
+    p.xcd_group = xcd_group && tiles <= 3 && slices >= 8;
+    const dim3 grid = p.xcd_group ? dim3(cdiv(slices, 8) * 8 * tiles, 1) : dim3(slices, tiles);
+    hipLaunchKernelGGL((wgrad_glds_kernel<TCO, NKY>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw, zero);
     return 1;
 }
 

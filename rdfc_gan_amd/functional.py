@@ -160,11 +160,12 @@ def _wgrad(d, a, b, weight, O, I, k, scale):
 class ConvSpec:
     """static description of one conv block (shared by forward and backward)"""
     __slots__ = ('k', 'stride', 'pad', 'transposed', 'out_pad', 'norm', 'act', 'slope', 'eps', 'momentum',
-                 'out_f32', 'wscale')
+                 'out_f32', 'wscale', 'dil')
 
     def __init__(self, k, stride=1, pad=0, transposed=False, out_pad=0, norm='none', act='none', slope=0.0,
-                 eps=1e-5, momentum=0.1, out_f32=False, wscale=1.0):
-        self.k, self.stride, self.pad, self.transposed, self.out_pad = k, stride, pad, transposed, out_pad
+                 eps=1e-5, momentum=0.1, out_f32=False, wscale=1.0, dil=1):
+        assert dil == 1 or not transposed
+        self.k, self.stride, self.pad, self.transposed, self.out_pad, self.dil = k, stride, pad, transposed, out_pad, dil
         self.norm, self.act, self.slope, self.eps, self.momentum = norm, act, slope, eps, momentum
         self.out_f32, self.wscale = out_f32, wscale
 
@@ -175,8 +176,8 @@ def _geometry(spec, x, weight):
     k, s, p = spec.k, spec.stride, spec.pad
     if not spec.transposed:
         Cout = weight.shape[0]
-        Ho = (H + 2 * p - k) // s + 1
-        Wo = (W + 2 * p - k) // s + 1
+        Ho = (H + 2 * p - spec.dil * (k - 1) - 1) // s + 1
+        Wo = (W + 2 * p - spec.dil * (k - 1) - 1) // s + 1
     else:   # ConvTranspose2d weight [Cin, Cout, k, k]
         Cout = weight.shape[1]
         Ho = (H - 1) * s - 2 * p + k + spec.out_pad
@@ -198,7 +199,7 @@ class _ConvBlock(torch.autograd.Function):
         fused = None                # (mean, rstd) when the conv's epilogue produced the normalisation statistics
         live_stats = has_norm and not (spec.norm == 'bn' and not training)
         if not spec.transposed:
-            d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
+            d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
                               act=epi_act, slope=spec.slope, out_f32=out_f32)
             G_ = N if spec.norm == 'in' else 1
             if live_stats and _DETERMINISTIC and hip.conv_stats_nchunk(d, G_) > 0:
@@ -274,11 +275,11 @@ class _ConvBlock(torch.autograd.Function):
         g_x = g_w = None
         if not spec.transposed:
             if ctx.needs_input_grad[0]:
-                d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, ldx=Cin, ldy=hip.ld(dy), dtype=hip.dt(x))
+                d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=Cin, ldy=hip.ld(dy), dtype=hip.dt(x))
                 g_x = torch.empty(N, H, W, Cin, dtype=x.dtype, device=x.device)
                 hip.conv_dgrad(d, dy, wb, None, g_x)
             if ctx.needs_input_grad[1]:
-                d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, ldx=hip.ld(x), ldy=hip.ld(dy), dtype=hip.dt(x))
+                d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=hip.ld(x), ldy=hip.ld(dy), dtype=hip.dt(x))
                 g_w = _wgrad(d, x, dy, weight, Cout, Cin, spec.k, spec.wscale)
         else:
             if ctx.needs_input_grad[0]:

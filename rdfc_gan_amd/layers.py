@@ -76,12 +76,13 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
     else:
         raise TypeError(f'unsupported norm layer {type(norm)}')
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    assert conv.kernel_size[0] == conv.kernel_size[1] and conv.dilation == (1, 1) and conv.groups == 1
+    assert conv.kernel_size[0] == conv.kernel_size[1] and conv.dilation[0] == conv.dilation[1] and conv.groups == 1
+    assert conv.padding[0] == conv.padding[1] and conv.stride[0] == conv.stride[1]
     momentum = getattr(norm, 'momentum', 0.1) or 0.1
     if BN_STAT_REPEAT != 1:
         momentum = 1.0 - (1.0 - momentum) ** BN_STAT_REPEAT
     spec = ConvSpec(k, s, p, transposed, conv.output_padding[0] if transposed else 0, nname, aname, slope,
-                    eps=getattr(norm, 'eps', 1e-5), momentum=momentum, out_f32=out_f32)
+                    eps=getattr(norm, 'eps', 1e-5), momentum=momentum, out_f32=out_f32, dil=conv.dilation[0])
     gamma = beta = rm = rv = None
     training = True
     if nname == 'bn':

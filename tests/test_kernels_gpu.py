@@ -135,6 +135,42 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     assert rel_err(gw, wr.grad) < tol(dtype), 'wgrad'
 
 
+DILATED_CASES = [
+    # N, H, W, Ci, Co, k, s, p, dil   (label net: dilated ResNet-50 stages, backbone_resnet50.py:126-235)
+    (2, 15, 19, 64, 64, 3, 1, 2, 2),
+    (1, 29, 38, 128, 128, 3, 1, 4, 4),
+    (2, 17, 21, 256, 128, 3, 1, 8, 8),
+    (1, 29, 38, 64, 64, 3, 1, 16, 16),
+    (2, 15, 19, 128, 64, 3, 2, 2, 2),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', DILATED_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_dilated(case, dtype):
+    h = hip()
+    N, H, W, Ci, Co, k, s, p, dil = case
+    x = rnd(N, Ci, H, W, seed=1).to(dtype).float()
+    w = rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5).to(dtype).float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, s, p, dil)
+    gy = rnd(*y_ref.shape, seed=4).to(dtype).float()
+    y_ref.backward(gy)
+    x_pm, gy_pm = to_pm(x, dtype), to_pm(gy, dtype)
+    wf, wb = h.pack_weight(w.to(DEV), dtype)
+    Ho, Wo = y_ref.shape[2:]
+    y_pm = torch.empty(N, Ho, Wo, Co, dtype=dtype, device=DEV)
+    d = h.conv_desc(x_pm.shape, Co, k, s, p, dil, ldx=Ci, ldy=Co, dtype=h.dt(x_pm))
+    assert (d.Ho, d.Wo) == (Ho, Wo)
+    h.conv_forward(d, x_pm, wf, None, y_pm)
+    assert rel_err(from_pm(y_pm), y_ref.detach()) < tol(dtype), 'forward'
+    dx_pm = torch.empty(N, H, W, Ci, dtype=dtype, device=DEV)
+    h.conv_dgrad(d, gy_pm, wb, None, dx_pm)
+    assert rel_err(from_pm(dx_pm), xr.grad) < tol(dtype), 'dgrad'
+    gw = h.unpack_wgrad(h.conv_wgrad(d, x_pm, gy_pm), Co, Ci, k, k)
+    assert rel_err(gw, wr.grad) < tol(dtype), 'wgrad'
+
+
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
 @pytest.mark.parametrize('case', [(2, 5, 7, 512, 256), (2, 8, 10, 192, 64), (1, 15, 19, 128, 64)],
                          ids=lambda c: 'x'.join(map(str, c)))

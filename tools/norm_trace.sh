@@ -19,7 +19,15 @@ for r in rows[len(rows)//2:]:
             g = (r.get('Grid_Size_X') or r.get('Grid_Size'), r.get('Grid_Size_Y'), r.get('Grid_Size_Z'))
             a = agg[(key, g)]; a[0] += 1; a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
             break
-for (key, g), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+seen = {}
+for r in rows:
+    n = r['Kernel_Name']
+    if ('_kernel' in n) and n not in seen:
+        seen[n] = (r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'], r['Scratch_Size'], r['LDS_Block_Size'])
+for n, v in sorted(seen.items()):
+    if any(k in n for k in ('apply', 'reduce', 'stats', 'chsum')):
+        print('vgpr/agpr/sgpr/scratch/lds', v, n[:100])
+for (key, g), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
     print(f'{key:18s} grid {g}  calls {n:4d}  total {t/1e3:7.2f} ms  avg {t/n:7.1f} us')
 PY
 rm -rf gpurun_out/prof_nt

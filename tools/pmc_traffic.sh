@@ -6,12 +6,16 @@ tag=$1; shift
 root=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $root
 rm -rf gpurun_out/pmc_${tag}
-timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d gpurun_out/pmc_${tag} -- python3 tools/conv_bench.py "$@" 5 > /dev/null 2>&1
+# one counter per pass: FETCH_SIZE takes 3 of the 4 TCC slots and WRITE_SIZE 2, both in one pass do not fit (and hung the run)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${tag}/$c -- python3 tools/conv_bench.py "$@" 5 > gpurun_out/pmc_${tag}_$c.log 2>&1
+  echo "pass $c rc=$?"
+done
 python3 - "$tag" "$@" <<'PY'
 import csv, glob, sys, collections
 tag = sys.argv[1]
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-for f in glob.glob(f'gpurun_out/pmc_{tag}/*/*counter_collection.csv'):
+for f in glob.glob(f'gpurun_out/pmc_{tag}/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'][:80]
         if any(t in k for t in ('igemm', 'patch', 'slab', 'wgrad', 'thin', 'glds')):
