@@ -251,6 +251,43 @@ int rdfc_adam_step_dev(float *param, const float *grad, float *exp_avg, float *e
 int rdfc_depth_metrics(const float *gt_norm, const float *pred_norm, const uint8_t *evaluate_mask, int N, int HW, float std,
                        float mean, float t_valid, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------
+ * Semantic-label net: the operators of PSPNet / dilated ResNet-50 that are not convolutions or
+ * normalisations (lib/models/generator/label_net/labels_model.py:12-94, backbone_resnet50.py:150-235) and the
+ * label loss (rdfc_gan.py:59,238-239).  Pixel-major maps [N][H][W][C] with leading dimension ld (elements), dtype
+ * RDFC_F32 | RDFC_BF16; C and ld multiples of the 16-byte vector (4 | 8) except for the bilinear resize and the
+ * cross entropy, which take any C (the 14-class logits).  Every backward is a gather: no atomics.
+ * ------------------------------------------------------------------------------ */
+/* nn.MaxPool2d(k, s, p) (backbone_resnet50.py:172): first maximum in scan order wins, NaN propagates;
+ * idx u8 [N][Ho][Wo][C] = kh * k + kw of the winner, consumed by the backward. */
+int rdfc_maxpool2d_forward(const void *x, void *y, uint8_t *idx, int N, int Hi, int Wi, int C, int ldx, int ldy, int k, int s,
+                           int p, int Ho, int Wo, int dtype, void *stream);
+int rdfc_maxpool2d_backward(const void *dy, const uint8_t *idx, void *dx, int N, int Hi, int Wi, int C, int lddy, int lddx,
+                            int k, int s, int p, int Ho, int Wo, int dtype, void *stream);
+/* nn.AdaptiveAvgPool2d((Ho, Wo)) (labels_model.py:28): bin = [floor(o * I / O), ceil((o + 1) * I / O)). */
+int rdfc_adaptive_avgpool_forward(const void *x, void *y, int N, int Hi, int Wi, int C, int ldx, int ldy, int Ho, int Wo,
+                                  int dtype, void *stream);
+int rdfc_adaptive_avgpool_backward(const void *dy, void *dx, int N, int Hi, int Wi, int C, int lddy, int lddx, int Ho, int Wo,
+                                   int dtype, void *stream);
+/* F.interpolate(size=(Ho, Wo), mode='bilinear', align_corners=True) (labels_model.py:37-38,82,87).  out_f32 / dy_f32:
+ * the resized map (its gradient) is f32 although the source is bf16 -- the full-resolution logits feed the loss. */
+int rdfc_bilinear_forward(const void *x, void *y, int N, int Hi, int Wi, int C, int ldx, int ldy, int Ho, int Wo, int dtype,
+                          int out_f32, void *stream);
+int rdfc_bilinear_backward(const void *dy, void *dx, int N, int Hi, int Wi, int C, int lddy, int lddx, int Ho, int Wo,
+                           int dtype, int dy_f32, void *stream);
+/* nn.Dropout2d's arithmetic (labels_model.py:23,71): y = x * scale[n][c], scale = keep / (1 - p) drawn by the caller. */
+int rdfc_scale_nc(const void *x, const float *scale, void *y, int N, int HW, int C, int ldx, int ldy, int dtype, void *stream);
+/* torch.nn.CrossEntropyLoss() (rdfc_gan.py:59): logits [P][C] (ld), labels i64 [P]; mean of lse(z) - z[t] over the
+ * pixels with t != ignore_index.  partial: f64 [2 * rdfc_cross_entropy_nchunk(P)] scratch; loss_out / count_out: f32
+ * scalars on the device.  Backward: dlogits = (softmax(z) - onehot(t)) * grad_scale * (*grad_scale_dev, if given)
+ * / count, zero rows for ignored pixels. */
+int rdfc_cross_entropy_nchunk(int P);
+int rdfc_cross_entropy(const void *logits, const int64_t *labels, int P, int C, int ld, int dtype, int64_t ignore_index,
+                       double *partial, float *loss_out, float *count_out, void *stream);
+int rdfc_cross_entropy_backward(const void *logits, const int64_t *labels, int P, int C, int ld, int dtype,
+                                int64_t ignore_index, const float *count, const float *grad_scale_dev, float grad_scale,
+                                void *dlogits, int lddl, void *stream);
+
 /* addPepperNoise (helper.py:384-402) given the host-drawn mask (0 keep, 1 -> +1, 2 -> -1), in place. */
 int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, int HW, void *stream);
 

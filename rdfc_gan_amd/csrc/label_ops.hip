@@ -1,0 +1,464 @@
+// label_ops.hip -- the non-convolution operators of the semantic-label net (lib/models/generator/label_net/
+// labels_model.py:12-94, backbone_resnet50.py:150-235) and its loss (rdfc_gan.py:59,238-239) on pixel-major maps
+// [N][H][W][C] (leading dimension ld):
+//   MaxPool2d(3, 2, 1), AdaptiveAvgPool2d(b), F.interpolate(bilinear, align_corners=True), Dropout2d's per-(n, c)
+//   scale, CrossEntropyLoss (mean over the pixels whose label is not ignore_index).
+// All HBM-bound or tiny; every backward is a gather (no atomics): results do not depend on the launch order.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+inline int nblk(size_t total) { return (int)min((size_t)65535 * 16, (total + NT - 1) / NT); }
+#define GRID_STRIDE(i, total) \
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (size_t)gridDim.x * blockDim.x)
+
+// ---- MaxPool2d ------------------------------------------------------------------------------------------------------
+// first maximum in window scan order wins (strict >, NaN propagates) like at::max_pool2d; idx = kh * k + kw of the winner
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, uint8_t *__restrict__ idx, int N, int Hi, int Wi,
+                                   int C, int ldx, int ldy, int k, int s, int p, int Ho, int Wo) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * Ho * Wo * CV;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % CV);
+        size_t r = i / CV;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float best[VEC];
+        int bi[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { best[v] = -INFINITY; bi[v] = 255; }
+        for (int kh = 0; kh < k; ++kh) {
+            const int h = oh * s - p + kh;
+            if ((unsigned)h >= (unsigned)Hi) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int w = ow * s - p + kw;
+                if ((unsigned)w >= (unsigned)Wi) continue;
+                Vec16<T> xv;
+                xv.load(x + ((size_t)(n * Hi + h) * Wi + w) * ldx + cv * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float val = xv.get(v);
+                    if (bi[v] == 255 || val > best[v] || val != val) { best[v] = val; bi[v] = kh * k + kw; }
+                }
+            }
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.set(v, best[v]);
+        o.store(y + ((size_t)(n * Ho + oh) * Wo + ow) * ldy + cv * VEC);
+        uint8_t *ip = idx + ((size_t)(n * Ho + oh) * Wo + ow) * C + cv * VEC;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ip[v] = (uint8_t)bi[v];
+    }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T *__restrict__ dy, const uint8_t *__restrict__ idx, T *__restrict__ dx, int N, int Hi,
+                                   int Wi, int C, int lddy, int lddx, int k, int s, int p, int Ho, int Wo) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * Hi * Wi * CV;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % CV);
+        size_t r = i / CV;
+        const int w = (int)(r % Wi); r /= Wi;
+        const int h = (int)(r % Hi);
+        const int n = (int)(r / Hi);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        // windows that contain (h, w): oh * s - p <= h <= oh * s - p + k - 1
+        int oh0 = h + p - k + 1;
+        oh0 = oh0 <= 0 ? 0 : (oh0 + s - 1) / s;
+        int ow0 = w + p - k + 1;
+        ow0 = ow0 <= 0 ? 0 : (ow0 + s - 1) / s;
+        const int oh1 = min((h + p) / s, Ho - 1), ow1 = min((w + p) / s, Wo - 1);
+        for (int oh = oh0; oh <= oh1; ++oh)
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                const int off = (h - (oh * s - p)) * k + (w - (ow * s - p));
+                const size_t o = (size_t)(n * Ho + oh) * Wo + ow;
+                Vec16<T> dv;
+                dv.load(dy + o * lddy + cv * VEC);
+                const uint8_t *ip = idx + o * C + cv * VEC;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (ip[v] == off) acc[v] += dv.get(v);
+            }
+        Vec16<T> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.set(v, acc[v]);
+        o.store(dx + ((size_t)(n * Hi + h) * Wi + w) * lddx + cv * VEC);
+    }
+}
+
+// ---- AdaptiveAvgPool2d ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bin_start(int o, int O, int I) { return (int)floorf((float)(o * I) / O); }
+__device__ __forceinline__ int bin_end(int o, int O, int I) { return (int)ceilf((float)((o + 1) * I) / O); }
+
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int N, int Hi, int Wi, int C, int ldx, int ldy, int Ho,
+                                   int Wo) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * Ho * Wo * CV;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % CV);
+        size_t r = i / CV;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const int h0 = bin_start(oh, Ho, Hi), h1 = bin_end(oh, Ho, Hi), w0 = bin_start(ow, Wo, Wi), w1 = bin_end(ow, Wo, Wi);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) {
+                Vec16<T> xv;
+                xv.load(x + ((size_t)(n * Hi + h) * Wi + w) * ldx + cv * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += xv.get(v);
+            }
+        const float area = (float)((h1 - h0) * (w1 - w0));
+        Vec16<T> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.set(v, acc[v] / area);
+        o.store(y + ((size_t)(n * Ho + oh) * Wo + ow) * ldy + cv * VEC);
+    }
+}
+
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T *__restrict__ dy, T *__restrict__ dx, int N, int Hi, int Wi, int C, int lddy, int lddx,
+                                   int Ho, int Wo) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * Hi * Wi * CV;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % CV);
+        size_t r = i / CV;
+        const int w = (int)(r % Wi); r /= Wi;
+        const int h = (int)(r % Hi);
+        const int n = (int)(r / Hi);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int oh = 0; oh < Ho; ++oh) {
+            const int h0 = bin_start(oh, Ho, Hi), h1 = bin_end(oh, Ho, Hi);
+            if (h < h0 || h >= h1) continue;
+            for (int ow = 0; ow < Wo; ++ow) {
+                const int w0 = bin_start(ow, Wo, Wi), w1 = bin_end(ow, Wo, Wi);
+                if (w < w0 || w >= w1) continue;
+                const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+                Vec16<T> dv;
+                dv.load(dy + ((size_t)(n * Ho + oh) * Wo + ow) * lddy + cv * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += dv.get(v) * inv;
+            }
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.set(v, acc[v]);
+        o.store(dx + ((size_t)(n * Hi + h) * Wi + w) * lddx + cv * VEC);
+    }
+}
+
+// ---- bilinear resize, align_corners = True (at::upsample_bilinear2d) -------------------------------------------------
+__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_of(int o, float scale, int in) {
+    const float src = scale * (float)o;
+    Lerp r;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+template <typename TI, typename TO>
+__global__ void bilinear_fwd_kernel(const TI *__restrict__ x, TO *__restrict__ y, int N, int Hi, int Wi, int C, int ldx, int ldy, int Ho,
+                                    int Wo) {
+    const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
+    const size_t total = (size_t)N * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const Lerp a = lerp_of(oh, sh, Hi), b = lerp_of(ow, sw, Wi);
+        const TI *base = x + (size_t)n * Hi * Wi * ldx + c;
+        const float v00 = Elem<TI>::ld(base + ((size_t)a.i0 * Wi + b.i0) * ldx), v01 = Elem<TI>::ld(base + ((size_t)a.i0 * Wi + b.i1) * ldx);
+        const float v10 = Elem<TI>::ld(base + ((size_t)a.i1 * Wi + b.i0) * ldx), v11 = Elem<TI>::ld(base + ((size_t)a.i1 * Wi + b.i1) * ldx);
+        const float o = a.l0 * (b.l0 * v00 + b.l1 * v01) + a.l1 * (b.l0 * v10 + b.l1 * v11);
+        Elem<TO>::st(y + ((size_t)(n * Ho + oh) * Wo + ow) * ldy + c, o);
+    }
+}
+
+// adjoint as a gather: input pixel (h, w) collects every output pixel whose two taps along each axis include it
+__device__ __forceinline__ void out_range(int i, float scale, int in, int out, int &lo, int &hi) {
+    if (scale == 0.f) { lo = 0; hi = out - 1; return; }
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    lo = max(lo, 0);
+    hi = min(hi, out - 1);
+}
+__device__ __forceinline__ float tap_weight(int o, int i, float scale, int in) {
+    const Lerp a = lerp_of(o, scale, in);
+    return (a.i0 == i ? a.l0 : 0.f) + (a.i1 == i ? a.l1 : 0.f);
+}
+
+template <typename TI, typename TO>   // TI: dtype of dx (the forward's input), TO: dtype of dy
+__global__ void bilinear_bwd_kernel(const TO *__restrict__ dy, TI *__restrict__ dx, int N, int Hi, int Wi, int C, int lddy, int lddx,
+                                    int Ho, int Wo) {
+    const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
+    const size_t total = (size_t)N * Hi * Wi * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int w = (int)(r % Wi); r /= Wi;
+        const int h = (int)(r % Hi);
+        const int n = (int)(r / Hi);
+        int oh0, oh1, ow0, ow1;
+        out_range(h, sh, Hi, Ho, oh0, oh1);
+        out_range(w, sw, Wi, Wo, ow0, ow1);
+        float acc = 0.f;
+        for (int oh = oh0; oh <= oh1; ++oh) {
+            const float wh = tap_weight(oh, h, sh, Hi);
+            if (wh == 0.f) continue;
+            float row = 0.f;
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                const float ww = tap_weight(ow, w, sw, Wi);
+                if (ww != 0.f) row += ww * Elem<TO>::ld(dy + ((size_t)(n * Ho + oh) * Wo + ow) * lddy + c);
+            }
+            acc += wh * row;
+        }
+        Elem<TI>::st(dx + ((size_t)(n * Hi + h) * Wi + w) * lddx + c, acc);
+    }
+}
+
+// ---- Dropout2d: y = x * scale[n][c] -------------------------------------------------------------------------------
+template <typename T>
+__global__ void scale_nc_kernel(const T *__restrict__ x, const float *__restrict__ scale, T *__restrict__ y, int N, int HW, int C, int ldx,
+                                int ldy) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * HW * CV;
+    GRID_STRIDE(i, total) {
+        const int cv = (int)(i % CV);
+        const size_t px = i / CV;
+        const int n = (int)(px / HW);
+        Vec16<T> xv, o;
+        xv.load(x + px * ldx + cv * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.set(v, xv.get(v) * scale[n * C + cv * VEC + v]);
+        o.store(y + px * ldy + cv * VEC);
+    }
+}
+
+// ---- CrossEntropyLoss over pixel-major logits [P][C] ---------------------------------------------------------------
+constexpr int CE_MAXC = 4096;
+template <typename T>   // log-sum-exp of one pixel's logits; zt = the target's logit (two passes over the row, no per-thread array)
+__device__ __forceinline__ float pixel_lse(const T *__restrict__ row, int C, int t, float &zt) {
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, Elem<T>::ld(row + c));
+    float s = 0.f;
+    zt = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float z = Elem<T>::ld(row + c);
+        s += expf(z - m);
+        if (c == t) zt = z;
+    }
+    return m + logf(s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ce_fwd_kernel(const T *__restrict__ logits, const long long *__restrict__ labels, int P, int C, int ld,
+                                                    long long ignore_index, double *__restrict__ partial) {
+    __shared__ double red[2][NT / 64];
+    double s = 0.0, cnt = 0.0;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < (size_t)P; i += (size_t)gridDim.x * NT) {
+        const long long t = labels[i];
+        if (t == ignore_index || t < 0 || t >= C) continue;
+        float zt;
+        const float lse = pixel_lse(logits + i * ld, C, (int)t, zt);
+        s += (double)(lse - zt);
+        cnt += 1.0;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); cnt += __shfl_down(cnt, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < NT / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+        partial[2 * blockIdx.x] = a;
+        partial[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ void ce_finalize_kernel(const double *__restrict__ partial, int nb, float *__restrict__ loss, float *__restrict__ count) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nb; ++k) { a += partial[2 * k]; b += partial[2 * k + 1]; }
+        *loss = (float)(a / b);          // 0 / 0 = NaN like torch when every pixel is ignored
+        *count = (float)b;
+    }
+}
+
+template <typename T>
+__global__ void ce_bwd_kernel(const T *__restrict__ logits, const long long *__restrict__ labels, int P, int C, int ld, long long ignore_index,
+                              const float *__restrict__ count, const float *__restrict__ gscale_dev, float gscale, T *__restrict__ dl,
+                              int lddl) {
+    const float g = gscale * (gscale_dev ? *gscale_dev : 1.f) / *count;
+    GRID_STRIDE(i, (size_t)P) {
+        const long long t = labels[i];
+        T *o = dl + i * lddl;
+        if (t == ignore_index || t < 0 || t >= C) {
+            for (int c = 0; c < C; ++c) Elem<T>::st(o + c, 0.f);
+            continue;
+        }
+        float zt;
+        const float lse = pixel_lse(logits + i * ld, C, (int)t, zt);
+        for (int c = 0; c < C; ++c) Elem<T>::st(o + c, (expf(Elem<T>::ld(logits + i * ld + c) - lse) - (c == t ? 1.f : 0.f)) * g);
+    }
+}
+
+#define DISPATCH(dtype, ...)                                      \
+    if ((dtype) == RDFC_BF16) { using T = bf16_t; __VA_ARGS__; } \
+    else { using T = float; __VA_ARGS__; }
+#define CHECK_DTYPE(who, dtype) RDFC_REQUIRE((dtype) == RDFC_F32 || (dtype) == RDFC_BF16, "%s: bad dtype %d", who, dtype)
+#define CHECK_VEC(who, dtype, C, ...)                                                                                     \
+    {                                                                                                                     \
+        const int vec_ = (dtype) == RDFC_BF16 ? 8 : 4;                                                                    \
+        RDFC_REQUIRE((C) > 0 && (C) % vec_ == 0, "%s: C = %d must be a positive multiple of %d", who, C, vec_);            \
+        for (int l_ : {__VA_ARGS__}) RDFC_REQUIRE(l_ >= (C) && l_ % vec_ == 0, "%s: bad leading dimension %d", who, l_); \
+    }
+
+}  // namespace
+
+extern "C" int rdfc_maxpool2d_forward(const void *x, void *y, uint8_t *idx, int N, int Hi, int Wi, int C, int ldx, int ldy, int k, int s,
+                                      int p, int Ho, int Wo, int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_maxpool2d_forward", dtype);
+    CHECK_VEC("rdfc_maxpool2d_forward", dtype, C, ldx, ldy);
+    RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && k > 0 && k * k < 255 && s > 0 && p >= 0 && 2 * p <= k, "rdfc_maxpool2d_forward: bad geometry");
+    RDFC_REQUIRE(Ho == (Hi + 2 * p - k) / s + 1 && Wo == (Wi + 2 * p - k) / s + 1, "rdfc_maxpool2d_forward: output %dx%d does not match", Ho, Wo);
+    RDFC_REQUIRE(x && y && idx, "rdfc_maxpool2d_forward: null pointer");
+    const size_t total = (size_t)N * Ho * Wo * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    DISPATCH(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)x, (T *)y, idx, N,
+                                       Hi, Wi, C, ldx, ldy, k, s, p, Ho, Wo));
+    RDFC_LAUNCH_CHECK("rdfc_maxpool2d_forward");
+    return 0;
+}
+
+extern "C" int rdfc_maxpool2d_backward(const void *dy, const uint8_t *idx, void *dx, int N, int Hi, int Wi, int C, int lddy, int lddx, int k,
+                                       int s, int p, int Ho, int Wo, int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_maxpool2d_backward", dtype);
+    CHECK_VEC("rdfc_maxpool2d_backward", dtype, C, lddy, lddx);
+    RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && k > 0 && k * k < 255 && s > 0 && p >= 0, "rdfc_maxpool2d_backward: bad geometry");
+    RDFC_REQUIRE(dy && dx && idx, "rdfc_maxpool2d_backward: null pointer");
+    const size_t total = (size_t)N * Hi * Wi * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    DISPATCH(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)dy, idx, (T *)dx,
+                                       N, Hi, Wi, C, lddy, lddx, k, s, p, Ho, Wo));
+    RDFC_LAUNCH_CHECK("rdfc_maxpool2d_backward");
+    return 0;
+}
+
+extern "C" int rdfc_adaptive_avgpool_forward(const void *x, void *y, int N, int Hi, int Wi, int C, int ldx, int ldy, int Ho, int Wo, int dtype,
+                                             void *stream) {
+    CHECK_DTYPE("rdfc_adaptive_avgpool_forward", dtype);
+    CHECK_VEC("rdfc_adaptive_avgpool_forward", dtype, C, ldx, ldy);
+    RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && x && y, "rdfc_adaptive_avgpool_forward: bad arguments");
+    const size_t total = (size_t)N * Ho * Wo * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    DISPATCH(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)x, (T *)y, N, Hi,
+                                       Wi, C, ldx, ldy, Ho, Wo));
+    RDFC_LAUNCH_CHECK("rdfc_adaptive_avgpool_forward");
+    return 0;
+}
+
+extern "C" int rdfc_adaptive_avgpool_backward(const void *dy, void *dx, int N, int Hi, int Wi, int C, int lddy, int lddx, int Ho, int Wo,
+                                              int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_adaptive_avgpool_backward", dtype);
+    CHECK_VEC("rdfc_adaptive_avgpool_backward", dtype, C, lddy, lddx);
+    RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && dy && dx, "rdfc_adaptive_avgpool_backward: bad arguments");
+    const size_t total = (size_t)N * Hi * Wi * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    DISPATCH(dtype, hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)dy, (T *)dx, N, Hi,
+                                       Wi, C, lddy, lddx, Ho, Wo));
+    RDFC_LAUNCH_CHECK("rdfc_adaptive_avgpool_backward");
+    return 0;
+}
+
+extern "C" int rdfc_bilinear_forward(const void *x, void *y, int N, int Hi, int Wi, int C, int ldx, int ldy, int Ho, int Wo, int dtype,
+                                     int out_f32, void *stream) {
+    CHECK_DTYPE("rdfc_bilinear_forward", dtype);
+    RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && ldx >= C && ldy >= C && x && y, "rdfc_bilinear_forward: bad arguments");
+    const size_t total = (size_t)N * Ho * Wo * C;
+    const dim3 g(nblk(total)), b(NT);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RDFC_BF16 && out_f32)
+        hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t *)x, (float *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo);
+    else if (dtype == RDFC_BF16)
+        hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t *)x, (bf16_t *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo);
+    else
+        hipLaunchKernelGGL((bilinear_fwd_kernel<float, float>), g, b, 0, st, (const float *)x, (float *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo);
+    RDFC_LAUNCH_CHECK("rdfc_bilinear_forward");
+    return 0;
+}
+
+extern "C" int rdfc_bilinear_backward(const void *dy, void *dx, int N, int Hi, int Wi, int C, int lddy, int lddx, int Ho, int Wo, int dtype,
+                                      int dy_f32, void *stream) {
+    CHECK_DTYPE("rdfc_bilinear_backward", dtype);
+    RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && lddx >= C && lddy >= C && dx && dy, "rdfc_bilinear_backward: bad arguments");
+    const size_t total = (size_t)N * Hi * Wi * C;
+    const dim3 g(nblk(total)), b(NT);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RDFC_BF16 && dy_f32)
+        hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, float>), g, b, 0, st, (const float *)dy, (bf16_t *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo);
+    else if (dtype == RDFC_BF16)
+        hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t *)dy, (bf16_t *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo);
+    else
+        hipLaunchKernelGGL((bilinear_bwd_kernel<float, float>), g, b, 0, st, (const float *)dy, (float *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo);
+    RDFC_LAUNCH_CHECK("rdfc_bilinear_backward");
+    return 0;
+}
+
+extern "C" int rdfc_scale_nc(const void *x, const float *scale, void *y, int N, int HW, int C, int ldx, int ldy, int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_scale_nc", dtype);
+    CHECK_VEC("rdfc_scale_nc", dtype, C, ldx, ldy);
+    RDFC_REQUIRE(N > 0 && HW > 0 && x && y && scale, "rdfc_scale_nc: bad arguments");
+    const size_t total = (size_t)N * HW * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    DISPATCH(dtype, hipLaunchKernelGGL(scale_nc_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)x, scale, (T *)y, N, HW,
+                                       C, ldx, ldy));
+    RDFC_LAUNCH_CHECK("rdfc_scale_nc");
+    return 0;
+}
+
+extern "C" int rdfc_cross_entropy_nchunk(int P) { return (int)min((size_t)1024, ((size_t)P + NT - 1) / NT); }
+
+extern "C" int rdfc_cross_entropy(const void *logits, const int64_t *labels, int P, int C, int ld, int dtype, int64_t ignore_index,
+                                  double *partial, float *loss_out, float *count_out, void *stream) {
+    CHECK_DTYPE("rdfc_cross_entropy", dtype);
+    RDFC_REQUIRE(P > 0 && C > 0 && C <= CE_MAXC && ld >= C, "rdfc_cross_entropy: bad shape (P %d, C %d <= %d, ld %d)", P, C, CE_MAXC, ld);
+    RDFC_REQUIRE(logits && labels && partial && loss_out && count_out, "rdfc_cross_entropy: null pointer");
+    const int nb = rdfc_cross_entropy_nchunk(P);
+    DISPATCH(dtype, hipLaunchKernelGGL(ce_fwd_kernel<T>, dim3(nb), dim3(NT), 0, (hipStream_t)stream, (const T *)logits,
+                                       (const long long *)labels, P, C, ld, (long long)ignore_index, partial));
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, loss_out, count_out);
+    RDFC_LAUNCH_CHECK("rdfc_cross_entropy");
+    return 0;
+}
+
+extern "C" int rdfc_cross_entropy_backward(const void *logits, const int64_t *labels, int P, int C, int ld, int dtype, int64_t ignore_index,
+                                           const float *count, const float *grad_scale_dev, float grad_scale, void *dlogits, int lddl,
+                                           void *stream) {
+    CHECK_DTYPE("rdfc_cross_entropy_backward", dtype);
+    RDFC_REQUIRE(P > 0 && C > 0 && C <= CE_MAXC && ld >= C && lddl >= C, "rdfc_cross_entropy_backward: bad shape");
+    RDFC_REQUIRE(logits && labels && count && dlogits, "rdfc_cross_entropy_backward: null pointer");
+    DISPATCH(dtype, hipLaunchKernelGGL(ce_bwd_kernel<T>, dim3(nblk((size_t)P)), dim3(NT), 0, (hipStream_t)stream, (const T *)logits,
+                                       (const long long *)labels, P, C, ld, (long long)ignore_index, count, grad_scale_dev, grad_scale,
+                                       (T *)dlogits, lddl));
+    RDFC_LAUNCH_CHECK("rdfc_cross_entropy_backward");
+    return 0;
+}

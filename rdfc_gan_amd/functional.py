@@ -479,3 +479,97 @@ class _WeightedLoss(torch.autograd.Function):
 
 def weighted_loss(pred, target, weight, kind):
     return _WeightedLoss.apply(pred, target, weight, kind)
+
+
+# ---- label net operators: labels_model.py / backbone_resnet50.py ----------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        y, idx = hip.maxpool2d(x, k, s, p)
+        ctx.save_for_backward(idx)
+        ctx.geom = (tuple(x.shape), k, s, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, k, s, p = ctx.geom
+        return hip.maxpool2d_backward(dy.contiguous(), ctx.saved_tensors[0], shape, k, s, p), None, None, None
+
+
+def max_pool2d(x, k, s, p):
+    return _MaxPool.apply(x, k, s, p)
+
+
+class _AdaptiveAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        ctx.shape = tuple(x.shape)
+        return hip.adaptive_avgpool(x, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return hip.adaptive_avgpool_backward(dy.contiguous(), ctx.shape), None, None
+
+
+def adaptive_avg_pool2d(x, size):
+    Ho, Wo = (size, size) if isinstance(size, int) else size
+    return _AdaptiveAvgPool.apply(x, Ho, Wo)
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, out_f32):
+        ctx.meta = (tuple(x.shape), x.dtype)
+        return hip.bilinear(x, Ho, Wo, out_f32=out_f32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, dtype = ctx.meta
+        if dy.dtype != torch.float32 and dy.dtype != dtype:
+            dy = dy.to(dtype)
+        return hip.bilinear_backward(dy.contiguous(), shape, dtype), None, None, None
+
+
+def interpolate_bilinear(x, size, out_f32=False):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) on a pixel-major map"""
+    return _Bilinear.apply(x, size[0], size[1], out_f32)
+
+
+class _ScaleNC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(scale)
+        return hip.scale_nc(x, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return hip.scale_nc(dy.contiguous(), ctx.saved_tensors[0]), None
+
+
+def dropout2d(x, p, training):
+    """nn.Dropout2d: whole channels of a sample are zeroed with probability p, the rest scaled by 1 / (1 - p).  The keep
+    mask comes from torch's generator on the device (one draw of N x C values, like upstream's feature_dropout)."""
+    if not training or p == 0.0:
+        return x
+    N, _, _, C = x.shape
+    keep = torch.empty(N, C, dtype=torch.float32, device=x.device).bernoulli_(1.0 - p).div_(1.0 - p)
+    return _ScaleNC.apply(x, keep)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        loss, count = hip.cross_entropy(logits, labels, ignore_index)
+        ctx.save_for_backward(logits, labels, count)
+        ctx.ignore_index = ignore_index
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, count = ctx.saved_tensors
+        return hip.cross_entropy_backward(logits, labels, count, g, ctx.ignore_index), None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """torch.nn.CrossEntropyLoss()(logits, labels) with pixel-major logits [N,H,W,C]"""
+    return _CrossEntropy.apply(logits, labels, ignore_index)

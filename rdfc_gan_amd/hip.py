@@ -74,6 +74,8 @@ def _declare_argtypes(lib_):
                     types.append(C.c_double)
                 elif re.match(r'^(const )?size_t\b', a):
                     types.append(C.c_size_t)
+                elif re.match(r'^(const )?int64_t\b', a):
+                    types.append(C.c_int64)
                 else:
                     types.append(C.c_int)
         fn = getattr(lib_, name)
@@ -559,3 +561,94 @@ def mdconv_backward(inp, offset, mask, weight, grad_out, stride, pad, dil, group
     _chk(lib().rdfc_mdconv_backward(C.byref(d), _p(inp), _p(offset), _p(mask), _p(weight), _p(grad_out), _p(gi), _p(go),
                                     _p(gm), _p(gw), _p(gb), _st()), 'rdfc_mdconv_backward')
     return gi, go, gm, gw, gb
+
+
+# --------------------------------------------------------------------------- label net operators (label_ops.hip)
+def maxpool2d(x, k, s, p):
+    """pixel-major [N,H,W,C] -> (y [N,Ho,Wo,C], idx u8)"""
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    y = torch.empty(N, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
+    idx = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=x.device)
+    _chk(lib().rdfc_maxpool2d_forward(_p(x), _p(y), _p(idx), N, H, W, Cc, ld(x), Cc, k, s, p, Ho, Wo, dt(x), _st()),
+         'rdfc_maxpool2d_forward')
+    return y, idx
+
+
+def maxpool2d_backward(dy, idx, x_shape, k, s, p):
+    N, H, W, Cc = x_shape
+    Ho, Wo = dy.shape[1:3]
+    dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
+    _chk(lib().rdfc_maxpool2d_backward(_p(dy), _p(idx), _p(dx), N, H, W, Cc, ld(dy), Cc, k, s, p, Ho, Wo, dt(dy), _st()),
+         'rdfc_maxpool2d_backward')
+    return dx
+
+
+def adaptive_avgpool(x, Ho, Wo):
+    N, H, W, Cc = x.shape
+    y = torch.empty(N, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
+    _chk(lib().rdfc_adaptive_avgpool_forward(_p(x), _p(y), N, H, W, Cc, ld(x), Cc, Ho, Wo, dt(x), _st()),
+         'rdfc_adaptive_avgpool_forward')
+    return y
+
+
+def adaptive_avgpool_backward(dy, x_shape):
+    N, H, W, Cc = x_shape
+    Ho, Wo = dy.shape[1:3]
+    dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
+    _chk(lib().rdfc_adaptive_avgpool_backward(_p(dy), _p(dx), N, H, W, Cc, ld(dy), Cc, Ho, Wo, dt(dy), _st()),
+         'rdfc_adaptive_avgpool_backward')
+    return dx
+
+
+def bilinear(x, Ho, Wo, out=None, out_f32=False):
+    """align_corners=True resize of a pixel-major map; `out` may be a channel window of a wider map (torch.cat target)"""
+    N, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty(N, Ho, Wo, Cc, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    f32o = out.dtype == torch.float32 and x.dtype != torch.float32
+    _chk(lib().rdfc_bilinear_forward(_p(x), _p(out), N, H, W, Cc, ld(x), ld(out), Ho, Wo, dt(x), int(f32o), _st()),
+         'rdfc_bilinear_forward')
+    return out
+
+
+def bilinear_backward(dy, x_shape, x_dtype):
+    N, H, W, Cc = x_shape
+    Ho, Wo = dy.shape[1:3]
+    dx = torch.empty(N, H, W, Cc, dtype=x_dtype, device=dy.device)
+    f32y = dy.dtype == torch.float32 and x_dtype != torch.float32
+    _chk(lib().rdfc_bilinear_backward(_p(dy), _p(dx), N, H, W, Cc, ld(dy), Cc, Ho, Wo, dt(dx), int(f32y), _st()),
+         'rdfc_bilinear_backward')
+    return dx
+
+
+def scale_nc(x, scale):
+    """x [N,H,W,C] * scale [N,C] (f32)"""
+    N, H, W, Cc = x.shape
+    y = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
+    _chk(lib().rdfc_scale_nc(_p(x), _p(scale), _p(y), N, H * W, Cc, ld(x), Cc, dt(x), _st()), 'rdfc_scale_nc')
+    return y
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """logits pixel-major [N,H,W,C], labels i64 [N,H,W] -> (loss scalar, count scalar) on the device"""
+    N, H, W, Cc = logits.shape
+    P = N * H * W
+    labels = labels.contiguous()
+    assert labels.dtype == torch.int64 and labels.numel() == P
+    partial = torch.empty(2 * lib().rdfc_cross_entropy_nchunk(P), dtype=torch.float64, device=logits.device)
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    _chk(lib().rdfc_cross_entropy(_p(logits), _p(labels), P, Cc, ld(logits), dt(logits), ignore_index, _p(partial), _p(out),
+                                  out.data_ptr() + 4, _st()), 'rdfc_cross_entropy')
+    return out[0], out[1]
+
+
+def cross_entropy_backward(logits, labels, count, grad_out, ignore_index=-100, grad_scale=1.0):
+    """grad_out: device scalar (the cotangent of the loss) or None"""
+    N, H, W, Cc = logits.shape
+    dl = torch.empty(N, H, W, Cc, dtype=logits.dtype, device=logits.device)
+    if grad_out is not None:
+        grad_out = grad_out.to(torch.float32).contiguous()
+    _chk(lib().rdfc_cross_entropy_backward(_p(logits), _p(labels), N * H * W, Cc, ld(logits), dt(logits), ignore_index, _p(count),
+                                           _p(grad_out), _f(grad_scale), _p(dl), Cc, _st()), 'rdfc_cross_entropy_backward')
+    return dl
