@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_harness as rh                                   # noqa: E402
 from detweights import det_state_dict, det_tensor          # noqa: E402
-from cases import NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP, metric_case   # noqa: E402
+from cases import NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP, metric_case, label_net_weights, LABEL_CASE   # noqa: E402
 
 
 def save(name, **arrs):
@@ -207,6 +207,32 @@ def metric():
          per_image=np.array([[r[n] for n in names] for r in per_image], dtype=np.float64))
 
 
+def label_net(B, H, W, name):
+    """upstream's PSPNet (G_label) with the deterministic weights: eval logits, train-mode [out, aux] and the gradients of
+    a fixed linear functional of both.  Dropout2d is switched off (p = 0) in the reference instance: its mask comes from
+    the framework's RNG stream, which no other implementation can reproduce; the arithmetic around it is pinned."""
+    PSP = rh.real_pspnet()
+    net = PSP(LABEL_CASE['classes'])
+    net.load_state_dict(label_net_weights(net.state_dict()))
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+
+    class AsDict(torch.nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            self.n = n
+
+        def forward(self, x):
+            o = self.n(x)
+            return dict(out=o[0], aux=o[1]) if isinstance(o, list) else dict(out=o)
+
+    rgb = gen_inputs('label_net', B, H, W)[0]
+    fg = ('n.master_branch.1.weight', 'n.master_branch.1.bias', 'n.auxiliary_branch.4.weight', 'n.initial.0.0.weight',
+          'n.layer1.0.bn1.weight', 'n.layer3.5.bn3.bias')   # (not bottleneck.0.bias: in front of a BN its gradient is analytically 0)
+    save(name, **run_module(AsDict(net), (rgb,), name, full_grads=fg))
+
+
 JOBS = {
     'g_a2b_small': lambda: g_a2b(False, 2, 60, 76, 'g_a2b_small'),
     'g_a2b_nlspn_small': lambda: g_a2b(True, 2, 60, 76, 'g_a2b_nlspn_small'),
@@ -218,6 +244,7 @@ JOBS = {
     'losses': losses,
     'step_trace': step_trace,
     'metric': metric,
+    'label_net_small': lambda: label_net(LABEL_CASE['B'], LABEL_CASE['H'], LABEL_CASE['W'], 'label_net_small'),
 }
 
 if __name__ == '__main__':

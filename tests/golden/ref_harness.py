@@ -210,3 +210,16 @@ def ref_classes():
     from lib.models.discriminator.patch_gan_discriminator import PatchGANDiscriminator
     from lib.losses import gan_loss
     return RDFGenerator, ResnetGenerator, PatchGANDiscriminator, gan_loss
+
+
+def real_pspnet():
+    """upstream's own PSPNet class (install() leaves a constant-output stand-in under its module name for the step trace;
+    the label-net fixtures need the real one: lib/models/generator/label_net/labels_model.py:43-94)"""
+    install()
+    name = 'lib.models.generator.label_net.labels_model'
+    stub = sys.modules.pop(name)
+    try:
+        real = importlib.import_module(name)
+    finally:
+        sys.modules[name] = stub
+    return real.PSPNet

@@ -48,6 +48,9 @@ def from_pm(x_pm):
 
 CONV_CASES = [
     # N, H, W, Ci, Co, k, s, p
+    (2, 29, 38, 512, 14, 1, 1, 0),          # label net: class logits (labels_model.py:63,72)
+    (2, 20, 24, 3, 64, 3, 2, 1),            # label net: deep stem (backbone_resnet50.py:155)
+    (1, 9, 11, 4096, 512, 1, 1, 0),         # label net: pyramid bottleneck (labels_model.py:19)
     (2, 12, 14, 64, 64, 3, 1, 1),
     (2, 13, 15, 64, 128, 3, 2, 1),
     (1, 9, 11, 128, 256, 1, 2, 0),

@@ -193,3 +193,38 @@ def test_metric_matches_upstream(golden):
     np.testing.assert_allclose([plain[n] for n in om.NAMES], g['plain'], rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose([masked[n] for n in om.NAMES], g['masked'], rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(per, g['per_image'], rtol=2e-6, atol=1e-7)
+
+
+def test_label_net_matches_upstream(golden):
+    """oracle.label_net.PSPNet against upstream's own PSPNet (labels_model.py:43-94 over backbone_resnet50.py): same
+    state_dict keys, eval logits, train-mode [out, aux], input gradient, per-parameter gradient norms, BN buffers"""
+    from oracle.label_net import PSPNet
+    from cases import LABEL_CASE, gen_inputs, label_net_weights, out_weights
+    g = golden('label_net_small')
+    net = PSPNet(LABEL_CASE['classes'])
+    net.load_state_dict(label_net_weights(net.state_dict()))
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0                                     # as in the fixture (make_golden.label_net)
+    x = gen_inputs('label_net', LABEL_CASE['B'], LABEL_CASE['H'], LABEL_CASE['W'])[0]
+    net.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(net(x).numpy(), g['eval.out'], rtol=0, atol=1e-6)
+    net.train()
+    xr = x.clone().requires_grad_(True)
+    out, aux = net(xr)
+    np.testing.assert_allclose(out.detach().numpy(), g['train.out'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(aux.detach().numpy(), g['train.aux'], rtol=0, atol=2e-5)
+    ((out * out_weights('label_net_small', 'out', out.shape)).sum() + (aux * out_weights('label_net_small', 'aux', aux.shape)).sum()).backward()
+    scale = np.abs(g['grad_in.0']).max()
+    np.testing.assert_allclose(xr.grad.numpy(), g['grad_in.0'], rtol=0, atol=2e-3 * scale)
+    ref = dict(zip((str(n)[2:] for n in g['grad_names']), g['grad_summary'][:, 1]))      # fixture names carry the wrapper's 'n.'
+    got = {k: float(p.grad.double().norm()) for k, p in net.named_parameters()}
+    assert sorted(got) == sorted(ref)
+    floor = 1e-6 * max(ref.values())
+    for k, v in ref.items():
+        if v > floor:
+            assert abs(got[k] - v) <= 5e-3 * v, k
+    sd = net.state_dict()
+    for k, row in zip(g['buf_names'], g['buf_summary']):
+        assert abs(float(sd[str(k)[2:]].norm()) - row[1]) <= 1e-5 * abs(row[1]) + 1e-6, k
