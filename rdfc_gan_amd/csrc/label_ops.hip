@@ -326,6 +326,91 @@ __global__ void ce_bwd_kernel(const T *__restrict__ logits, const long long *__r
     }
 }
 
+
+// ---- nor_loss + manhattan_loss (lib/losses/gan_loss.py:122-132, 50-99): values of the four normal-consistency terms ------
+// normal / gt_normal: f32 [N][3][HW] (upstream NCHW), norm_mask f32 [N][HW] or NULL, logits f32 pixel-major [N*HW][C].
+// cosine_similarity as ATen computes it: (a / max(|a|, 1e-8)) . (b / max(|b|, 1e-8)).
+// manhattan_loss multiplies its per-image cosine map [B,H,W] with the unsqueezed class mask [B,1,H,W] (:73-74,83,93):
+// the product broadcasts to [B,B,H,W], i.e. image j's term at pixel p is counted once for every image i whose pixel p
+// has the class.  Reproduced as is: a thread owns one pixel POSITION p and walks the batch,
+//   sum_k += M_k(p) * sum_j t_kj(p),  count_k += M_k(p) * #{j : t_kj(p) != 0},   M_k(p) = #{i : class_i(p) == k},
+// with t_kj = 1 - cos_j inside image j's class-k mask and 1 - 0 outside it (floor / ceiling), 2 cos_j inside and 0
+// outside (wall).
+// sums (f64): 0 nor sum, 1 nor count, 2 floor sum, 3 floor count, 4 wall sum, 5 wall count, 6 ceiling sum, 7 ceiling count
+__global__ __launch_bounds__(NT) void normal_losses_kernel(const float *__restrict__ nrm, const float *__restrict__ gtn,
+                                                           const float *__restrict__ nmask, const float *__restrict__ logits, int N, int HW,
+                                                           int C, int ld, int wall, int floor_, int ceiling, double *__restrict__ partial) {
+// the reference multiplies, subtracts and compares in separately rounded steps ((1 - cos) != 0 decides the count)
+#pragma clang fp contract(off)
+    __shared__ double red[8][NT / 64];
+    double s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.0;
+    for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < (size_t)HW; p += (size_t)gridDim.x * NT) {
+        int M[3] = {0, 0, 0};                 // images whose pixel p is floor / wall / ceiling
+        float T[3] = {0.f, 0.f, 0.f};         // sum over images of the term
+        int Z[3] = {0, 0, 0};                 // images whose term is non-zero
+        for (int n = 0; n < N; ++n) {
+            const size_t i = (size_t)n * HW + p;
+            const float *a = nrm + (size_t)n * 3 * HW + p;
+            const float ax = a[0], ay = a[HW], az = a[2 * (size_t)HW];
+            const float an = fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-8f);
+            if (gtn != nullptr) {
+                const float *b = gtn + (size_t)n * 3 * HW + p;
+                const float bx = b[0], by = b[HW], bz = b[2 * (size_t)HW];
+                const float bn = fmaxf(sqrtf(bx * bx + by * by + bz * bz), 1e-8f);
+                const float dot = (ax / an) * (bx / bn) + (ay / an) * (by / bn) + (az / an) * (bz / bn);
+                const float m = nmask ? nmask[i] : 1.f;
+                const bool valid = m * (dot < 0.999f ? 1.f : 0.f) * (dot > -0.999f ? 1.f : 0.f) > 0.f;
+                const float v = valid ? (dot * -1.f) + 1.f : 0.f;
+                s[0] += (double)v;
+                s[1] += v != 0.f ? 1.0 : 0.0;
+            }
+            if (logits != nullptr) {
+                const float *z = logits + i * ld;
+                int best = 0;
+                float bz = z[0];
+                for (int c = 1; c < C; ++c) {
+                    const float v = z[c];
+                    if (v > bz) { bz = v; best = c; }
+                }
+                const float cy = ay / an;                              // cos with (0, 1, 0); (0, -1, 0): -cy
+                const float tf = ((best == floor_ ? cy : 0.f) * -1.f) + 1.f;
+                const float tw = (best == wall ? cy : 0.f) * 2.f;
+                const float tc = ((best == ceiling ? -cy : 0.f) * -1.f) + 1.f;
+                M[0] += best == floor_; M[1] += best == wall; M[2] += best == ceiling;
+                T[0] += tf; T[1] += fabsf(tw); T[2] += tc;
+                Z[0] += tf != 0.f; Z[1] += tw != 0.f; Z[2] += tc != 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            s[2 + 2 * k] += (double)M[k] * (double)T[k];
+            s[3 + 2 * k] += (double)M[k] * (double)Z[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double v = s[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double a = 0.0;
+        for (int w = 0; w < NT / 64; ++w) a += red[threadIdx.x][w];
+        partial[(size_t)blockIdx.x * 8 + threadIdx.x] = a;
+    }
+}
+
+__global__ void normal_losses_finalize_kernel(const double *__restrict__ partial, int nb, float *__restrict__ out) {
+    if (threadIdx.x < 4 && blockIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nb; ++k) { a += partial[(size_t)k * 8 + 2 * threadIdx.x]; b += partial[(size_t)k * 8 + 2 * threadIdx.x + 1]; }
+        out[threadIdx.x] = (float)((float)a / ((float)b + 1e-6f));
+    }
+}
+
 #define DISPATCH(dtype, ...)                                      \
     if ((dtype) == RDFC_BF16) { using T = bf16_t; __VA_ARGS__; } \
     else { using T = float; __VA_ARGS__; }
@@ -460,5 +545,20 @@ extern "C" int rdfc_cross_entropy_backward(const void *logits, const int64_t *la
                                        (const long long *)labels, P, C, ld, (long long)ignore_index, count, grad_scale_dev, grad_scale,
                                        (T *)dlogits, lddl));
     RDFC_LAUNCH_CHECK("rdfc_cross_entropy_backward");
+    return 0;
+}
+
+extern "C" int rdfc_normal_losses_nchunk(int P) { return (int)min((size_t)512, ((size_t)P + NT - 1) / NT); }
+
+extern "C" int rdfc_normal_losses(const float *normal, const float *gt_normal, const float *norm_mask, const float *logits, int N, int HW,
+                                  int C, int ld, int label_wall, int label_floor, int label_ceiling, double *partial, float *out4,
+                                  void *stream) {
+    RDFC_REQUIRE(normal && partial && out4 && (gt_normal || logits), "rdfc_normal_losses: null pointer");
+    RDFC_REQUIRE(N > 0 && HW > 0 && (logits == nullptr || (C > 0 && ld >= C)), "rdfc_normal_losses: bad shape");
+    const int nb = rdfc_normal_losses_nchunk(HW);
+    hipLaunchKernelGGL(normal_losses_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, normal, gt_normal, norm_mask, logits, N, HW, C, ld,
+                       label_wall, label_floor, label_ceiling, partial);
+    hipLaunchKernelGGL(normal_losses_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, out4);
+    RDFC_LAUNCH_CHECK("rdfc_normal_losses");
     return 0;
 }

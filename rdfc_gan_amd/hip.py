@@ -652,3 +652,24 @@ def cross_entropy_backward(logits, labels, count, grad_out, ignore_index=-100, g
     _chk(lib().rdfc_cross_entropy_backward(_p(logits), _p(labels), N * H * W, Cc, ld(logits), dt(logits), ignore_index, _p(count),
                                            _p(grad_out), _f(grad_scale), _p(dl), Cc, _st()), 'rdfc_cross_entropy_backward')
     return dl
+
+
+def normal_losses(normal, gt_normal, norm_mask, logits_nchw, label_wall, label_floor, label_ceiling):
+    """-> f32 [4] on the device: nor_loss, floor, wall, ceiling terms (unweighted).  logits_nchw: the label net's
+    [N,C,H,W] channels-last view (or None); normal / gt_normal [N,3,H,W] f32"""
+    normal = normal.contiguous().float()
+    N, _, H, W = normal.shape
+    gt = gt_normal.contiguous().float() if gt_normal is not None else None
+    m = None
+    if norm_mask is not None and gt is not None:
+        m = norm_mask.reshape(N, -1, H, W)[:, 0].contiguous().float()
+    z, Cc, ldz = None, 0, 0
+    if logits_nchw is not None:
+        z = logits_nchw.detach().permute(0, 2, 3, 1)
+        assert z.dtype == torch.float32 and z.shape[:3] == (N, H, W)
+        Cc, ldz = z.shape[3], ld(z)
+    partial = torch.empty(8 * lib().rdfc_normal_losses_nchunk(H * W), dtype=torch.float64, device=normal.device)
+    out = torch.empty(4, dtype=torch.float32, device=normal.device)
+    _chk(lib().rdfc_normal_losses(_p(normal), _p(gt), _p(m), _p(z), N, H * W, Cc, ldz, label_wall, label_floor, label_ceiling,
+                                  _p(partial), _p(out), _st()), 'rdfc_normal_losses')
+    return out

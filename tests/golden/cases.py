@@ -119,3 +119,17 @@ def label_net_weights(template):
 
 
 LABEL_CASE = dict(B=4, H=48, W=64, classes=14)
+
+
+def normal_loss_case(B=3, H=30, W=38, seed=31, classes=14):
+    """predicted / ground-truth unit normals, a normal mask and class logits for nor_loss / manhattan_loss.  A patch of
+    predictions equals the ground truth (cos = 1: excluded by the 0.999 rule) and a patch faces exactly (0, 1, 0) (a floor
+    pixel whose 1 - cos is exactly 0 is not counted by upstream's `!= 0`)."""
+    pred = unit_normals(seed, 'nl.pred', B, H, W)
+    gt = unit_normals(seed, 'nl.gt', B, H, W)
+    pred[:, :, :4, :6] = gt[:, :, :4, :6]
+    pred[:, :, 10:14, 10:20] = torch.tensor([0.0, 1.0, 0.0]).view(1, 3, 1, 1)
+    mask = (det_tensor(seed, 'nl.mask', (B, 1, H, W), 'rand') > 0.2).float()
+    logits = _smooth(det_tensor(seed, 'nl.logits', (B, classes, H, W)), 3) * 4
+    logits[:, 5, 9:16, 8:24] += 3.0                                   # a floor region over the exact-up patch
+    return pred, gt, mask, logits

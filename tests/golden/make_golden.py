@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_harness as rh                                   # noqa: E402
 from detweights import det_state_dict, det_tensor          # noqa: E402
-from cases import NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP, metric_case, label_net_weights, LABEL_CASE   # noqa: E402
+from cases import normal_loss_case, NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP, metric_case, label_net_weights, LABEL_CASE   # noqa: E402
 
 
 def save(name, **arrs):
@@ -233,6 +233,18 @@ def label_net(B, H, W, name):
     save(name, **run_module(AsDict(net), (rgb,), name, full_grads=fg))
 
 
+def normal_losses():
+    """upstream's nor_loss / manhattan_loss (lib/losses/gan_loss.py:122-132, 50-99) with RDFCGAN's label ids (rdfc_gan.py:32-34)"""
+    _, _, _, gl = rh.ref_classes()
+    pred, gt, mask, logits = normal_loss_case()
+    res = dict(nor=gl.nor_loss(pred, gt, mask), nor_nomask=gl.nor_loss(pred, gt, torch.ones_like(mask)))
+    f, w, c = gl.manhattan_loss(pred, logits, mask, 12, 5, 3, 100.0)
+    res.update(floor=f, wall=w, ceiling=c)
+    f2, w2, c2 = gl.manhattan_loss(pred, logits, mask, 12, 5, 99, 100.0)     # no pixel of class 99: python 0.0 * weight
+    res.update(ceiling_absent=np.float32(c2), classes_present=np.bincount(logits.argmax(1).flatten().numpy(), minlength=14))
+    save('normal_losses', **res)
+
+
 JOBS = {
     'g_a2b_small': lambda: g_a2b(False, 2, 60, 76, 'g_a2b_small'),
     'g_a2b_nlspn_small': lambda: g_a2b(True, 2, 60, 76, 'g_a2b_nlspn_small'),
@@ -244,6 +256,7 @@ JOBS = {
     'losses': losses,
     'step_trace': step_trace,
     'metric': metric,
+    'normal_losses': normal_losses,
     'label_net_small': lambda: label_net(LABEL_CASE['B'], LABEL_CASE['H'], LABEL_CASE['W'], 'label_net_small'),
 }
 

@@ -122,3 +122,25 @@ def test_bad_arguments_are_reported():
         h.maxpool2d(x, 3, 2, 1)
     with pytest.raises(RuntimeError, match='bad shape'):
         h.cross_entropy(torch.zeros(1, 2, 2, 5000, device=DEV), torch.zeros(1, 2, 2, dtype=torch.int64, device=DEV))
+
+
+def test_normal_losses_against_upstream_fixture_and_oracle(golden):
+    """rdfc_normal_losses: nor_loss + manhattan_loss values (gan_loss.py:122-132, 50-99) against the fixture from upstream's
+    functions and, on a full-size batch, against the oracle"""
+    from oracle import losses as ol
+    from cases import normal_loss_case
+    import numpy as np
+    h = hip()
+    g = golden('normal_losses')
+    pred, gt, mask, logits = normal_loss_case()
+    z = logits.permute(0, 2, 3, 1).contiguous().to(DEV).permute(0, 3, 1, 2)          # the label net's channels-last view
+    out = h.normal_losses(pred.to(DEV), gt.to(DEV), mask.to(DEV), z, 12, 5, 3).cpu().numpy()
+    np.testing.assert_allclose(out * [1, 100, 100, 100], [g['nor'], g['floor'], g['wall'], g['ceiling']], rtol=3e-6)
+    out = h.normal_losses(pred.to(DEV), gt.to(DEV), None, z, 12, 5, 99).cpu().numpy()
+    np.testing.assert_allclose(out[0], g['nor_nomask'], rtol=3e-6)
+    assert out[3] == 0.0                                                              # no pixel of that class
+    pred, gt, mask, logits = normal_loss_case(B=8, H=228, W=304, seed=32)
+    z = logits.permute(0, 2, 3, 1).contiguous().to(DEV).permute(0, 3, 1, 2)
+    out = h.normal_losses(pred.to(DEV), gt.to(DEV), mask.to(DEV), z, 12, 5, 3).cpu().numpy()
+    f, w, c = ol.manhattan_loss(pred, logits, 12, 5, 3, 1.0)
+    np.testing.assert_allclose(out, [float(ol.nor_loss(pred, gt, mask)), float(f), float(w), float(c)], rtol=2e-5)

@@ -228,3 +228,16 @@ def test_label_net_matches_upstream(golden):
     sd = net.state_dict()
     for k, row in zip(g['buf_names'], g['buf_summary']):
         assert abs(float(sd[str(k)[2:]].norm()) - row[1]) <= 1e-5 * abs(row[1]) + 1e-6, k
+
+
+def test_normal_losses_match_upstream(golden):
+    """oracle.losses.nor_loss / manhattan_loss against upstream's (lib/losses/gan_loss.py:122-132, 50-99)"""
+    from oracle import losses as ol
+    from cases import normal_loss_case
+    g = golden('normal_losses')
+    pred, gt, mask, logits = normal_loss_case()
+    assert abs(float(ol.nor_loss(pred, gt, mask)) - float(g['nor'])) < 1e-6
+    assert abs(float(ol.nor_loss(pred, gt, torch.ones_like(mask))) - float(g['nor_nomask'])) < 1e-6
+    f, w, c = ol.manhattan_loss(pred, logits, 12, 5, 3, 100.0)
+    np.testing.assert_allclose([float(f), float(w), float(c)], [g['floor'], g['wall'], g['ceiling']], rtol=2e-6)
+    assert float(ol.manhattan_loss(pred, logits, 12, 5, 99, 100.0)[2]) == float(g['ceiling_absent']) == 0.0
