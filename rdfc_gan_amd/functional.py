@@ -573,3 +573,9 @@ class _CrossEntropy(torch.autograd.Function):
 def cross_entropy(logits, labels, ignore_index=-100):
     """torch.nn.CrossEntropyLoss()(logits, labels) with pixel-major logits [N,H,W,C]"""
     return _CrossEntropy.apply(logits, labels, ignore_index)
+
+
+def cross_entropy_nchw(logits_nchw, labels, ignore_index=-100):
+    """the label net hands out upstream's [N, classes, H, W] shape as a view of its pixel-major map: undo the view (no copy)"""
+    z = logits_nchw.permute(0, 2, 3, 1)
+    return cross_entropy(z if z.is_contiguous() else z.contiguous(), labels, ignore_index)

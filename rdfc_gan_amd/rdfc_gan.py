@@ -84,8 +84,13 @@ def _cfg_get(node, key, default=None):
 class RDFCGAN:
     def __init__(self, device, distributed, args, is_train=True, fixed_training_samples=None, fixed_testing_samples=None,
                  num_classes=14, out_height=224, out_width=304, label_wall=12, label_floor=5, label_ceiling=3,
-                 normal_provider=None, exact_schedule=False, compute_dtype=None):
+                 normal_provider=None, exact_schedule=False, compute_dtype=None, use_label_net=False):
         self.device, self.distributed, self.args, self.is_train = device, distributed, args, is_train
+        # G_label and the label / normal-consistency terms of loss_G (rdfc_gan.py:89,187-203,238-267): off by default -- the
+        # benchmarked hot path is the four-network step; on, the step computes upstream's full objective except that the
+        # surface normals still come from `normal_provider` / the batch (G_normal is not part of this build)
+        self.use_label_net = bool(use_label_net)
+        self.num_classes, self.label_wall, self.label_floor, self.label_ceiling = num_classes, label_wall, label_floor, label_ceiling
         self.local_rank = _cfg_get(args, 'local_rank', 0)
         self.out_height, self.out_width = out_height, out_width
         self.normal_provider = normal_provider
@@ -111,6 +116,10 @@ class RDFCGAN:
         for net in (self.G_A2B, self.G_B2A, self.disc_A, self.disc_B):
             init_weights(net, verbose=False)
         self.models = dict(G_A2B=self.G_A2B, G_B2A=self.G_B2A, disc_A=self.disc_A, disc_B=self.disc_B)
+        if self.use_label_net:
+            from .label_net import PSPNet
+            self.G_label = PSPNet(self.num_classes).to(self.device)              # rdfc_gan.py:89
+            self.models['G_label'] = self.G_label
         if self.distributed:
             # DDP-constructor semantics without DDP: same start on every rank; gradients are
             # exchanged by FlatAdam.all_reduce_grads_async (one bucket per optimizer)
@@ -122,6 +131,9 @@ class RDFCGAN:
         self.optimizer_G = FlatAdam(itertools.chain(self.G_A2B.parameters(), self.G_B2A.parameters()), lr=lr, betas=betas)
         self.optimizer_D = FlatAdam(itertools.chain(self.disc_A.parameters(), self.disc_B.parameters()), lr=lr, betas=betas)
         self.optimizers = dict(G=self.optimizer_G, D=self.optimizer_D)
+        if self.use_label_net:
+            self.optimizer_Label = FlatAdam(self.G_label.parameters(), lr=lr, betas=betas)   # rdfc_gan.py:145-147
+            self.optimizers['label'] = self.optimizer_Label
 
     def init_lr_scheduler(self):
         a = self.args
@@ -138,6 +150,9 @@ class RDFCGAN:
             raise NotImplementedError
         self.lr_scheduler_G, self.lr_scheduler_D = make(self.optimizer_G), make(self.optimizer_D)
         self.lr_schedulers = dict(G=self.lr_scheduler_G, D=self.lr_scheduler_D)
+        if self.use_label_net:
+            self.lr_scheduler_Label = make(self.optimizer_Label)
+            self.lr_schedulers['label'] = self.lr_scheduler_Label
 
     # ---- data ------------------------------------------------------------------------------------
     def set_input(self, data):
@@ -149,6 +164,9 @@ class RDFCGAN:
         self.gt_normal = data['gt_normal'].to(dev) if 'gt_normal' in data else None
         self.mask = data['depth_masks'].to(dev) if 'depth_masks' in data else torch.ones_like(self.real_B)
         self.image_loss_weight = self.mask / (self.mask.sum() + 1e-6)
+        if self.use_label_net:
+            self.gt_label = data['labels'].to(dev)                               # rdfc_gan.py set_input: labels, normal_masks
+            self.norm_mask = data['normal_masks'].to(dev) if 'normal_masks' in data else None
         self._batch = data
 
     def _set_input_static(self, data):
@@ -188,7 +206,10 @@ class RDFCGAN:
             self.gt_normal = kwargs['gt_normal'].to(self.device)
         pred_normal = self._normal('real_A', rgb)
         ret = self.G_A2B(rgb, raw, pred_normal)
-        return dict(pred_depth=ret['pred_depth'], pred_normal=pred_normal)
+        out = dict(pred_depth=ret['pred_depth'], pred_normal=pred_normal)
+        if self.use_label_net:
+            out['pred_label'] = self.G_label(rgb)
+        return out
 
     def __call__(self, **kwargs):
         return self.forward_test(**kwargs)
@@ -205,7 +226,10 @@ class RDFCGAN:
 
     def forward(self):
         hip.reset_sums(self.device)         # zeroed f64 scratch of the one-stage normalisation reductions: rewound per step
-        self.fake_B = self.G_A2B(self.real_A, self.aux_A, self._normal('real_A', self.real_A))['pred_depth']
+        self.fake_normal_realA = self._normal('real_A', self.real_A)
+        if self.use_label_net:
+            self.fake_label_realA_list = self.G_label(self.real_A)               # :187
+        self.fake_B = self.G_A2B(self.real_A, self.aux_A, self.fake_normal_realA)['pred_depth']
         if getattr(self, '_graph_mode', False):
             # host RNG draw happened before the replay (_draw_pepper_static); an all-zero mask is the "no noise" draw
             self.fake_B = _PepperNoise.apply(self.fake_B, self._pepper_static)
@@ -219,6 +243,8 @@ class RDFCGAN:
         with self._net_stream_ctx():                                             # B->A does not depend on A->B: own stream
             self.fake_A = self.G_B2A(self.real_B)
             self.fake_normal_fakeA = self._normal('fake_A', self.fake_A)
+            if self.use_label_net:
+                self.fake_label_fakeA_list = self.G_label(self.fake_A)           # :201 (its loss reaches G_B2A through fake_A)
         if self.exact_schedule:
             with torch.no_grad():
                 self.G_A2B(self.fake_A, self.aux_A, self.fake_normal_fakeA)      # dead forward (:207)
@@ -262,16 +288,37 @@ class RDFCGAN:
             finally:
                 layers.BN_STAT_REPEAT = 1
             loss_cycle_B2A = self.criterionCycle(rec_B, self.real_B, weight=self.image_loss_weight) * lam_B
+            extra_B = self._label_and_normal_terms('B2A', self.fake_label_fakeA_list, self.fake_normal_fakeA, lam_1) \
+                if self.use_label_net else {}
         loss_G_A2B = self.criterionGAN(self.disc_A(self.fake_B), True)
         loss_A2B_L1 = self.criterionL1(self.fake_B, self.real_B, weight=self.image_loss_weight) * lam_1 * 5
         rec_A = self.G_B2A(self.fake_B)
         loss_cycle_A2B = self.criterionCycle(rec_A, self.real_A) * lam_A
-        self._join_net_stream((loss_G_B2A, loss_B2A_L1, loss_cycle_B2A))
+        extra_A = self._label_and_normal_terms('A2B', self.fake_label_realA_list, self.fake_normal_realA, lam_1) \
+            if self.use_label_net else {}
+        self._join_net_stream((loss_G_B2A, loss_B2A_L1, loss_cycle_B2A) + tuple(extra_B.values()))
         loss_G = loss_G_A2B + loss_cycle_A2B + loss_cycle_B2A + loss_G_B2A + loss_A2B_L1 + loss_B2A_L1
+        for v in list(extra_A.values()) + list(extra_B.values()):               # :252-267
+            loss_G = loss_G + v
         loss_G.backward()
-        return dict(loss_G=loss_G, loss_G_A2B=loss_G_A2B, loss_G_B2A=loss_G_B2A, loss_B2A_L1=loss_B2A_L1,
-                    loss_A2B_L1=loss_B2A_L1,          # upstream logs B2A under this key (rdfc_gan.py:276)
-                    loss_cycle_A=loss_cycle_A2B, loss_cycle_B=loss_cycle_B2A)
+        stats = dict(loss_G=loss_G, loss_G_A2B=loss_G_A2B, loss_G_B2A=loss_G_B2A, loss_B2A_L1=loss_B2A_L1,
+                     loss_A2B_L1=loss_B2A_L1,          # upstream logs B2A under this key (rdfc_gan.py:276)
+                     loss_cycle_A=loss_cycle_A2B, loss_cycle_B=loss_cycle_B2A)
+        stats.update(extra_A)
+        stats.update(extra_B)
+        return stats
+
+    def _label_and_normal_terms(self, tag, label_list, normal, lam_1):
+        """rdfc_gan.py:238-250 for one direction: cross entropy of the label net's two heads (aux x 0.4), nor_loss x 2 and the
+        three manhattan terms, all x lambda_L1.  The normal terms are values only: normals are an input here."""
+        ce = Fh.cross_entropy_nchw
+        loss_label = (ce(label_list[0], self.gt_label) + ce(label_list[1], self.gt_label) * 0.4) * lam_1
+        if normal.requires_grad:
+            raise NotImplementedError('nor_loss / manhattan_loss are computed without a gradient path to the normals')
+        v = hip.normal_losses(normal, self.gt_normal, self.norm_mask, label_list[0], self.label_wall, self.label_floor,
+                              self.label_ceiling)
+        return {f'loss_label_{tag}': loss_label, f'loss_normal_{tag}': v[0] * (lam_1 * 2), f'floor_loss_{tag}': v[1] * lam_1,
+                f'wall_loss_{tag}': v[2] * lam_1, f'ceiling_loss_{tag}': v[3] * lam_1}
 
     def backward_D_basic(self, model_D, real, fake):
         loss_D_real = self.criterionGAN(model_D(real), True)
@@ -291,6 +338,8 @@ class RDFCGAN:
     # ---- HIP-graph mode: the step is captured once as three graphs (G step | D step | Adam) and replayed; the
     #      data-parallel all-reduces stay eager between them, the host only draws the pepper mask and copies the batch in
     def enable_graph(self, enabled=True):
+        if enabled and self.use_label_net:
+            raise NotImplementedError('graph mode captures the four-network step only')
         self._graph_mode = bool(enabled)
         self._graphs = None
         Fh.set_multi_stream(not enabled)        # the capture is single-stream; the eager step spreads over four streams
@@ -424,9 +473,13 @@ class RDFCGAN:
         self.forward()
         self.set_requires_grad([self.disc_A, self.disc_B], False)
         self.optimizer_G.zero_grad()
+        if self.use_label_net:
+            self.optimizer_Label.zero_grad()
         loss_stats.update(self.backward_G())
         # G gradients fly over xGMI on the side stream while the D step computes
         self.optimizer_G.all_reduce_grads_async()
+        if self.use_label_net:
+            self.optimizer_Label.all_reduce_grads_async()
         self.set_requires_grad([self.disc_A, self.disc_B], True)
         self.optimizer_D.zero_grad()
         with self._net_stream_ctx():                  # the two discriminators are independent: D_B's step on the second stream
@@ -436,6 +489,8 @@ class RDFCGAN:
         loss_stats.update(stats_DB)
         self.optimizer_D.all_reduce_grads_async()
         self.optimizer_G.step()
+        if self.use_label_net:
+            self.optimizer_Label.step()
         self.optimizer_D.step()
         return self.reduce_loss(loss_stats) if sync_losses else loss_stats
 

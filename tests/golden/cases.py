@@ -133,3 +133,12 @@ def normal_loss_case(B=3, H=30, W=38, seed=31, classes=14):
     logits = _smooth(det_tensor(seed, 'nl.logits', (B, classes, H, W)), 3) * 4
     logits[:, 5, 9:16, 8:24] += 3.0                                   # a floor region over the exact-up patch
     return pred, gt, mask, logits
+
+
+def step_batch_label(it, B, H, W, classes=14):
+    """step_batch with real label maps (blocky, every class present) and a normal mask with holes"""
+    data, nA, nfA = step_batch(it, B, H, W)
+    z = _smooth(det_tensor(40 + it, 'step.labels', (B, classes, H, W)), 7)
+    data['labels'] = z.argmax(1)
+    data['normal_masks'] = (det_tensor(40 + it, 'step.nmask', (B, 1, H, W), 'rand') > 0.15).float()
+    return data, nA, nfA

@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_harness as rh                                   # noqa: E402
 from detweights import det_state_dict, det_tensor          # noqa: E402
-from cases import normal_loss_case, NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP, metric_case, label_net_weights, LABEL_CASE   # noqa: E402
+from cases import step_batch_label, normal_loss_case, NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP, metric_case, label_net_weights, LABEL_CASE   # noqa: E402
 
 
 def save(name, **arrs):
@@ -141,12 +141,18 @@ class _Node(dict):
     __getattr__ = dict.__getitem__
 
 
-def step_trace(nsteps=2):
+def step_trace(nsteps=2, label=False):
     """Run upstream RDFCGAN.optimize_parameters itself (NNET / PSPNet replaced by
-    constant stand-ins) and record the loss dict + weight / BN-buffer checksums."""
+    constant stand-ins) and record the loss dict + weight / BN-buffer checksums.
+    label=True: G_label is upstream's real PSPNet (Dropout2d off, see label_net()), the batch carries label maps and a
+    normal mask, and every entry of the loss dict is recorded -> step_trace_label.npz."""
     rh.install()
+    import lib.models.rdfc_gan as ref_mod
     from lib.models.rdfc_gan import RDFCGAN
     from lib.models.generator.normal_net.NNET import NNET
+    stub_psp = ref_mod.PSPNet
+    if label:
+        ref_mod.PSPNet = rh.real_pspnet()
     hp = STEP_HP
     model_cfg = _Node(
         G_A2B=dict(type='RDFGenerator', pretrained_on_imagenet=False),
@@ -158,31 +164,40 @@ def step_trace(nsteps=2):
                  lambda_A=hp['lambda_A'], lambda_B=hp['lambda_B'], lambda_L1=hp['lambda_L1'], optimizer='adam')
     m = RDFCGAN(device=torch.device('cpu'), distributed=False, args=args, is_train=True,
                 out_height=hp['H'], out_width=hp['W'])
-    for key, net in (('G_A2B', m.G_A2B), ('G_B2A', m.G_B2A), ('disc_A', m.disc_A), ('disc_B', m.disc_B)):
+    ref_mod.PSPNet = stub_psp
+    nets = [('G_A2B', m.G_A2B), ('G_B2A', m.G_B2A), ('disc_A', m.disc_A), ('disc_B', m.disc_B)]
+    for key, net in nets:
         net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    if label:
+        m.G_label.load_state_dict(label_net_weights(m.G_label.state_dict()))
+        for mod in m.G_label.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        nets.append(('G_label', m.G_label))
     m.train()
     res = {}
     for it in range(nsteps):
-        data, normal_A, normal_fA = step_batch(it, hp['B'], hp['H'], hp['W'])
+        data, normal_A, normal_fA = (step_batch_label if label else step_batch)(it, hp['B'], hp['H'], hp['W'])
         pad = torch.zeros(hp['B'], 1, hp['H'], hp['W'])
         NNET.queue[:] = [torch.cat([normal_A, pad], 1), torch.cat([normal_fA, pad], 1), torch.cat([normal_fA, pad], 1)]
         random.seed(100 + it)
         np.random.seed(100 + it)
         m.set_input(data)
         ls = m.optimize_parameters()
-        keys = sorted(k for k in ls if not any(s in k for s in ('label', 'normal', 'floor', 'wall', 'ceiling')))
+        aux_terms = () if label else ('label', 'normal', 'floor', 'wall', 'ceiling')
+        keys = sorted(k for k in ls if not any(s in k for s in aux_terms))
         res[f'loss_names.{it}'] = np.array(keys)
         res[f'loss_values.{it}'] = np.array([ls[k] for k in keys], dtype=np.float64)
-        extra = sum(ls[k] for k in ls if any(s in k for s in ('label', 'normal', 'floor', 'wall', 'ceiling')))
+        extra = sum(ls[k] for k in ls if any(s in k for s in aux_terms))
         res[f'loss_extra.{it}'] = np.float64(extra)
-        for key, net in (('G_A2B', m.G_A2B), ('G_B2A', m.G_B2A), ('disc_A', m.disc_A), ('disc_B', m.disc_B)):
+        for key, net in nets:
             sd = net.state_dict()
             names = [k for k in sd if not k.endswith('num_batches_tracked')]
             res[f'sd_names.{key}'] = np.array(names)
             res[f'sd_summary.{key}.{it}'] = np.array([[float(sd[k].double().sum()), float(sd[k].double().norm())] for k in names])
         res[f'fake_B.{it}'] = m.fake_B.detach().clone()
         res[f'fake_A.{it}'] = m.fake_A.detach().clone()
-    save('step_trace', **res)
+    save('step_trace_label' if label else 'step_trace', **res)
 
 
 def metric():
@@ -257,6 +272,7 @@ JOBS = {
     'step_trace': step_trace,
     'metric': metric,
     'normal_losses': normal_losses,
+    'step_trace_label': lambda: step_trace(2, label=True),
     'label_net_small': lambda: label_net(LABEL_CASE['B'], LABEL_CASE['H'], LABEL_CASE['W'], 'label_net_small'),
 }
 

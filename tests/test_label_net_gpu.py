@@ -76,3 +76,50 @@ def test_label_net_argmax_agreement_full_resolution():
     decided = (top2[:, 0] - top2[:, 1]) > 0.05 * float(want.abs().max())          # pixels whose winner is not a near-tie
     agree = (got.argmax(1) == want.argmax(1))[decided].float().mean()
     assert float(agree) > 0.995 and float(decided.float().mean()) > 0.5
+
+
+def test_train_step_with_label_net_against_upstream_trace(golden):
+    """Two steps of RDFCGAN(use_label_net=True), f32 mode, against upstream's own optimize_parameters with its real PSPNet
+    (tests/golden/step_trace_label.npz): every entry of the loss dict -- label cross entropies, nor_loss and the three
+    manhattan terms included -- the fake images and the weights of all five networks."""
+    import random
+    from cases import STEP_HP, noise_driven, step_batch_label
+    from detweights import det_state_dict
+    from rdfc_gan_amd import functional as Fh
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    from test_modules_gpu import _step_cfg
+    setup_dtype(torch.float32)
+    g = golden('step_trace_label')
+    hp = STEP_HP
+    cfg = _step_cfg(hp)
+    cfg.update(scheduler='linear', epoch=0, decay_epoch=100, n_epochs=150, lambda_A=hp['lambda_A'], lambda_B=hp['lambda_B'],
+               lambda_L1=hp['lambda_L1'])
+    normals = {}
+    m = RDFCGAN(torch.device(DEV), False, cfg, is_train=True, use_label_net=True, normal_provider=lambda tag, img: normals[tag])
+    for key, net in m.models.items():
+        net.load_state_dict(label_net_weights(net.state_dict()) if key == 'G_label' else det_state_dict(net.state_dict(), 0))
+    for mod in m.G_label.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    Fh.invalidate_packed_weights()
+    m.train()
+    for it in range(2):
+        data, nA, nfA = step_batch_label(it, hp['B'], hp['H'], hp['W'])
+        normals.update(real_A=nA.to(DEV), fake_A=nfA.to(DEV), fake_A_again=nfA.to(DEV))
+        random.seed(100 + it)
+        np.random.seed(100 + it)
+        m.set_input(data)
+        ls = m.optimize_parameters()
+        ref = dict(zip((str(k) for k in g[f'loss_names.{it}']), g[f'loss_values.{it}']))
+        assert sorted(ls) == sorted(ref)
+        for k, v in ref.items():
+            # step 0 is a function of the inputs alone; afterwards Adam's first updates (~ lr * g / |g|) turn rounding-level
+            # gradient differences into lr-sized weight differences (same bounds as test_train_step_against_upstream_trace)
+            lim = 2e-3 * abs(v) + 1e-4 if it == 0 else 3e-2 * abs(v) + 2e-3
+            assert abs(ls[k] - v) <= lim, f'step {it} {k}: {ls[k]} vs {v}'
+        for key, net in m.models.items():
+            sd = net.state_dict()
+            keep = [i for i, k in enumerate(g[f'sd_names.{key}']) if not noise_driven(key, str(k))
+                    and not (key == 'G_label' and str(k).endswith('bottleneck.0.bias'))]      # bias in front of a BN: zero gradient
+            got = np.array([float(sd[k].double().norm()) for k in g[f'sd_names.{key}']])
+            np.testing.assert_allclose(got[keep], g[f'sd_summary.{key}.{it}'][keep, 1], rtol=5e-3, atol=2e-4, err_msg=f'step {it} {key}')
