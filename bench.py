@@ -28,17 +28,18 @@ for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
         sys.path.insert(0, p)
 
 # forward GFLOP per pair (2*MAC over conv / conv-transpose / linear) at 228x304
-GFLOP_FWD = dict(G_A2B=209.64, G_B2A=73.28, D_A=6.49, D_B=6.56)
+GFLOP_FWD = dict(G_A2B=209.64, G_B2A=73.28, D_A=6.49, D_B=6.56, G_label=72.49)   # G_label: train mode, both heads
 PEAK_TFLOPS = dict(bf16=2500.0, f32=157.3)        # dense MFMA peaks, MI355X_MICROARCH.md
 
 
-def step_gflop_per_pair(exact_schedule, scale=1.0):
+def step_gflop_per_pair(exact_schedule, scale=1.0, label_net=False):
     """G nets: fwd x3 (x2 when the dead forwards are elided) + bwd x2 (bwd = 2x fwd);
-    D nets: fwd x3 + input-gradient-only pass x1 + full bwd x2."""
+    D nets: fwd x3 + input-gradient-only pass x1 + full bwd x2; G_label (--label-net): fwd x2 + bwd x2."""
     nf = 3 if exact_schedule else 2
     g = (GFLOP_FWD['G_A2B'] + GFLOP_FWD['G_B2A']) * (nf + 2 * 2)
     d = (GFLOP_FWD['D_A'] + GFLOP_FWD['D_B']) * (3 + 1 + 2 * 2)
-    return (g + d) * scale
+    lab = GFLOP_FWD['G_label'] * (2 + 2 * 2) if label_net else 0.0
+    return (g + d + lab) * scale
 
 
 def synth_batch(B, H, W, seed, device):
@@ -56,7 +57,8 @@ def synth_batch(B, H, W, seed, device):
             raw[b, :, y0:y0 + hh, x0:x0 + ww] = -1.0
     normal = F.normalize(torch.randn(B, 3, H, W, generator=g), dim=1)
     data = dict(rgb=rgb, gt_depth=gt, raw_depth=raw, depth_masks=m > 1e-4, gt_normal=normal,
-                labels=torch.zeros(B, H, W, dtype=torch.long), normal_masks=torch.ones(B, 1, H, W))
+                labels=torch.randint(0, 14, (B, H // 12 + 1, W // 12 + 1), generator=g).repeat_interleave(12, 1).repeat_interleave(12, 2)[:, :H, :W]
+                .contiguous(), normal_masks=torch.ones(B, 1, H, W))
     return {k: v.to(device) for k, v in data.items()}
 
 
@@ -107,6 +109,8 @@ def main():
     ap.add_argument('--dtype', choices=('bf16', 'f32'), default='bf16')
     ap.add_argument('--nlspn', action='store_true', help='BASELINE configs[2]: NLSPN refinement on')
     ap.add_argument('--exact-schedule', action='store_true', help="run upstream's two dead forwards too")
+    ap.add_argument('--label-net', action='store_true', help='SURVEY 8f rank 1 (not the headline workload): G_label (PSPNet) twice '
+                    'per step + label cross entropy + normal-consistency terms + its Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the step into HIP graphs and replay them (single stream; on ROCm 7.2 the '
@@ -133,7 +137,7 @@ def main():
     torch.manual_seed(0)
     random.seed(1234 + rank)
     np.random.seed(1234 + rank)
-    model = RDFCGAN(dev, world > 1, model_cfg(a.nlspn), is_train=True, exact_schedule=a.exact_schedule)
+    model = RDFCGAN(dev, world > 1, model_cfg(a.nlspn), is_train=True, exact_schedule=a.exact_schedule, use_label_net=a.label_net)
     model.train()
     batches = [synth_batch(a.batch, a.height, a.width, 1234 + rank * 100 + i, dev) for i in range(2)]
 
@@ -201,13 +205,13 @@ def main():
 
     if rank == 0:
         scale = (a.height * a.width) / (228.0 * 304.0)
-        gflop_pair = step_gflop_per_pair(a.exact_schedule, scale)
+        gflop_pair = step_gflop_per_pair(a.exact_schedule, scale, a.label_net)
         pairs_s = world * a.batch * a.steps / elapsed
         out = dict(metric='RGB-D pairs/sec per train step (G+D), NYUv2 304x228', value=round(pairs_s, 3), unit='pairs/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * elapsed / a.steps, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.dtype, data='synthetic',
                    config=dict(workload=f'RDFCGAN.optimize_parameters: G_A2B(RDFGenerator, NLSPN {"on" if a.nlspn else "off"}) + '
-                                        f'G_B2A(ResnetGenerator IN2d) + D_A + D_B (PatchGAN), fwd+bwd+Adam, {a.height}x{a.width}, '
+                                        f'G_B2A(ResnetGenerator IN2d) + D_A + D_B (PatchGAN){" + G_label (PSPNet-ResNet50) x2 + label / normal terms" if a.label_net else ""}, fwd+bwd+Adam, {a.height}x{a.width}, '
                                         f'batch {a.batch}/GPU, random-init weights',
                                global_batch=world * a.batch, parallelism=f'dp{world}',
                                dead_forwards='executed' if a.exact_schedule else 'elided (result-identical, see DESIGN.md)',
@@ -234,6 +238,17 @@ def main():
                                    avg_launch_us=round(1e6 * sec / n, 2),
                                    share_of_step=round(sec / (elapsed * ev_steps / a.steps), 4),
                                    event_steps=ev_steps)
+            # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from the
+            # committed rocprofv3 passes over this same command (tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
+            # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and only apply to the default workload
+            tfile = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            default_wl = (a.batch, a.height, a.width, a.dtype, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, 'bf16', False, False, False)
+            if default_wl and os.path.exists(tfile):
+                for k, v in json.load(open(tfile)).items():
+                    if top + '(' in k:
+                        out['roofline']['traffic'] = round(v['fetch_bytes'] + v['write_bytes'])
+                        out['roofline']['traffic_note'] = (f"bytes per launch (read {v['fetch_bytes'] / 1e6:.1f} MB + write {v['write_bytes'] / 1e6:.1f} MB), "
+                                                           'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_bench.sh (profiles/r01_pmc_traffic.json)')
             if iso:
                 ifl = sum(r[1] for r in iso if r[5] == top)
                 isec = sum(r[2].elapsed_time(r[3]) * 1e-3 for r in iso if r[5] == top)

@@ -62,6 +62,9 @@ class _PSPModule(nn.Module):
         size = f.shape[1:3]
         levels = [f]
         for b, st in zip(self.bin_sizes, self.stages):
+            if self.training and f.shape[0] * b * b == 1:          # what nn.BatchNorm2d raises upstream at batch size 1
+                raise ValueError(f'Expected more than 1 value per channel when training, got input size '
+                                 f'torch.Size([1, {st[1].out_channels}, 1, 1])')
             levels.append(Fh.interpolate_bilinear(run_conv(Fh.adaptive_avg_pool2d(f, b), st[1], st[2], st[3]), size))
         bt = self.bottleneck
         y = run_conv(torch.cat(levels, 3), bt[0], bt[1], bt[2])

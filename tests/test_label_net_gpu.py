@@ -123,3 +123,15 @@ def test_train_step_with_label_net_against_upstream_trace(golden):
                     and not (key == 'G_label' and str(k).endswith('bottleneck.0.bias'))]      # bias in front of a BN: zero gradient
             got = np.array([float(sd[k].double().norm()) for k in g[f'sd_names.{key}']])
             np.testing.assert_allclose(got[keep], g[f'sd_summary.{key}.{it}'][keep, 1], rtol=5e-3, atol=2e-4, err_msg=f'step {it} {key}')
+
+
+def test_label_net_batch_of_one_in_train_mode_raises_like_upstream():
+    """the 1x1 pyramid level leaves one value per channel: nn.BatchNorm2d refuses it in training mode (upstream's PSPNet
+    cannot train at batch size 1); eval mode works"""
+    net = build(torch.bfloat16)
+    x = gen_inputs('label_b1', 1, 48, 64)[0].to(DEV)
+    net.train()
+    with pytest.raises(ValueError, match='Expected more than 1 value per channel'):
+        net(x)
+    net.eval()
+    assert net(x).shape == (1, LABEL_CASE['classes'], 48, 64)
