@@ -130,6 +130,46 @@ __global__ void avgpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, i
     }
 }
 
+// large bins (the 1x1 .. 3x3 pyramid levels over a 29x38 map): one WAVE per (n, bin, channel vector), lanes stride the bin's
+// pixels and a butterfly adds the 64 partial sums -- the thread-per-output version walks up to 1102 pixels serially with 2 048
+// threads on the whole chip (169 us per call inside the label net, this one ~15 us)
+template <typename T>
+__global__ __launch_bounds__(NT) void avgpool_fwd_wave_kernel(const T *__restrict__ x, T *__restrict__ y, int N, int Hi, int Wi, int C, int ldx,
+                                                              int ldy, int Ho, int Wo) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * Ho * Wo * CV;
+    const int lane = threadIdx.x & 63;
+    for (size_t i = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); i < total; i += (size_t)gridDim.x * (NT / 64)) {
+        const int cv = (int)(i % CV);
+        size_t r = i / CV;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const int h0 = bin_start(oh, Ho, Hi), h1 = bin_end(oh, Ho, Hi), w0 = bin_start(ow, Wo, Wi), w1 = bin_end(ow, Wo, Wi);
+        const int bw = w1 - w0, area = (h1 - h0) * bw;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int q = lane; q < area; q += 64) {
+            const int h = h0 + q / bw, w = w0 + q % bw;
+            Vec16<T> xv;
+            xv.load(x + ((size_t)(n * Hi + h) * Wi + w) * ldx + cv * VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += xv.get(v);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            for (int off = 32; off > 0; off >>= 1) acc[v] += __shfl_xor(acc[v], off, 64);
+        if (lane == 0) {
+            Vec16<T> o;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o.set(v, acc[v] / (float)area);
+            o.store(y + ((size_t)(n * Ho + oh) * Wo + ow) * ldy + cv * VEC);
+        }
+    }
+}
+
 template <typename T>
 __global__ void avgpool_bwd_kernel(const T *__restrict__ dy, T *__restrict__ dx, int N, int Hi, int Wi, int C, int lddy, int lddx,
                                    int Ho, int Wo) {
@@ -237,6 +277,51 @@ __global__ void bilinear_bwd_kernel(const TO *__restrict__ dy, TI *__restrict__ 
             acc += wh * row;
         }
         Elem<TI>::st(dx + ((size_t)(n * Hi + h) * Wi + w) * lddx + c, acc);
+    }
+}
+
+// small sources (the pyramid levels: 1x1 .. 6x6 -> 29x38): one WAVE per (n, source pixel, channel vector); lanes stride the window
+// of output pixels that can touch the source pixel, butterfly at the end (thread-per-source-element: 282 us per call, 4 096 threads
+// walking up to 1102 outputs each)
+template <typename T>
+__global__ __launch_bounds__(NT) void bilinear_bwd_wave_kernel(const T *__restrict__ dy, T *__restrict__ dx, int N, int Hi, int Wi, int C, int lddy,
+                                                               int lddx, int Ho, int Wo) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int CV = C / VEC;
+    const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
+    const size_t total = (size_t)N * Hi * Wi * CV;
+    const int lane = threadIdx.x & 63;
+    for (size_t i = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); i < total; i += (size_t)gridDim.x * (NT / 64)) {
+        const int cv = (int)(i % CV);
+        size_t r = i / CV;
+        const int w = (int)(r % Wi); r /= Wi;
+        const int h = (int)(r % Hi);
+        const int n = (int)(r / Hi);
+        int oh0, oh1, ow0, ow1;
+        out_range(h, sh, Hi, Ho, oh0, oh1);
+        out_range(w, sw, Wi, Wo, ow0, ow1);
+        const int bw = ow1 - ow0 + 1, area = (oh1 - oh0 + 1) * bw;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int q = lane; q < area; q += 64) {
+            const int oh = oh0 + q / bw, ow = ow0 + q % bw;
+            const float wt = tap_weight(oh, h, sh, Hi) * tap_weight(ow, w, sw, Wi);
+            if (wt == 0.f) continue;
+            Vec16<T> dv;
+            dv.load(dy + ((size_t)(n * Ho + oh) * Wo + ow) * lddy + cv * VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += wt * dv.get(v);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            for (int off = 32; off > 0; off >>= 1) acc[v] += __shfl_xor(acc[v], off, 64);
+        if (lane == 0) {
+            Vec16<T> o;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o.set(v, acc[v]);
+            o.store(dx + ((size_t)(n * Hi + h) * Wi + w) * lddx + cv * VEC);
+        }
     }
 }
 
@@ -457,8 +542,13 @@ extern "C" int rdfc_adaptive_avgpool_forward(const void *x, void *y, int N, int 
     CHECK_VEC("rdfc_adaptive_avgpool_forward", dtype, C, ldx, ldy);
     RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && x && y, "rdfc_adaptive_avgpool_forward: bad arguments");
     const size_t total = (size_t)N * Ho * Wo * (C / (dtype == RDFC_BF16 ? 8 : 4));
-    DISPATCH(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)x, (T *)y, N, Hi,
-                                       Wi, C, ldx, ldy, Ho, Wo));
+    if ((Hi / Ho) * (Wi / Wo) >= 64) {         // wave per output vector
+        DISPATCH(dtype, hipLaunchKernelGGL(avgpool_fwd_wave_kernel<T>, dim3(nblk(total * 64)), dim3(NT), 0, (hipStream_t)stream, (const T *)x,
+                                           (T *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo));
+    } else {
+        DISPATCH(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)x, (T *)y, N,
+                                           Hi, Wi, C, ldx, ldy, Ho, Wo));
+    }
     RDFC_LAUNCH_CHECK("rdfc_adaptive_avgpool_forward");
     return 0;
 }
@@ -499,6 +589,13 @@ extern "C" int rdfc_bilinear_backward(const void *dy, void *dx, int N, int Hi, i
     const size_t total = (size_t)N * Hi * Wi * C;
     const dim3 g(nblk(total)), b(NT);
     hipStream_t st = (hipStream_t)stream;
+    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    if (!dy_f32 && C % vec == 0 && lddy % vec == 0 && lddx % vec == 0 && (Ho / Hi) * (Wo / Wi) >= 16) {      // wave per source vector
+        const dim3 gw(nblk(total / vec * 64));
+        DISPATCH(dtype, hipLaunchKernelGGL(bilinear_bwd_wave_kernel<T>, gw, b, 0, st, (const T *)dy, (T *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo));
+        RDFC_LAUNCH_CHECK("rdfc_bilinear_backward");
+        return 0;
+    }
     if (dtype == RDFC_BF16 && dy_f32)
         hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, float>), g, b, 0, st, (const float *)dy, (bf16_t *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo);
     else if (dtype == RDFC_BF16)
