@@ -56,11 +56,33 @@ __device__ inline void glds16(const void *gsrc, unsigned lds_base) {
 }
 template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TCO, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
+// Diagnostic build only (tools/glds_stamps.sh, -DRDFC_GLDS_STAMPS): s_memtime stamps of one workgroup's waves around the parts of
+// a phase, slab 2 of the K loop; no stamp executes in the shipped library.
+#ifdef RDFC_GLDS_STAMPS
+__device__ unsigned long long g_stamps[8][9][6];
+#define RDFC_STAMP(TAP, K)                                                                    \
+    if (stamp_on && cc == 2) {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sbuf[TAP][K])::"memory");   \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    }
+#else
+#define RDFC_STAMP(TAP, K)
+#endif
+
+// SPEC: NW consumer waves (fragment reads + MFMA + epilogue) plus NW producer waves that do nothing but issue the LDS-DMAs and
+// wait for them, and the consumers read phase p+1's fragments while phase p's MFMAs run (two register sets, no copies).
+// In-kernel stamps of the unspecialised kernel (tools/glds_stamps.sh, 256->256 @ 57x76, cycles per phase of a wave that
+// has its SIMD to itself): vmcnt wait 20, barrier 45, DMA issue 130 (2-3 pieces at ~55), fragment reads until the data
+// is back 125, 16 MFMAs 280 -- 600 in all, the matrix pipe busy 43 %.  Here a consumer's phase is barrier + MFMAs.
+template <int TCO, int NW, int NPROD = 0>
+__global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds_kernel(GParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
                                                                   const float *__restrict__ bias, void *__restrict__ yout,
                                                                   const bf16_t *__restrict__ zero, float *__restrict__ stats) {
-    constexpr int NT = NW * 64;
+    constexpr bool SPEC = NPROD > 0;
+    constexpr int NT = NW * 64;                                // threads the tile and the DMA piece numbering are laid out for
+    constexpr int VPW = SPEC ? NW / NPROD : 1;                 // DMA shares ("virtual waves") per issuing wave
+    static_assert(!SPEC || NW % NPROD == 0, "producer waves must split the DMA shares evenly");
     constexpr int WCO = TCO / 64, WPX = NW / WCO;              // waves along co / along pixel rows (64 co x 4 rows x 16 px each)
     constexpr int TR = 4 * WPX, PH = TR + 2, NPATCH = PH * PW; // tile rows, patch rows, patch pixels (180 / 324)
     constexpr int NPIECE = NPATCH * 4;                         // 16-byte pieces per slab
@@ -68,12 +90,19 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
     constexpr int NR = (NPIECE + NT - 1) / NT;                 // patch DMA rounds per slab (3 / 6)
     constexpr int NWP = TCO * 4 / NT;                          // weight DMAs per thread and tap (2 / 1)
     constexpr int WSLOT = TCO * BK * 2;                        // bytes per weight slot
-    constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + WRING * WSLOT;
+    constexpr int RING = SPEC ? 5 : WRING;                     // SPEC reads a phase's fragments one phase early: one more slot
+    constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + RING * WSLOT;
     static_assert(NR <= 6, "patch rounds must be issued at least three phases before the slab ends");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = SPEC && wave_all >= NW;
+    // consumers: `wave` places the wave in the output tile; a DMA-issuing wave (every wave, or producer pw) carries the shares
+    // dwave(v) = pw + v * NPROD of the NW-share piece numbering
+    const int wave = producer ? wave_all - NW : wave_all;
+    const int tid = (int)threadIdx.x;                            // (statistics epilogue, unspecialised kernel only)
+    auto dwave = [&](int v) { return SPEC ? wave + v * NPROD : wave; };
     const int co0 = blockIdx.y * TCO;
     // Workgroups are dealt to the 8 XCDs round-robin; renumber so that each XCD (own L2) gets a contiguous run of
     // tiles: neighbouring tiles share halo rows and then hit in the same L2.
@@ -92,48 +121,62 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
     const int ncc = p.Cin / BK;
 
     // ---- per-thread DMA sources (computed once) -------------------------------------------------------------
-    const bf16_t *psrc[NR];
-    int pstep[NR];
-    unsigned pdst[NR];                                           // wave-uniform LDS offset inside a patch buffer, or junk
+    const bf16_t *psrc[VPW][NR];
+    int pstep[VPW][NR];
+    unsigned pdst[VPW][NR];                                      // wave-uniform LDS offset inside a patch buffer, or junk
+    const bf16_t *wsrc[VPW][NWP];
+    int wmul[VPW][NWP];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int e = r * NT + tid, q = e >> 2, slot = e & 3;
-        psrc[r] = zero;
-        pstep[r] = 0;
-        if (q < NPATCH) {
-            const int py = q / PW, px = q - py * PW;
-            const int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px;
-            if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
-                psrc[r] = x + ((size_t)(n * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
-                pstep[r] = BK;
+    for (int v = 0; v < VPW; ++v) {
+        const int dw = dwave(v), dtid = dw * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int e = r * NT + dtid, q = e >> 2, slot = e & 3;
+            psrc[v][r] = zero;
+            pstep[v][r] = 0;
+            if (q < NPATCH) {
+                const int py = q / PW, px = q - py * PW;
+                const int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px;
+                if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
+                    psrc[v][r] = x + ((size_t)(n * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
+                    pstep[v][r] = BK;
+                }
+            }
+            const int wbase = (r * NT + dw * 64) * 16;           // this share's 1 KB of the patch image
+            pdst[v][r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < NWP; ++k) {
+            const int e = k * NT + dtid, row = e >> 2, slot = e & 3;
+            wsrc[v][k] = zero;
+            wmul[v][k] = 0;
+            if (co0 + row < p.Cout) {
+                wsrc[v][k] = w + (size_t)(co0 + row) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3);
+                wmul[v][k] = 1;
             }
         }
-        const int wbase = (r * NT + wave * 64) * 16;             // this wave's 1 KB of the patch image
-        pdst[r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
     }
-    const bf16_t *wsrc[NWP];
-    int wmul[NWP];
-#pragma unroll
-    for (int k = 0; k < NWP; ++k) {
-        const int e = k * NT + tid, row = e >> 2, slot = e & 3;
-        wsrc[k] = zero;
-        wmul[k] = 0;
-        if (co0 + row < p.Cout) {
-            wsrc[k] = w + (size_t)(co0 + row) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3);
-            wmul[k] = 1;
-        }
-    }
-    auto issue_w = [&](int it) {                                 // weights of global phase `it` -> ring slot it & 3
+    auto issue_w = [&](int it) {                                 // weights of global phase `it` -> ring slot it % RING
         const int cc = it / 9, tap = it - cc * 9;
+#ifdef RDFC_GLDS_EXP_WHIT   /* timing experiment only (wrong results): every phase re-reads the first weight block -> L1 hits */
+        const int off = 0 * tap;
+#else
         const int off = cc < ncc ? tap * p.Cin + cc * BK : 0;
+#endif
 #pragma unroll
-        for (int k = 0; k < NWP; ++k)
-            glds16((cc < ncc ? wsrc[k] : zero) + off * wmul[k], lds0 + OFF_W + (it % WRING) * WSLOT + (k * NT + wave * 64) * 16);
+        for (int v = 0; v < VPW; ++v)
+#pragma unroll
+            for (int k = 0; k < NWP; ++k)
+                glds16((cc < ncc ? wsrc[v][k] : zero) + off * wmul[v][k],
+                       lds0 + OFF_W + (it % RING) * WSLOT + (k * NT + dwave(v) * 64) * 16);
     };
     auto issue_p = [&](int r, int cc) {                          // round r of slab cc -> patch buffer cc & 1
         const bool live = cc < ncc;
-        const unsigned dst = pdst[r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[r];
-        glds16(live ? psrc[r] + (size_t)cc * pstep[r] : zero, dst);
+#pragma unroll
+        for (int v = 0; v < VPW; ++v) {
+            const unsigned dst = pdst[v][r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[v][r];
+            glds16(live ? psrc[v][r] + (size_t)cc * pstep[v][r] : zero, dst);
+        }
     };
 
     // ---- fragment coordinates ---------------------------------------------------------------------------------
@@ -157,14 +200,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
 #ifdef RDFC_GLDS_RECOMPUTE
         asm volatile("" : "+s"(shift));                          // keep the nine taps' B addresses out of registers (recomputed per phase)
 #endif
-        const unsigned char *Wt = smem + OFF_W + (it % WRING) * WSLOT + a_off;
+        const unsigned char *Wt = smem + OFF_W + (it % RING) * WSLOT + a_off;
         const unsigned char *Pt = smem + (cc & 1) * PATCH_BYTES;
+        if (!SPEC) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = bpp[j] + shift;
             b[j] = *reinterpret_cast<const bf16x8 *>(Pt + (((row << 6) | (kg << 4)) ^ ((row & 4) << 3)));
+        }
+        if (SPEC) {          // pipelined reads, in the order the next phase's MFMAs need them: a[0] and every b first, a[3] last
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
         }
     };
     auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
@@ -178,7 +227,73 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
         read_frags(it, cc, tap, a, b);
         mma(a, b);
     };
+#ifdef RDFC_GLDS_STAMPS
+    unsigned long long sbuf[9][6];
+    const bool stamp_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;
+#endif
 
+    if constexpr (SPEC) {
+        // Phase q = (slab, tap).  Barrier B(q): "the data of phase q is in LDS" (the producers waited for it) and "every consumer
+        // has issued the MFMAs of phase q-2" (so its fragment reads are complete: their slot and, at a slab boundary, their
+        // patch buffer may be overwritten).  Producers after B(q): weights of phase q+3 into slot (q+3) % 5 (held phase q-2),
+        // patch rounds of the next slab on taps 1..NR (its buffer held slab cc-1, last read in phase 9cc-1).
+        if (producer) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) issue_p(r, 0);
+#pragma unroll
+            for (int h = 0; h < 3; ++h) issue_w(h);
+#define RDFC_GLDS_PRODUCE(TAP)                                                                                 \
+    {                                                                                                          \
+        constexpr int ALLOW = VPW * (2 * NWP + (((TAP + 6) % 9) < NR ? 1 : 0) + (((TAP + 7) % 9) < NR ? 1 : 0)); \
+        wait_vm<ALLOW>();                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        issue_w(it0 + TAP + 3);                                                                                \
+        if (TAP >= 1 && TAP <= NR) issue_p(TAP >= 1 && TAP <= NR ? TAP - 1 : 0, cc + 1);                       \
+    }
+            for (int cc = 0; cc < ncc; ++cc) {
+                const int it0 = cc * 9;
+                RDFC_GLDS_PRODUCE(0) RDFC_GLDS_PRODUCE(1) RDFC_GLDS_PRODUCE(2) RDFC_GLDS_PRODUCE(3) RDFC_GLDS_PRODUCE(4)
+                RDFC_GLDS_PRODUCE(5) RDFC_GLDS_PRODUCE(6) RDFC_GLDS_PRODUCE(7) RDFC_GLDS_PRODUCE(8)
+            }
+#undef RDFC_GLDS_PRODUCE
+            wait_vm<0>();                                        // (the trailing zero-page pieces land in LDS this workgroup owns)
+            __builtin_amdgcn_s_barrier();                        // B(P): the consumers' last step reads one phase past the end
+            return;                                              // an ended wave no longer counts at s_barrier
+        }
+        bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+        __builtin_amdgcn_s_barrier();                            // B(0)
+        read_frags(0, 0, 0, fa0, fb0);
+        // one step: B(q+1), start reading phase q+1 into the other register set, run phase q's MFMAs on this one
+#define RDFC_GLDS_CONSUME(CC, TAP, CA, CB, NA_, NB_)                                                           \
+    {                                                                                                          \
+        const int q_ = (CC) * 9 + TAP;                                                                         \
+        RDFC_STAMP(TAP, 0)                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        RDFC_STAMP(TAP, 2)                                                                                     \
+        read_frags(q_ + 1, TAP == 8 ? (CC) + 1 : (CC), (TAP + 1) % 9, NA_, NB_);                               \
+        mma(CA, CB);                                                                                           \
+        /* schedule: one fragment read, two MFMAs, ... -- the reads ride in the MFMAs' issue slack and land a phase early; left \
+           alone the compiler sinks every read to just before its use and the MFMA waits out the LDS latency */ \
+        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                 \
+        }                                                                                                      \
+        RDFC_STAMP(TAP, 5)                                                                                     \
+    }
+        for (int cc = 0; cc < ncc; cc += 2) {                    // two slabs per trip: 18 phases, the register sets alternate
+            RDFC_GLDS_CONSUME(cc, 0, fa0, fb0, fa1, fb1) RDFC_GLDS_CONSUME(cc, 1, fa1, fb1, fa0, fb0)
+            RDFC_GLDS_CONSUME(cc, 2, fa0, fb0, fa1, fb1) RDFC_GLDS_CONSUME(cc, 3, fa1, fb1, fa0, fb0)
+            RDFC_GLDS_CONSUME(cc, 4, fa0, fb0, fa1, fb1) RDFC_GLDS_CONSUME(cc, 5, fa1, fb1, fa0, fb0)
+            RDFC_GLDS_CONSUME(cc, 6, fa0, fb0, fa1, fb1) RDFC_GLDS_CONSUME(cc, 7, fa1, fb1, fa0, fb0)
+            RDFC_GLDS_CONSUME(cc, 8, fa0, fb0, fa1, fb1)
+            RDFC_GLDS_CONSUME(cc + 1, 0, fa1, fb1, fa0, fb0) RDFC_GLDS_CONSUME(cc + 1, 1, fa0, fb0, fa1, fb1)
+            RDFC_GLDS_CONSUME(cc + 1, 2, fa1, fb1, fa0, fb0) RDFC_GLDS_CONSUME(cc + 1, 3, fa0, fb0, fa1, fb1)
+            RDFC_GLDS_CONSUME(cc + 1, 4, fa1, fb1, fa0, fb0) RDFC_GLDS_CONSUME(cc + 1, 5, fa0, fb0, fa1, fb1)
+            RDFC_GLDS_CONSUME(cc + 1, 6, fa1, fb1, fa0, fb0) RDFC_GLDS_CONSUME(cc + 1, 7, fa0, fb0, fa1, fb1)
+            RDFC_GLDS_CONSUME(cc + 1, 8, fa1, fb1, fa0, fb0)
+        }
+#undef RDFC_GLDS_CONSUME
+    } else {
     // ---- prologue: slab 0 patch, weights of the first WRING-1 phases -------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < NR; ++r) issue_p(r, 0);
@@ -205,11 +320,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
 #define RDFC_GLDS_PHASE(TAP)                                                                                   \
     {                                                                                                          \
         constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
+        RDFC_STAMP(TAP, 0)                                                                                     \
         wait_vm<ALLOW>();                                                                                      \
+        RDFC_STAMP(TAP, 1)                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                          \
+        RDFC_STAMP(TAP, 2)                                                                                     \
         issue_w(it0 + TAP + 3);                                                                                \
         if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
-        compute(it0 + TAP, cc, TAP);                                                                           \
+        RDFC_STAMP(TAP, 3)                                                                                     \
+        {                                                                                                      \
+            bf16x8 a_[4], b_[4];                                                                               \
+            read_frags(it0 + TAP, cc, TAP, a_, b_);                                                            \
+            RDFC_STAMP(TAP, 4)                                                                                 \
+            mma(a_, b_);                                                                                       \
+        }                                                                                                      \
+        RDFC_STAMP(TAP, 5)                                                                                     \
     }
 #else
     // deep variant: the wait of phase p retires the DMAs of phase p+1 (issued four phases ahead), the barrier publishes them,
@@ -221,15 +346,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
 #define RDFC_GLDS_PHASE(TAP)                                                                                   \
     {                                                                                                          \
         constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
+        RDFC_STAMP(TAP, 0)                                                                                     \
         wait_vm<ALLOW>();                                                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        RDFC_STAMP(TAP, 1)                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                          \
+        RDFC_STAMP(TAP, 2)                                                                                     \
         issue_w(it0 + TAP + 4);                                                                                \
         if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
+        RDFC_STAMP(TAP, 3)                                                                                     \
+        RDFC_STAMP(TAP, 4)                                                                                     \
         bf16x8 na[4], nb[4];                                                                                   \
         read_frags(it0 + TAP + 1, TAP == 8 ? cc + 1 : cc, (TAP + 1) % 9, na, nb);                              \
         mma(fa, fb);                                                                                           \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) { fa[q] = na[q]; fb[q] = nb[q]; }                        \
+        RDFC_STAMP(TAP, 5)                                                                                     \
     }
 #endif
     for (int cc = 0; cc < ncc; ++cc) {
@@ -246,6 +377,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
     }
 #undef RDFC_GLDS_PHASE
     wait_vm<0>();
+    }
+#ifdef RDFC_GLDS_STAMPS
+    if (stamp_on && lane == 0 && ncc > 2)
+        for (int t_ = 0; t_ < 9; ++t_)
+            for (int k_ = 0; k_ < 6; ++k_) g_stamps[wave_all & 7][t_][k_] = sbuf[t_][k_];
+#endif
 
     // ---- epilogue: bias + activation + store, 4 consecutive output channels per lane -------------------------------
     // (the activation is selected once, outside the 64-value loop: a per-element switch costs more than the stores)
@@ -261,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_glds_kernel(GParams p, con
         }
     // ---- fused normalisation statistics: per-tile partial {sum, sum of squares} of the STORED values, one row per tile in
     //      stats[g][tile][2][Cout] (the fixed-order f64 finalize of norm.hip reads them; no atomics) --------------------
-    if (stats != nullptr) {
+    if (!SPEC && stats != nullptr) {
         float s1[4][4], s2[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -376,19 +513,23 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO, int NW>
+template <int TCO, int NW, int NPROD = 0>
 int launch(const GParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, float *stats, hipStream_t st) {
+    constexpr bool SPEC = NPROD > 0;
     constexpr int NT = NW * 64, TR = 4 * NW / (TCO / 64);
     constexpr int NPIECE = (TR + 2) * PW * 4, PATCH = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;
-    constexpr int SMEM = 2 * PATCH + WRING * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
+    constexpr int SMEM = 2 * PATCH + (SPEC ? 5 : WRING) * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM + 65536) != hipSuccess) return 0;
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
-    rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, NW);
-    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, NW>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
+    if (SPEC) rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d>", TCO, NW, NPROD);
+    else rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, NW);
+    // experiment knob: extra (unused) dynamic LDS, e.g. 40960 leaves room for ONE workgroup per CU
+    static const int pad_lds = getenv("RDFC_GLDS_PAD_LDS") ? atoi(getenv("RDFC_GLDS_PAD_LDS")) : 0;
+    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, NW, NPROD>), grid, dim3((NW + NPROD) * 64), SMEM + pad_lds, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
     return 1;
 }
 
@@ -439,6 +580,11 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
             return launch<128, 8>(p, in, w, bias, out, zero, stats, st);
         }
         p.tiles_y = cdiv(p.H, 8);
+        // A/B switches RDFC_GLDS=4 / 5: specialised variants, 4 consumer + 4 (one workgroup per CU) or + 2 (two per CU) producer
+        // waves.  A workgroup alone on its CU runs 16 % faster (256->256 @ 57x76, 160 workgroups: 21.2 vs 25.3 us) but a CU's
+        // throughput does not move: 62.9 / 63.6 vs 58.2 us on 640 workgroups -- see DESIGN.md section 7 for the stamp and counter data.
+        if (stats == nullptr && mode == 4 && (Cin / BK) % 2 == 0) return launch<128, 4, 4>(p, in, w, bias, out, zero, stats, st);
+        if (stats == nullptr && mode == 5 && (Cin / BK) % 2 == 0) return launch<128, 4, 2>(p, in, w, bias, out, zero, stats, st);
         return launch<128, 4>(p, in, w, bias, out, zero, stats, st);
     }
     if (mode == 2 && stats == nullptr) {               // A/B switch: 2-wave workgroups (4 per CU) measured 1-4 % slower
@@ -446,5 +592,14 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
         return launch<64, 2>(p, in, w, bias, out, zero, stats, st);
     }
     p.tiles_y = cdiv(p.H, 16);
+    if (stats == nullptr && mode == 4 && (Cin / BK) % 2 == 0) return launch<64, 4, 4>(p, in, w, bias, out, zero, stats, st);
+    if (stats == nullptr && mode == 5 && (Cin / BK) % 2 == 0) return launch<64, 4, 2>(p, in, w, bias, out, zero, stats, st);
     return launch<64, 4>(p, in, w, bias, out, zero, stats, st);
 }
+
+#ifdef RDFC_GLDS_STAMPS
+extern "C" int rdfc_debug_glds_stamps(unsigned long long *out) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif

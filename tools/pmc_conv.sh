@@ -17,7 +17,7 @@ cnt = collections.Counter()
 for f in glob.glob(f'gpurun_out/pmc_{tag}/p*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'][:70]
-        if 'igemm' in k or 'patch' in k or 'slab' in k or 'wgrad' in k or 'thin' in k:
+        if any(t in k for t in ('igemm', 'patch', 'slab', 'wgrad', 'thin', 'glds')):
             tot[k][r['Counter_Name']] += float(r['Counter_Value'])
             cnt[(k, r['Counter_Name'])] += 1
 for k, d in tot.items():
