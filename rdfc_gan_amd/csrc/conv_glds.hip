@@ -75,7 +75,9 @@ __device__ unsigned long long g_stamps[8][9][6];
 // In-kernel stamps of the unspecialised kernel (tools/glds_stamps.sh, 256->256 @ 57x76, cycles per phase of a wave that
 // has its SIMD to itself): vmcnt wait 20, barrier 45, DMA issue 130 (2-3 pieces at ~55), fragment reads until the data
 // is back 125, 16 MFMAs 280 -- 600 in all, the matrix pipe busy 43 %.  Here a consumer's phase is barrier + MFMAs.
-template <int TCO, int NW, int NPROD = 0>
+// JR: pixel rows (of 16) per wave: 4 -> a wave owns 64 co x 64 px; 8 -> 64 co x 128 px (32 MFMAs per phase and barrier against 12
+// fragment reads, and the tap's weights serve twice the pixels: 45 % fewer DMA'd bytes and L2 requests per MFMA; 128 accumulators)
+template <int TCO, int NW, int NPROD = 0, int JR = 4>
 __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds_kernel(GParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
                                                                   const float *__restrict__ bias, void *__restrict__ yout,
                                                                   const bf16_t *__restrict__ zero, float *__restrict__ stats) {
@@ -84,7 +86,8 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
     constexpr int VPW = SPEC ? NW / NPROD : 1;                 // DMA shares ("virtual waves") per issuing wave
     static_assert(!SPEC || NW % NPROD == 0, "producer waves must split the DMA shares evenly");
     constexpr int WCO = TCO / 64, WPX = NW / WCO;              // waves along co / along pixel rows (64 co x 4 rows x 16 px each)
-    constexpr int TR = 4 * WPX, PH = TR + 2, NPATCH = PH * PW; // tile rows, patch rows, patch pixels (180 / 324)
+    static_assert(JR == 4 || NPROD == 0, "the specialised variants keep two fragment sets: 4-row wave tiles only");
+    constexpr int TR = JR * WPX, PH = TR + 2, NPATCH = PH * PW; // tile rows, patch rows, patch pixels (180 / 324)
     constexpr int NPIECE = NPATCH * 4;                         // 16-byte pieces per slab
     constexpr int PATCH_BYTES = (NPIECE + 63) / 64 * 1024;     // whole DMA instructions (1 KB each): 12 KB / 21 KB
     constexpr int NR = (NPIECE + NT - 1) / NT;                 // patch DMA rounds per slab (3 / 6)
@@ -122,24 +125,24 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
 
     // ---- per-thread DMA sources (computed once) -------------------------------------------------------------
     const bf16_t *psrc[VPW][NR];
-    int pstep[VPW][NR];
+    unsigned plive[VPW];                                         // bit r: round r reads the image (else the zero page)
     unsigned pdst[VPW][NR];                                      // wave-uniform LDS offset inside a patch buffer, or junk
     const bf16_t *wsrc[VPW][NWP];
-    int wmul[VPW][NWP];
+    unsigned wlive[VPW];                                         // bit k: weight row in range
 #pragma unroll
     for (int v = 0; v < VPW; ++v) {
         const int dw = dwave(v), dtid = dw * 64 + lane;
+        plive[v] = wlive[v] = 0;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int e = r * NT + dtid, q = e >> 2, slot = e & 3;
             psrc[v][r] = zero;
-            pstep[v][r] = 0;
             if (q < NPATCH) {
                 const int py = q / PW, px = q - py * PW;
                 const int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px;
                 if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
                     psrc[v][r] = x + ((size_t)(n * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
-                    pstep[v][r] = BK;
+                    plive[v] |= 1u << r;
                 }
             }
             const int wbase = (r * NT + dw * 64) * 16;           // this share's 1 KB of the patch image
@@ -149,10 +152,9 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
         for (int k = 0; k < NWP; ++k) {
             const int e = k * NT + dtid, row = e >> 2, slot = e & 3;
             wsrc[v][k] = zero;
-            wmul[v][k] = 0;
             if (co0 + row < p.Cout) {
                 wsrc[v][k] = w + (size_t)(co0 + row) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3);
-                wmul[v][k] = 1;
+                wlive[v] |= 1u << k;
             }
         }
     }
@@ -167,7 +169,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
         for (int v = 0; v < VPW; ++v)
 #pragma unroll
             for (int k = 0; k < NWP; ++k)
-                glds16((cc < ncc ? wsrc[v][k] : zero) + off * wmul[v][k],
+                glds16((cc < ncc ? wsrc[v][k] : zero) + ((wlive[v] >> k) & 1 ? off : 0),
                        lds0 + OFF_W + (it % RING) * WSLOT + (k * NT + dwave(v) * 64) * 16);
     };
     auto issue_p = [&](int r, int cc) {                          // round r of slab cc -> patch buffer cc & 1
@@ -175,30 +177,32 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
 #pragma unroll
         for (int v = 0; v < VPW; ++v) {
             const unsigned dst = pdst[v][r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[v][r];
-            glds16(live ? psrc[v][r] + (size_t)cc * pstep[v][r] : zero, dst);
+            glds16(live ? psrc[v][r] + ((plive[v] >> r) & 1 ? cc * BK : 0) : zero, dst);
         }
     };
 
     // ---- fragment coordinates ---------------------------------------------------------------------------------
     const int wr = wave / WPX, wc = wave % WPX;
-    int bpp[4];
+    int bpp[JR];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bpp[j] = (4 * wc + j) * PW + (lane & 15);
+    for (int j = 0; j < JR; ++j) bpp[j] = (JR * wc + j) * PW + (lane & 15);
     const int arow = wr * 64 + (lane & 15), kg = lane >> 4;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][JR];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        for (int j = 0; j < JR; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
     // byte address of (row, 16-byte chunk kg) in a swizzled 64-byte-row image: (row*64 + kg*16) ^ ((row & 4) << 3)
     const unsigned a_off = (unsigned)((arow << 6) | (kg << 4)) ^ (unsigned)((arow & 4) << 3);     // + i*1024: rows arow + 16 i share bit 2
-    auto read_frags = [&](int it, int cc, int tap, bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+    auto read_frags = [&](int it, int cc, int tap, bf16x8 (&a)[4], bf16x8 (&b)[JR]) {
         const int kh = tap / 3, kw = tap - kh * 3;
         int shift = p.transposed ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
 #ifdef RDFC_GLDS_RECOMPUTE
         asm volatile("" : "+s"(shift));                          // keep the nine taps' B addresses out of registers (recomputed per phase)
+#else
+        if (JR > 4) asm volatile("" : "+s"(shift));              // 128 accumulators + 48 fragment registers: no room for 72 hoisted addresses
 #endif
         const unsigned char *Wt = smem + OFF_W + (it % RING) * WSLOT + a_off;
         const unsigned char *Pt = smem + (cc & 1) * PATCH_BYTES;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
             for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < JR; ++j) {
             const int row = bpp[j] + shift;
             b[j] = *reinterpret_cast<const bf16x8 *>(Pt + (((row << 6) | (kg << 4)) ^ ((row & 4) << 3)));
         }
@@ -216,14 +220,14 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
             for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
         }
     };
-    auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
+    auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[JR]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < JR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
     auto compute = [&](int it, int cc, int tap) {
-        bf16x8 a[4], b[4];
+        bf16x8 a[4], b[JR];
         read_frags(it, cc, tap, a, b);
         mma(a, b);
     };
@@ -329,7 +333,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
         if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
         RDFC_STAMP(TAP, 3)                                                                                     \
         {                                                                                                      \
-            bf16x8 a_[4], b_[4];                                                                               \
+            bf16x8 a_[4], b_[JR];                                                                              \
             read_frags(it0 + TAP, cc, TAP, a_, b_);                                                            \
             RDFC_STAMP(TAP, 4)                                                                                 \
             mma(a_, b_);                                                                                       \
@@ -339,7 +343,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
 #else
     // deep variant: the wait of phase p retires the DMAs of phase p+1 (issued four phases ahead), the barrier publishes them,
     // and phase p+1's fragments are read while phase p's MFMAs (operands read one phase ago) execute
-    bf16x8 fa[4], fb[4];
+    bf16x8 fa[4], fb[JR];
     wait_vm<(WRING - 2) * NWP>();                               // patch 0 and weights 0 are in
     __builtin_amdgcn_s_barrier();
     read_frags(0, 0, 0, fa, fb);
@@ -356,7 +360,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
         if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
         RDFC_STAMP(TAP, 3)                                                                                     \
         RDFC_STAMP(TAP, 4)                                                                                     \
-        bf16x8 na[4], nb[4];                                                                                   \
+        bf16x8 na[4], nb[JR];                                                                                  \
         read_frags(it0 + TAP + 1, TAP == 8 ? cc + 1 : cc, (TAP + 1) % 9, na, nb);                              \
         mma(fa, fb);                                                                                           \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) { fa[q] = na[q]; fb[q] = nb[q]; }                        \
@@ -405,8 +409,8 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
 #pragma unroll
             for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int oy = y0 + 4 * wc + j, ox = x0 + (lane & 15);
+        for (int j = 0; j < JR; ++j) {
+            const int oy = y0 + JR * wc + j, ox = x0 + (lane & 15);
             if (oy < p.H && ox < p.W) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -460,8 +464,8 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
     }
     auto store_all = [&](auto actf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int oy = y0 + 4 * wc + j, ox = x0 + (lane & 15);
+        for (int j = 0; j < JR; ++j) {
+            const int oy = y0 + JR * wc + j, ox = x0 + (lane & 15);
             if (oy >= p.H || ox >= p.W) continue;
             const size_t po = ((size_t)n * p.H + oy) * p.W + ox;
 #pragma unroll
@@ -513,23 +517,24 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO, int NW, int NPROD = 0>
+template <int TCO, int NW, int NPROD = 0, int JR = 4>
 int launch(const GParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, float *stats, hipStream_t st) {
     constexpr bool SPEC = NPROD > 0;
-    constexpr int NT = NW * 64, TR = 4 * NW / (TCO / 64);
+    constexpr int NT = NW * 64, TR = JR * NW / (TCO / 64);
     constexpr int NPIECE = (TR + 2) * PW * 4, PATCH = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;
     constexpr int SMEM = 2 * PATCH + (SPEC ? 5 : WRING) * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM + 65536) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW, NPROD, JR>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM + 65536) != hipSuccess) return 0;
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
     if (SPEC) rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d>", TCO, NW, NPROD);
+    else if (JR != 4) rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, 0, %d>", TCO, NW, JR);
     else rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, NW);
     // experiment knob: extra (unused) dynamic LDS, e.g. 40960 leaves room for ONE workgroup per CU
     static const int pad_lds = getenv("RDFC_GLDS_PAD_LDS") ? atoi(getenv("RDFC_GLDS_PAD_LDS")) : 0;
-    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, NW, NPROD>), grid, dim3((NW + NPROD) * 64), SMEM + pad_lds, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
+    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, NW, NPROD, JR>), grid, dim3((NW + NPROD) * 64), SMEM + pad_lds, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
     return 1;
 }
 
@@ -583,6 +588,10 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
         // A/B switches RDFC_GLDS=4 / 5: specialised variants, 4 consumer + 4 (one workgroup per CU) or + 2 (two per CU) producer
         // waves.  A workgroup alone on its CU runs 16 % faster (256->256 @ 57x76, 160 workgroups: 21.2 vs 25.3 us) but a CU's
         // throughput does not move: 62.9 / 63.6 vs 58.2 us on 640 workgroups -- see DESIGN.md section 7 for the stamp and counter data.
+        if (stats == nullptr && mode == 6) {                    // 4 waves x (64 co x 128 px): 128 co x (16x16) px per workgroup
+            p.tiles_y = cdiv(p.H, 16);
+            return launch<128, 4, 0, 8>(p, in, w, bias, out, zero, stats, st);
+        }
         if (stats == nullptr && mode == 4 && (Cin / BK) % 2 == 0) return launch<128, 4, 4>(p, in, w, bias, out, zero, stats, st);
         if (stats == nullptr && mode == 5 && (Cin / BK) % 2 == 0) return launch<128, 4, 2>(p, in, w, bias, out, zero, stats, st);
         return launch<128, 4>(p, in, w, bias, out, zero, stats, st);

@@ -15,6 +15,8 @@ Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
 y = torch.empty(N, Ho, Wo, Co, device='cuda', dtype=dt)
 gy = torch.randn(N, Ho, Wo, Co, device='cuda').to(dt)
 dx = torch.empty_like(x)
+if os.environ.get('RDFC_BENCH_ZERO') == '1':      # all-zero operands: no switching power in the matrix pipe -> shows what the clock costs
+    x.zero_(); gy.zero_(); w.zero_(); wf, wb = hip.pack_weight(w, dt)
 d = hip.conv_desc(x.shape, Co, k, s, p, ldx=Ci, ldy=Co, dtype=hip.dt(x))
 def run():
     if which == 'fwd': hip.conv_forward(d, x, wf, None, y)
