@@ -142,3 +142,25 @@ def step_batch_label(it, B, H, W, classes=14):
     data['labels'] = z.argmax(1)
     data['normal_masks'] = (det_tensor(40 + it, 'step.nmask', (B, 1, H, W), 'rand') > 0.15).float()
     return data, nA, nfA
+
+
+NORMAL_FEATS = {4: (24, 32, 40), 5: (40, 16, 20), 6: (64, 8, 10), 8: (176, 4, 5), 11: (2048, 2, 3)}   # index -> (C, h, w)
+
+
+def normal_features(B=2, seed=51):
+    """the five EfficientNet feature maps G_normal's decoder consumes (decoder.py:17), as seeded tensors"""
+    return [det_tensor(seed, f'nfeat{i}', (B, c, h, w)) for i, (c, h, w) in NORMAL_FEATS.items()]
+
+
+class FeatureListAdapter(torch.nn.Module):
+    """five tensors -> upstream's 12-entry feature list -> decoder; parameters under 'n.' like the other fixtures"""
+
+    def __init__(self, n):
+        super().__init__()
+        self.n = n
+
+    def forward(self, f4, f5, f6, f8, f11):
+        feats = [None] * 12
+        for i, t in zip(NORMAL_FEATS, (f4, f5, f6, f8, f11)):
+            feats[i] = t
+        return self.n(feats)

@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_harness as rh                                   # noqa: E402
 from detweights import det_state_dict, det_tensor          # noqa: E402
-from cases import step_batch_label, normal_loss_case, NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP, metric_case, label_net_weights, LABEL_CASE   # noqa: E402
+from cases import normal_features, FeatureListAdapter, step_batch_label, normal_loss_case, NLSPN_CFG, gen_inputs, out_weights, grad_summary, step_batch, STEP_HP, metric_case, label_net_weights, LABEL_CASE   # noqa: E402
 
 
 def save(name, **arrs):
@@ -260,6 +260,18 @@ def normal_losses():
     save('normal_losses', **res)
 
 
+def normal_decoder():
+    """upstream's own Decoder (normal_net/submodules/decoder.py:6-25) on seeded feature maps: eval / train outputs, gradients
+    with respect to the five feature maps, parameter-gradient norms, BN buffers"""
+    rh.install()
+    import importlib
+    Dec = importlib.import_module('lib.models.generator.normal_net.submodules.decoder').Decoder
+    net = Dec()
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    fg = ('n.conv3.weight', 'n.conv3.bias', 'n.up4._net.4.weight', 'n.conv2.bias', 'n.up1._net.1.bias')   # (conv biases in front of a BN: zero gradient)
+    save('normal_decoder_small', **run_module(FeatureListAdapter(net), tuple(normal_features()), 'normal_decoder_small', full_grads=fg))
+
+
 JOBS = {
     'g_a2b_small': lambda: g_a2b(False, 2, 60, 76, 'g_a2b_small'),
     'g_a2b_nlspn_small': lambda: g_a2b(True, 2, 60, 76, 'g_a2b_nlspn_small'),
@@ -272,6 +284,7 @@ JOBS = {
     'step_trace': step_trace,
     'metric': metric,
     'normal_losses': normal_losses,
+    'normal_decoder_small': normal_decoder,
     'step_trace_label': lambda: step_trace(2, label=True),
     'label_net_small': lambda: label_net(LABEL_CASE['B'], LABEL_CASE['H'], LABEL_CASE['W'], 'label_net_small'),
 }

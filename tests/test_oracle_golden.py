@@ -241,3 +241,26 @@ def test_normal_losses_match_upstream(golden):
     f, w, c = ol.manhattan_loss(pred, logits, 12, 5, 3, 100.0)
     np.testing.assert_allclose([float(f), float(w), float(c)], [g['floor'], g['wall'], g['ceiling']], rtol=2e-6)
     assert float(ol.manhattan_loss(pred, logits, 12, 5, 99, 100.0)[2]) == float(g['ceiling_absent']) == 0.0
+
+
+def test_normal_decoder_matches_upstream(golden):
+    """oracle.normal_net.Decoder against upstream's Decoder (normal_net/submodules/decoder.py:6-25)"""
+    from oracle.normal_net import Decoder
+    from cases import FeatureListAdapter, normal_features, out_weights
+    from detweights import det_state_dict
+    g = golden('normal_decoder_small')
+    net = Decoder()
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    w = FeatureListAdapter(net)
+    feats = normal_features()
+    w.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(w(*feats).numpy(), g['eval.out'], rtol=0, atol=1e-5)
+    w.train()
+    ins = [t.clone().requires_grad_(True) for t in feats]
+    out = w(*ins)
+    np.testing.assert_allclose(out.detach().numpy(), g['train.out'], rtol=0, atol=1e-5)
+    (out * out_weights('normal_decoder_small', 'out', out.shape)).sum().backward()
+    for i, t in enumerate(ins):
+        ref = g[f'grad_in.{i}']
+        np.testing.assert_allclose(t.grad.numpy(), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
