@@ -288,17 +288,21 @@ int rdfc_cross_entropy_backward(const void *logits, const int64_t *labels, int P
                                 int64_t ignore_index, const float *count, const float *grad_scale_dev, float grad_scale,
                                 void *dlogits, int lddl, void *stream);
 
-/* nor_loss (lib/losses/gan_loss.py:122-132) and manhattan_loss (:50-99), values only (in this build the surface normals
- * are an input of the hot path, so nothing differentiable hangs off them): out4 = {nor, floor, wall, ceiling}, each
- * sum / (count of non-zero terms + 1e-6), unweighted.  normal / gt_normal f32 [N][3][HW], norm_mask f32 [N][HW] or NULL,
+/* nor_loss (lib/losses/gan_loss.py:122-132) and manhattan_loss (:50-99): out8 = {nor, floor, wall, ceiling} -- each
+ * sum / (count of non-zero terms + 1e-6), unweighted -- followed by the four counts (consumed by the backward).  normal / gt_normal f32 [N][3][HW], norm_mask f32 [N][HW] or NULL,
  * logits f32 pixel-major [N*HW][C] (ld) -- their arg-max gives the wall / floor / ceiling masks.  gt_normal NULL skips
  * nor_loss, logits NULL skips the manhattan terms.  partial: f64 [8 * rdfc_normal_losses_nchunk(HW)].
  * manhattan_loss's [B,H,W] x [B,1,H,W] product broadcasts to [B,B,H,W] upstream (:73-74): every image's term at a pixel is
  * counted once per image of the batch whose pixel has the class; reproduced. */
 int rdfc_normal_losses_nchunk(int P);
 int rdfc_normal_losses(const float *normal, const float *gt_normal, const float *norm_mask, const float *logits, int N, int HW,
-                       int C, int ld, int label_wall, int label_floor, int label_ceiling, double *partial, float *out4,
+                       int C, int ld, int label_wall, int label_floor, int label_ceiling, double *partial, float *out8,
                        void *stream);
+/* grad_normal f32 [N][3][HW] = d(grad4 . {nor, floor, wall, ceiling}) / d normal (grad4: f32 [4] on the device, the
+ * cotangents of the four terms).  Masks and counts are constants of the graph, as upstream (dot.detach(), arg-max). */
+int rdfc_normal_losses_backward(const float *normal, const float *gt_normal, const float *norm_mask, const float *logits, int N,
+                                int HW, int C, int ld, int label_wall, int label_floor, int label_ceiling, const float *out8,
+                                const float *grad4, float *grad_normal, void *stream);
 
 /* addPepperNoise (helper.py:384-402) given the host-drawn mask (0 keep, 1 -> +1, 2 -> -1), in place. */
 int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, int HW, void *stream);

@@ -493,6 +493,69 @@ __global__ void normal_losses_finalize_kernel(const double *__restrict__ partial
         double a = 0.0, b = 0.0;
         for (int k = 0; k < nb; ++k) { a += partial[(size_t)k * 8 + 2 * threadIdx.x]; b += partial[(size_t)k * 8 + 2 * threadIdx.x + 1]; }
         out[threadIdx.x] = (float)((float)a / ((float)b + 1e-6f));
+        out[4 + threadIdx.x] = (float)b;                         // the count, for the backward
+    }
+}
+
+// gradient with respect to `normal` of  g[0] * nor + g[1] * floor + g[2] * wall + g[3] * ceiling  (the counts and the masks are
+// constants of the graph upstream too: dot.detach() in the validity mask, arg-max class masks, `!= 0` counts).
+//   d cos(a, b) / d a = (b^ - cos * a^) / |a|   for |a| > eps
+__global__ __launch_bounds__(NT) void normal_losses_bwd_kernel(const float *__restrict__ nrm, const float *__restrict__ gtn,
+                                                               const float *__restrict__ nmask, const float *__restrict__ logits, int N,
+                                                               int HW, int C, int ld, int wall, int floor_, int ceiling,
+                                                               const float *__restrict__ out8, const float *__restrict__ g4,
+                                                               float *__restrict__ grad) {
+#pragma clang fp contract(off)
+    const float gn = g4[0] / (out8[4] + 1e-6f), gf = g4[1] / (out8[5] + 1e-6f), gw = g4[2] / (out8[6] + 1e-6f),
+                gc = g4[3] / (out8[7] + 1e-6f);
+    for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < (size_t)HW; p += (size_t)gridDim.x * NT) {
+        int M[3] = {0, 0, 0};
+        if (logits != nullptr)
+            for (int n = 0; n < N; ++n) {
+                const float *z = logits + ((size_t)n * HW + p) * ld;
+                int best = 0;
+                float bz = z[0];
+                for (int c = 1; c < C; ++c)
+                    if (z[c] > bz) { bz = z[c]; best = c; }
+                M[0] += best == floor_; M[1] += best == wall; M[2] += best == ceiling;
+            }
+        for (int n = 0; n < N; ++n) {
+            const size_t i = (size_t)n * HW + p;
+            const float *a = nrm + (size_t)n * 3 * HW + p;
+            const float ax = a[0], ay = a[HW], az = a[2 * (size_t)HW];
+            const float an_raw = sqrtf(ax * ax + ay * ay + az * az), an = fmaxf(an_raw, 1e-8f);
+            const float hx = ax / an, hy = ay / an, hz = az / an;
+            const float live = an_raw > 1e-8f ? 1.f / an : 0.f;  // clamp_min(eps): no gradient through a clamped norm
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (gtn != nullptr) {
+                const float *b = gtn + (size_t)n * 3 * HW + p;
+                const float bx = b[0], by = b[HW], bz_ = b[2 * (size_t)HW];
+                const float bn = fmaxf(sqrtf(bx * bx + by * by + bz_ * bz_), 1e-8f);
+                const float ux = bx / bn, uy = by / bn, uz = bz_ / bn;
+                const float dot = hx * ux + hy * uy + hz * uz;
+                const float m = nmask ? nmask[i] : 1.f;
+                if (m * (dot < 0.999f ? 1.f : 0.f) * (dot > -0.999f ? 1.f : 0.f) > 0.f) {     // term (1 - dot)
+                    const float s = -gn * live;
+                    dx += s * (ux - dot * hx); dy += s * (uy - dot * hy); dz += s * (uz - dot * hz);
+                }
+            }
+            if (logits != nullptr) {
+                const float *z = logits + i * ld;
+                int best = 0;
+                float bz = z[0];
+                for (int c = 1; c < C; ++c)
+                    if (z[c] > bz) { bz = z[c]; best = c; }
+                // d cy / d a = (e_y - cy * a^) / |a| with cy = a^_y; only inside image n's own class mask (normal * mask)
+                float coef = 0.f;
+                if (best == floor_) coef += -gf * (float)M[0];                          // 1 - cy
+                if (best == wall) coef += gw * (float)M[1] * 2.f * (hy > 0.f ? 1.f : (hy < 0.f ? -1.f : 0.f));   // |2 cy|
+                if (best == ceiling) coef += gc * (float)M[2];                           // 1 + cy
+                coef *= live;
+                dx += coef * (0.f - hy * hx); dy += coef * (1.f - hy * hy); dz += coef * (0.f - hy * hz);
+            }
+            float *o = grad + (size_t)n * 3 * HW + p;
+            o[0] = dx; o[HW] = dy; o[2 * (size_t)HW] = dz;
+        }
     }
 }
 
@@ -648,14 +711,25 @@ extern "C" int rdfc_cross_entropy_backward(const void *logits, const int64_t *la
 extern "C" int rdfc_normal_losses_nchunk(int P) { return (int)min((size_t)512, ((size_t)P + NT - 1) / NT); }
 
 extern "C" int rdfc_normal_losses(const float *normal, const float *gt_normal, const float *norm_mask, const float *logits, int N, int HW,
-                                  int C, int ld, int label_wall, int label_floor, int label_ceiling, double *partial, float *out4,
+                                  int C, int ld, int label_wall, int label_floor, int label_ceiling, double *partial, float *out8,
                                   void *stream) {
-    RDFC_REQUIRE(normal && partial && out4 && (gt_normal || logits), "rdfc_normal_losses: null pointer");
+    RDFC_REQUIRE(normal && partial && out8 && (gt_normal || logits), "rdfc_normal_losses: null pointer");
     RDFC_REQUIRE(N > 0 && HW > 0 && (logits == nullptr || (C > 0 && ld >= C)), "rdfc_normal_losses: bad shape");
     const int nb = rdfc_normal_losses_nchunk(HW);
     hipLaunchKernelGGL(normal_losses_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, normal, gt_normal, norm_mask, logits, N, HW, C, ld,
                        label_wall, label_floor, label_ceiling, partial);
-    hipLaunchKernelGGL(normal_losses_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, out4);
+    hipLaunchKernelGGL(normal_losses_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, out8);
     RDFC_LAUNCH_CHECK("rdfc_normal_losses");
+    return 0;
+}
+
+extern "C" int rdfc_normal_losses_backward(const float *normal, const float *gt_normal, const float *norm_mask, const float *logits, int N,
+                                           int HW, int C, int ld, int label_wall, int label_floor, int label_ceiling, const float *out8,
+                                           const float *grad4, float *grad_normal, void *stream) {
+    RDFC_REQUIRE(normal && out8 && grad4 && grad_normal && (gt_normal || logits), "rdfc_normal_losses_backward: null pointer");
+    RDFC_REQUIRE(N > 0 && HW > 0 && (logits == nullptr || (C > 0 && ld >= C)), "rdfc_normal_losses_backward: bad shape");
+    hipLaunchKernelGGL(normal_losses_bwd_kernel, dim3(rdfc_normal_losses_nchunk(HW)), dim3(NT), 0, (hipStream_t)stream, normal, gt_normal,
+                       norm_mask, logits, N, HW, C, ld, label_wall, label_floor, label_ceiling, out8, grad4, grad_normal);
+    RDFC_LAUNCH_CHECK("rdfc_normal_losses_backward");
     return 0;
 }

@@ -579,3 +579,24 @@ def cross_entropy_nchw(logits_nchw, labels, ignore_index=-100):
     """the label net hands out upstream's [N, classes, H, W] shape as a view of its pixel-major map: undo the view (no copy)"""
     z = logits_nchw.permute(0, 2, 3, 1)
     return cross_entropy(z if z.is_contiguous() else z.contiguous(), labels, ignore_index)
+
+
+class _NormalLosses(torch.autograd.Function):
+    """nor_loss + manhattan_loss (lib/losses/gan_loss.py:122-132, 50-99) -> [nor, floor, wall, ceiling]; differentiable in `normal`"""
+
+    @staticmethod
+    def forward(ctx, normal, gt_normal, norm_mask, logits_nchw, labels3):
+        out8 = hip.normal_losses(normal, gt_normal, norm_mask, logits_nchw, *labels3, with_counts=True)
+        ctx.save_for_backward(normal, gt_normal, norm_mask, logits_nchw, out8)
+        ctx.labels3 = labels3
+        return out8[:4].clone()
+
+    @staticmethod
+    def backward(ctx, g4):
+        normal, gt_normal, norm_mask, logits_nchw, out8 = ctx.saved_tensors
+        return hip.normal_losses_backward(normal, gt_normal, norm_mask, logits_nchw, *ctx.labels3, out8, g4), None, None, None, None
+
+
+def normal_losses(normal, gt_normal, norm_mask, logits_nchw, label_wall, label_floor, label_ceiling):
+    return _NormalLosses.apply(normal, gt_normal, norm_mask, logits_nchw.detach() if logits_nchw is not None else None,
+                               (label_wall, label_floor, label_ceiling))

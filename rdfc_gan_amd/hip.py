@@ -654,9 +654,7 @@ def cross_entropy_backward(logits, labels, count, grad_out, ignore_index=-100, g
     return dl
 
 
-def normal_losses(normal, gt_normal, norm_mask, logits_nchw, label_wall, label_floor, label_ceiling):
-    """-> f32 [4] on the device: nor_loss, floor, wall, ceiling terms (unweighted).  logits_nchw: the label net's
-    [N,C,H,W] channels-last view (or None); normal / gt_normal [N,3,H,W] f32"""
+def _normal_loss_args(normal, gt_normal, norm_mask, logits_nchw):
     normal = normal.contiguous().float()
     N, _, H, W = normal.shape
     gt = gt_normal.contiguous().float() if gt_normal is not None else None
@@ -668,8 +666,23 @@ def normal_losses(normal, gt_normal, norm_mask, logits_nchw, label_wall, label_f
         z = logits_nchw.detach().permute(0, 2, 3, 1)
         assert z.dtype == torch.float32 and z.shape[:3] == (N, H, W)
         Cc, ldz = z.shape[3], ld(z)
-    partial = torch.empty(8 * lib().rdfc_normal_losses_nchunk(H * W), dtype=torch.float64, device=normal.device)
-    out = torch.empty(4, dtype=torch.float32, device=normal.device)
-    _chk(lib().rdfc_normal_losses(_p(normal), _p(gt), _p(m), _p(z), N, H * W, Cc, ldz, label_wall, label_floor, label_ceiling,
+    return normal, gt, m, z, Cc, ldz, N, H * W
+
+
+def normal_losses(normal, gt_normal, norm_mask, logits_nchw, label_wall, label_floor, label_ceiling, with_counts=False):
+    """-> f32 [4] on the device: nor_loss, floor, wall, ceiling terms (unweighted); with_counts: [8], the four counts appended.
+    logits_nchw: the label net's [N,C,H,W] channels-last view (or None); normal / gt_normal [N,3,H,W] f32"""
+    normal, gt, m, z, Cc, ldz, N, HW = _normal_loss_args(normal, gt_normal, norm_mask, logits_nchw)
+    partial = torch.empty(8 * lib().rdfc_normal_losses_nchunk(HW), dtype=torch.float64, device=normal.device)
+    out = torch.empty(8, dtype=torch.float32, device=normal.device)
+    _chk(lib().rdfc_normal_losses(_p(normal), _p(gt), _p(m), _p(z), N, HW, Cc, ldz, label_wall, label_floor, label_ceiling,
                                   _p(partial), _p(out), _st()), 'rdfc_normal_losses')
-    return out
+    return out if with_counts else out[:4]
+
+
+def normal_losses_backward(normal, gt_normal, norm_mask, logits_nchw, label_wall, label_floor, label_ceiling, out8, grad4):
+    normal, gt, m, z, Cc, ldz, N, HW = _normal_loss_args(normal, gt_normal, norm_mask, logits_nchw)
+    g = torch.empty_like(normal)
+    _chk(lib().rdfc_normal_losses_backward(_p(normal), _p(gt), _p(m), _p(z), N, HW, Cc, ldz, label_wall, label_floor, label_ceiling,
+                                           _p(out8), _p(grad4.contiguous().float()), _p(g), _st()), 'rdfc_normal_losses_backward')
+    return g

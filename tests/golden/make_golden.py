@@ -252,9 +252,15 @@ def normal_losses():
     """upstream's nor_loss / manhattan_loss (lib/losses/gan_loss.py:122-132, 50-99) with RDFCGAN's label ids (rdfc_gan.py:32-34)"""
     _, _, _, gl = rh.ref_classes()
     pred, gt, mask, logits = normal_loss_case()
+    pred.requires_grad_(True)
     res = dict(nor=gl.nor_loss(pred, gt, mask), nor_nomask=gl.nor_loss(pred, gt, torch.ones_like(mask)))
     f, w, c = gl.manhattan_loss(pred, logits, mask, 12, 5, 3, 100.0)
     res.update(floor=f, wall=w, ceiling=c)
+    # the way rdfc_gan.py:242-250 combines them (lambda_L1 = 100): gradient with respect to the predicted normals
+    (res['nor'] * 200.0 + f + w + c).backward()
+    res['grad_pred'] = pred.grad.clone()
+    pred = pred.detach()
+    res = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in res.items()}
     f2, w2, c2 = gl.manhattan_loss(pred, logits, mask, 12, 5, 99, 100.0)     # no pixel of class 99: python 0.0 * weight
     res.update(ceiling_absent=np.float32(c2), classes_present=np.bincount(logits.argmax(1).flatten().numpy(), minlength=14))
     save('normal_losses', **res)

@@ -144,3 +144,33 @@ def test_normal_losses_against_upstream_fixture_and_oracle(golden):
     out = h.normal_losses(pred.to(DEV), gt.to(DEV), mask.to(DEV), z, 12, 5, 3).cpu().numpy()
     f, w, c = ol.manhattan_loss(pred, logits, 12, 5, 3, 1.0)
     np.testing.assert_allclose(out, [float(ol.nor_loss(pred, gt, mask)), float(f), float(w), float(c)], rtol=2e-5)
+
+
+def test_normal_losses_gradient(golden):
+    """d(200 nor + 100 (floor + wall + ceiling)) / d normal: fixture from upstream's autograd, and the oracle's autograd on a
+    full-size batch with un-normalised predictions (|a| != 1 exercises the 1 / |a| factors)"""
+    from oracle import losses as ol
+    from cases import normal_loss_case
+    from rdfc_gan_amd import functional as Fh
+    import numpy as np
+    g = golden('normal_losses')
+    wts = torch.tensor([200.0, 100.0, 100.0, 100.0], device=DEV)
+
+    def hip_grad(pred, gt, mask, logits):
+        z = logits.permute(0, 2, 3, 1).contiguous().to(DEV).permute(0, 3, 1, 2)
+        pr = pred.to(DEV).requires_grad_(True)
+        out = Fh.normal_losses(pr, gt.to(DEV), mask.to(DEV), z, 12, 5, 3)
+        (out * wts).sum().backward()
+        return pr.grad.cpu()
+
+    pred, gt, mask, logits = normal_loss_case()
+    got = hip_grad(pred, gt, mask, logits)
+    ref = torch.from_numpy(g['grad_pred'])
+    assert float((got - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    pred, gt, mask, logits = normal_loss_case(B=4, H=114, W=152, seed=33)
+    pred = pred * (0.5 + torch.rand(4, 1, 114, 152, generator=torch.Generator().manual_seed(3)))
+    got = hip_grad(pred, gt, mask, logits)
+    pr = pred.clone().requires_grad_(True)
+    f, w, c = ol.manhattan_loss(pr, logits, 12, 5, 3, 100.0)
+    (ol.nor_loss(pr, gt, mask) * 200.0 + f + w + c).backward()
+    assert float((got - pr.grad).abs().max()) < 2e-5 * float(pr.grad.abs().max())

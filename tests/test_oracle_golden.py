@@ -264,3 +264,14 @@ def test_normal_decoder_matches_upstream(golden):
     for i, t in enumerate(ins):
         ref = g[f'grad_in.{i}']
         np.testing.assert_allclose(t.grad.numpy(), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+
+
+def test_normal_losses_gradient_matches_upstream(golden):
+    from oracle import losses as ol
+    from cases import normal_loss_case
+    g = golden('normal_losses')
+    pred, gt, mask, logits = normal_loss_case()
+    pred.requires_grad_(True)
+    f, w, c = ol.manhattan_loss(pred, logits, 12, 5, 3, 100.0)
+    (ol.nor_loss(pred, gt, mask) * 200.0 + f + w + c).backward()
+    np.testing.assert_allclose(pred.grad.numpy(), g['grad_pred'], rtol=0, atol=2e-6 * np.abs(g['grad_pred']).max())
