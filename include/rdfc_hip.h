@@ -238,6 +238,10 @@ int rdfc_mdconv_backward(const rdfc_mdconv_desc *d, const float *input, const fl
  * ------------------------------------------------------------------------------ */
 int rdfc_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
                    float lr, float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+/* torch.optim.AdamW (rdfc_gan.py:141-144, G_normal's optimizer): the same update after the decoupled decay
+ * param *= 1 - lr * weight_decay. */
+int rdfc_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream);
 /* Same update; lr and the (1-based) step count are read from device memory, hyper = {lr, step} (f32), so the launch
  * can be captured into a HIP graph and replayed while the schedule advances. */
 int rdfc_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, const float *hyper,

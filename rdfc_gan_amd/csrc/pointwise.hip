@@ -250,15 +250,15 @@ __global__ void loss_finalize_kernel(const float *partial, int n, float *out) {
 
 // ---- Adam (torch.optim.Adam, amsgrad=False, weight_decay=0) ------------------------------------------
 __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
-                            size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
-    GRID_STRIDE(i, n) {
+                            size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale, float keep) {
+    GRID_STRIDE(i, n) {                 // keep = 1 - lr * weight_decay (torch.optim.AdamW's decoupled decay; 1 for Adam)
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] -= (lr / bc1) * (mi / denom);
+        p[i] = p[i] * keep - (lr / bc1) * (mi / denom);
     }
 }
 
@@ -472,8 +472,18 @@ extern "C" int rdfc_adam_step(float *param, const float *grad, float *m, float *
     RDFC_REQUIRE(step >= 1, "rdfc_adam_step: step counts from 1");
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, m, v, n, lr, b1, b2, eps,
-                       (float)bc1, (float)sqrt(bc2), gscale);
+                       (float)bc1, (float)sqrt(bc2), gscale, 1.f);
     RDFC_LAUNCH_CHECK("rdfc_adam_step");
+    return 0;
+}
+
+extern "C" int rdfc_adamw_step(float *param, const float *grad, float *m, float *v, size_t n, float lr, float b1, float b2, float eps,
+                               float weight_decay, int step, float gscale, void *stream) {
+    RDFC_REQUIRE(step >= 1, "rdfc_adamw_step: step must be >= 1 (got %d)", step);
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, m, v, n, lr, b1, b2, eps,
+                       (float)bc1, (float)sqrt(bc2), gscale, 1.f - lr * weight_decay);
+    RDFC_LAUNCH_CHECK("rdfc_adamw_step");
     return 0;
 }
 

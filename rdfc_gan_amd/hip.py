@@ -506,6 +506,11 @@ def adam_step(param, grad, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
                               int(step), _f(grad_scale), _st()), 'rdfc_adam_step')
 
 
+def adamw_step(param, grad, m, v, lr, b1, b2, eps, weight_decay, step, grad_scale=1.0):
+    _chk(lib().rdfc_adamw_step(_p(param), _p(grad), _p(m), _p(v), C.c_size_t(param.numel()), _f(lr), _f(b1), _f(b2), _f(eps),
+                               _f(weight_decay), int(step), _f(grad_scale), _st()), 'rdfc_adamw_step')
+
+
 def adam_step_dev(param, grad, m, v, hyper, b1, b2, eps, grad_scale=1.0):
     """hyper: device f32 tensor {lr, step}"""
     _chk(lib().rdfc_adam_step_dev(_p(param), _p(grad), _p(m), _p(v), C.c_size_t(param.numel()), _p(hyper), _f(b1), _f(b2),

@@ -27,10 +27,11 @@ def _pview(buf, off, p):
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=2e-3, betas=(0.5, 0.999), eps=1e-8):
+    def __init__(self, params, lr=2e-3, betas=(0.5, 0.999), eps=1e-8, weight_decay=None):
+        """weight_decay=None: torch.optim.Adam; a number: torch.optim.AdamW (decoupled decay, upstream's optimizer_Normal)"""
         params = [p for p in params]
         assert params, 'optimizer got an empty parameter list'
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         dev = params[0].device
         self._params = params
         n = sum(p.numel() for p in params)
@@ -119,7 +120,11 @@ class FlatAdam(torch.optim.Optimizer):
         if not self.flat.is_cuda:
             raise RuntimeError('FlatAdam.step runs the HIP kernel rdfc_adam_step: parameters must live on the GPU '
                                '(there is no CPU fallback)')
-        if self._hyper is not None:
+        if g.get('weight_decay') is not None:
+            self.steps += 1
+            hip.adamw_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                           g['weight_decay'], self.steps, 1.0 / world)
+        elif self._hyper is not None:
             self._hyper[1:2] += 1.0           # device-side step count (captured with the update)
             hip.adam_step_dev(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._hyper, g['betas'][0],
                               g['betas'][1], g['eps'], 1.0 / world)

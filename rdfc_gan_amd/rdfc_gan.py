@@ -84,12 +84,16 @@ def _cfg_get(node, key, default=None):
 class RDFCGAN:
     def __init__(self, device, distributed, args, is_train=True, fixed_training_samples=None, fixed_testing_samples=None,
                  num_classes=14, out_height=224, out_width=304, label_wall=12, label_floor=5, label_ceiling=3,
-                 normal_provider=None, exact_schedule=False, compute_dtype=None, use_label_net=False):
+                 normal_provider=None, exact_schedule=False, compute_dtype=None, use_label_net=False, normal_net=None):
         self.device, self.distributed, self.args, self.is_train = device, distributed, args, is_train
         # G_label and the label / normal-consistency terms of loss_G (rdfc_gan.py:89,187-203,238-267): off by default -- the
         # benchmarked hot path is the four-network step; on, the step computes upstream's full objective except that the
         # surface normals still come from `normal_provider` / the batch (G_normal is not part of this build)
         self.use_label_net = bool(use_label_net)
+        # G_normal (rdfc_gan.py:88): an NNET-like module (rdfc_gan_amd.normal_net.NNET around the caller's encoder).  With it the
+        # normals are predicted -- fake_normal = norm_normalize(G_normal(img)[:, 0:3]) (:190-191, 205-206, 233-234) -- the normal
+        # terms back-propagate into it and it gets upstream's AdamW (:141-144)
+        self.G_normal = normal_net
         self.num_classes, self.label_wall, self.label_floor, self.label_ceiling = num_classes, label_wall, label_floor, label_ceiling
         self.local_rank = _cfg_get(args, 'local_rank', 0)
         self.out_height, self.out_width = out_height, out_width
@@ -120,6 +124,9 @@ class RDFCGAN:
             from .label_net import PSPNet
             self.G_label = PSPNet(self.num_classes).to(self.device)              # rdfc_gan.py:89
             self.models['G_label'] = self.G_label
+        if self.G_normal is not None:
+            self.G_normal = self.G_normal.to(self.device)
+            self.models['G_normal'] = self.G_normal
         if self.distributed:
             # DDP-constructor semantics without DDP: same start on every rank; gradients are
             # exchanged by FlatAdam.all_reduce_grads_async (one bucket per optimizer)
@@ -134,6 +141,10 @@ class RDFCGAN:
         if self.use_label_net:
             self.optimizer_Label = FlatAdam(self.G_label.parameters(), lr=lr, betas=betas)   # rdfc_gan.py:145-147
             self.optimizers['label'] = self.optimizer_Label
+        if self.G_normal is not None:                                            # torch.optim.AdamW, lr / 2 (:141-144)
+            self.optimizer_Normal = FlatAdam(self.G_normal.parameters(), lr=lr * 0.5, betas=betas,
+                                             weight_decay=_cfg_get(a, 'weight_decay', 0.0))
+            self.optimizers['Nor'] = self.optimizer_Normal
 
     def init_lr_scheduler(self):
         a = self.args
@@ -153,6 +164,9 @@ class RDFCGAN:
         if self.use_label_net:
             self.lr_scheduler_Label = make(self.optimizer_Label)
             self.lr_schedulers['label'] = self.lr_scheduler_Label
+        if self.G_normal is not None:
+            self.lr_scheduler_Nor = make(self.optimizer_Normal)
+            self.lr_schedulers['Nor'] = self.lr_scheduler_Nor
 
     # ---- data ------------------------------------------------------------------------------------
     def set_input(self, data):
@@ -166,6 +180,7 @@ class RDFCGAN:
         self.image_loss_weight = self.mask / (self.mask.sum() + 1e-6)
         if self.use_label_net:
             self.gt_label = data['labels'].to(dev)                               # rdfc_gan.py set_input: labels, normal_masks
+        if self.use_label_net or self.G_normal is not None:
             self.norm_mask = data['normal_masks'].to(dev) if 'normal_masks' in data else None
         self._batch = data
 
@@ -192,6 +207,8 @@ class RDFCGAN:
         self._batch = data
 
     def _normal(self, tag, img):
+        if self.G_normal is not None:
+            return norm_normalize(self.G_normal(img)[:, 0:3])
         if self.normal_provider is not None:
             return norm_normalize(self.normal_provider(tag, img)[:, 0:3])
         if self.gt_normal is None:
@@ -288,14 +305,12 @@ class RDFCGAN:
             finally:
                 layers.BN_STAT_REPEAT = 1
             loss_cycle_B2A = self.criterionCycle(rec_B, self.real_B, weight=self.image_loss_weight) * lam_B
-            extra_B = self._label_and_normal_terms('B2A', self.fake_label_fakeA_list, self.fake_normal_fakeA, lam_1) \
-                if self.use_label_net else {}
+            extra_B = self._label_and_normal_terms('B2A', getattr(self, 'fake_label_fakeA_list', None), self.fake_normal_fakeA, lam_1)
         loss_G_A2B = self.criterionGAN(self.disc_A(self.fake_B), True)
         loss_A2B_L1 = self.criterionL1(self.fake_B, self.real_B, weight=self.image_loss_weight) * lam_1 * 5
         rec_A = self.G_B2A(self.fake_B)
         loss_cycle_A2B = self.criterionCycle(rec_A, self.real_A) * lam_A
-        extra_A = self._label_and_normal_terms('A2B', self.fake_label_realA_list, self.fake_normal_realA, lam_1) \
-            if self.use_label_net else {}
+        extra_A = self._label_and_normal_terms('A2B', getattr(self, 'fake_label_realA_list', None), self.fake_normal_realA, lam_1)
         self._join_net_stream((loss_G_B2A, loss_B2A_L1, loss_cycle_B2A) + tuple(extra_B.values()))
         loss_G = loss_G_A2B + loss_cycle_A2B + loss_cycle_B2A + loss_G_B2A + loss_A2B_L1 + loss_B2A_L1
         for v in list(extra_A.values()) + list(extra_B.values()):               # :252-267
@@ -310,15 +325,25 @@ class RDFCGAN:
 
     def _label_and_normal_terms(self, tag, label_list, normal, lam_1):
         """rdfc_gan.py:238-250 for one direction: cross entropy of the label net's two heads (aux x 0.4), nor_loss x 2 and the
-        three manhattan terms, all x lambda_L1.  The normal terms are values only: normals are an input here."""
-        ce = Fh.cross_entropy_nchw
-        loss_label = (ce(label_list[0], self.gt_label) + ce(label_list[1], self.gt_label) * 0.4) * lam_1
-        if normal.requires_grad:
-            raise NotImplementedError('nor_loss / manhattan_loss are computed without a gradient path to the normals')
-        v = hip.normal_losses(normal, self.gt_normal, self.norm_mask, label_list[0], self.label_wall, self.label_floor,
-                              self.label_ceiling)
-        return {f'loss_label_{tag}': loss_label, f'loss_normal_{tag}': v[0] * (lam_1 * 2), f'floor_loss_{tag}': v[1] * lam_1,
-                f'wall_loss_{tag}': v[2] * lam_1, f'ceiling_loss_{tag}': v[3] * lam_1}
+        three manhattan terms, all x lambda_L1.  Without G_label there are no label / manhattan terms; without G_label and
+        G_normal nothing is added (the four-network hot path)."""
+        if not self.use_label_net and self.G_normal is None:
+            return {}
+        out = {}
+        logits = None
+        if self.use_label_net:
+            ce = Fh.cross_entropy_nchw
+            out[f'loss_label_{tag}'] = (ce(label_list[0], self.gt_label) + ce(label_list[1], self.gt_label) * 0.4) * lam_1
+            logits = label_list[0]
+        labels3 = (self.label_wall, self.label_floor, self.label_ceiling)
+        if normal.requires_grad:       # predicted normals: the terms back-propagate into G_normal
+            v = Fh.normal_losses(normal, self.gt_normal, self.norm_mask, logits, *labels3)
+        else:
+            v = hip.normal_losses(normal, self.gt_normal, self.norm_mask, logits, *labels3)
+        out[f'loss_normal_{tag}'] = v[0] * (lam_1 * 2)
+        if self.use_label_net:
+            out.update({f'floor_loss_{tag}': v[1] * lam_1, f'wall_loss_{tag}': v[2] * lam_1, f'ceiling_loss_{tag}': v[3] * lam_1})
+        return out
 
     def backward_D_basic(self, model_D, real, fake):
         loss_D_real = self.criterionGAN(model_D(real), True)
@@ -338,7 +363,7 @@ class RDFCGAN:
     # ---- HIP-graph mode: the step is captured once as three graphs (G step | D step | Adam) and replayed; the
     #      data-parallel all-reduces stay eager between them, the host only draws the pepper mask and copies the batch in
     def enable_graph(self, enabled=True):
-        if enabled and self.use_label_net:
+        if enabled and (self.use_label_net or self.G_normal is not None):
             raise NotImplementedError('graph mode captures the four-network step only')
         self._graph_mode = bool(enabled)
         self._graphs = None
@@ -473,11 +498,15 @@ class RDFCGAN:
         self.forward()
         self.set_requires_grad([self.disc_A, self.disc_B], False)
         self.optimizer_G.zero_grad()
+        if self.G_normal is not None:
+            self.optimizer_Normal.zero_grad()
         if self.use_label_net:
             self.optimizer_Label.zero_grad()
         loss_stats.update(self.backward_G())
         # G gradients fly over xGMI on the side stream while the D step computes
         self.optimizer_G.all_reduce_grads_async()
+        if self.G_normal is not None:
+            self.optimizer_Normal.all_reduce_grads_async()
         if self.use_label_net:
             self.optimizer_Label.all_reduce_grads_async()
         self.set_requires_grad([self.disc_A, self.disc_B], True)
@@ -489,6 +518,8 @@ class RDFCGAN:
         loss_stats.update(stats_DB)
         self.optimizer_D.all_reduce_grads_async()
         self.optimizer_G.step()
+        if self.G_normal is not None:
+            self.optimizer_Normal.step()
         if self.use_label_net:
             self.optimizer_Label.step()
         self.optimizer_D.step()

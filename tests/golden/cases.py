@@ -164,3 +164,20 @@ class FeatureListAdapter(torch.nn.Module):
         for i, t in zip(NORMAL_FEATS, (f4, f5, f6, f8, f11)):
             feats[i] = t
         return self.n(feats)
+
+
+class StandInEncoder(torch.nn.Module):
+    """Stock-PyTorch stand-in for upstream's torch.hub EfficientNet-B5 encoder (normal_net/submodules/encoder.py:7-31, not in the
+    tree): the same contract -- a 12-entry feature list whose entries 4, 5, 6, 8, 11 carry 24 / 40 / 64 / 176 / 2048 channels at
+    1/4 ... 1/32 of the input -- from five small convolutions.  Used on BOTH sides of the G_normal step trace."""
+
+    def __init__(self):
+        super().__init__()
+        self.convs = torch.nn.ModuleList(torch.nn.Conv2d(3, c, 3, padding=1) for c, _, _ in NORMAL_FEATS.values())
+        self.strides = (4, 8, 16, 32, 32)
+
+    def forward(self, img):
+        feats = [None] * 12
+        for i, conv, s in zip(NORMAL_FEATS, self.convs, self.strides):
+            feats[i] = torch.tanh(conv(F.avg_pool2d(img, s, s, ceil_mode=True)))
+        return feats

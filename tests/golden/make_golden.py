@@ -141,7 +141,7 @@ class _Node(dict):
     __getattr__ = dict.__getitem__
 
 
-def step_trace(nsteps=2, label=False):
+def step_trace(nsteps=2, label=False, normal=False):
     """Run upstream RDFCGAN.optimize_parameters itself (NNET / PSPNet replaced by
     constant stand-ins) and record the loss dict + weight / BN-buffer checksums.
     label=True: G_label is upstream's real PSPNet (Dropout2d off, see label_net()), the batch carries label maps and a
@@ -150,21 +150,23 @@ def step_trace(nsteps=2, label=False):
     import lib.models.rdfc_gan as ref_mod
     from lib.models.rdfc_gan import RDFCGAN
     from lib.models.generator.normal_net.NNET import NNET
-    stub_psp = ref_mod.PSPNet
+    stub_psp, stub_nnet = ref_mod.PSPNet, ref_mod.NNET
     if label:
         ref_mod.PSPNet = rh.real_pspnet()
+    if normal:      # G_normal = upstream's Decoder behind the stand-in encoder (-> step_trace_full.npz), AdamW with weight decay
+        ref_mod.NNET = rh.ref_nnet_with_stand_in_encoder()
     hp = STEP_HP
     model_cfg = _Node(
         G_A2B=dict(type='RDFGenerator', pretrained_on_imagenet=False),
         G_B2A=dict(type='ResnetGenerator', input_channels=1, output_channels=3, ngf=64, norm_layer='IN2d'),
         D_A=dict(type='PatchGANDiscriminator', in_channels=1, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'),
         D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'))
-    args = _Node(local_rank=0, model=model_cfg, lr=hp['lr'], beta1=hp['beta1'], beta2=hp['beta2'], weight_decay=0.0,
+    args = _Node(local_rank=0, model=model_cfg, lr=hp['lr'], beta1=hp['beta1'], beta2=hp['beta2'], weight_decay=0.01 if normal else 0.0,
                  gan_loss_type='lsgan', scheduler='linear', epoch=0, decay_epoch=100, n_epochs=150,
                  lambda_A=hp['lambda_A'], lambda_B=hp['lambda_B'], lambda_L1=hp['lambda_L1'], optimizer='adam')
     m = RDFCGAN(device=torch.device('cpu'), distributed=False, args=args, is_train=True,
                 out_height=hp['H'], out_width=hp['W'])
-    ref_mod.PSPNet = stub_psp
+    ref_mod.PSPNet, ref_mod.NNET = stub_psp, stub_nnet
     nets = [('G_A2B', m.G_A2B), ('G_B2A', m.G_B2A), ('disc_A', m.disc_A), ('disc_B', m.disc_B)]
     for key, net in nets:
         net.load_state_dict(det_state_dict(net.state_dict(), 0))
@@ -174,12 +176,16 @@ def step_trace(nsteps=2, label=False):
             if isinstance(mod, torch.nn.Dropout2d):
                 mod.p = 0.0
         nets.append(('G_label', m.G_label))
+    if normal:
+        m.G_normal.load_state_dict(det_state_dict(m.G_normal.state_dict(), 0))
+        nets.append(('G_normal', m.G_normal))
     m.train()
     res = {}
     for it in range(nsteps):
         data, normal_A, normal_fA = (step_batch_label if label else step_batch)(it, hp['B'], hp['H'], hp['W'])
         pad = torch.zeros(hp['B'], 1, hp['H'], hp['W'])
-        NNET.queue[:] = [torch.cat([normal_A, pad], 1), torch.cat([normal_fA, pad], 1), torch.cat([normal_fA, pad], 1)]
+        if not normal:
+            NNET.queue[:] = [torch.cat([normal_A, pad], 1), torch.cat([normal_fA, pad], 1), torch.cat([normal_fA, pad], 1)]
         random.seed(100 + it)
         np.random.seed(100 + it)
         m.set_input(data)
@@ -197,7 +203,7 @@ def step_trace(nsteps=2, label=False):
             res[f'sd_summary.{key}.{it}'] = np.array([[float(sd[k].double().sum()), float(sd[k].double().norm())] for k in names])
         res[f'fake_B.{it}'] = m.fake_B.detach().clone()
         res[f'fake_A.{it}'] = m.fake_A.detach().clone()
-    save('step_trace_label' if label else 'step_trace', **res)
+    save('step_trace_full' if normal else ('step_trace_label' if label else 'step_trace'), **res)
 
 
 def metric():
@@ -292,6 +298,7 @@ JOBS = {
     'normal_losses': normal_losses,
     'normal_decoder_small': normal_decoder,
     'step_trace_label': lambda: step_trace(2, label=True),
+    'step_trace_full': lambda: step_trace(2, label=True, normal=True),
     'label_net_small': lambda: label_net(LABEL_CASE['B'], LABEL_CASE['H'], LABEL_CASE['W'], 'label_net_small'),
 }
 

@@ -223,3 +223,25 @@ def real_pspnet():
     finally:
         sys.modules[name] = stub
     return real.PSPNet
+
+
+def ref_nnet_with_stand_in_encoder():
+    """class with NNET's constructor signature (NNET.py:10-15) built from upstream's own Decoder and the stand-in encoder of
+    cases.py; forward as NNET.py:21-25"""
+    install()
+    import torch.nn.functional as F
+    Dec = importlib.import_module('lib.models.generator.normal_net.submodules.decoder').Decoder
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cases import StandInEncoder
+
+    class RefNNET(nn.Module):
+        def __init__(self, out_height, out_width):
+            super().__init__()
+            self.encoder, self.decoder = StandInEncoder(), Dec()
+            self.out_height, self.out_width = out_height, out_width
+
+        def forward(self, img):
+            out = self.decoder(self.encoder(img))
+            return F.interpolate(out, size=[self.out_height, self.out_width], mode='bilinear', align_corners=True)
+
+    return RefNNET
