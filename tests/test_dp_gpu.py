@@ -11,11 +11,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_stay_identical():
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+@pytest.mark.parametrize('full', [False, True], ids=['four_networks', 'full_objective'])
+def test_two_ranks_stay_identical(full):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_SMOKE_FULL='1' if full else '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29517', os.path.join(ROOT, 'tools', 'dp_smoke.py')]
+           '--master-port', '29518' if full else '29517', os.path.join(ROOT, 'tools', 'dp_smoke.py')]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     assert 'max parameter difference between replicas after 2 steps = 0.000e+00' in out, out[-3000:]
+    if full:
+        assert "optimizers ['D', 'G', 'Nor', 'label']" in out, out[-3000:]

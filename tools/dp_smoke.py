@@ -18,7 +18,14 @@ torch.cuda.set_device(dev)
 Fh.set_compute_dtype(torch.bfloat16)
 torch.manual_seed(100 + rank)           # different initial weights per rank: the broadcast must equalise them
 random.seed(rank); np.random.seed(rank)
-m = RDFCGAN(dev, True, bench.model_cfg(False), is_train=True)
+full = os.environ.get('DP_SMOKE_FULL') == '1'          # all six networks: label net + G_normal (stand-in encoder), three more reducers
+kw = {}
+if full:
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from cases import StandInEncoder
+    from rdfc_gan_amd.normal_net import NNET
+    kw = dict(use_label_net=True, normal_net=NNET(64, 80, encoder=StandInEncoder()), out_height=64, out_width=80)
+m = RDFCGAN(dev, True, bench.model_cfg(False), is_train=True, **kw)
 m.train()
 for it in range(2):
     m.set_input(bench.synth_batch(2, 64, 80, 50 + 10 * rank + it, dev))
@@ -31,6 +38,6 @@ other = [torch.empty_like(mine) for _ in range(world)]
 dist.all_gather(other, mine)
 diff = max((o - other[0]).abs().max().item() for o in other)
 if rank == 0:
-    print(f'dp_smoke: world {world}, max parameter difference between replicas after 2 steps = {diff:.3e}; losses {losses}')
+    print(f'dp_smoke: optimizers {sorted(m.optimizers)}; world {world}, max parameter difference between replicas after 2 steps = {diff:.3e}; losses {losses}')
 assert diff == 0.0, diff
 dist.destroy_process_group()
