@@ -84,6 +84,12 @@ def set_multi_stream(enabled):
 
 def multi_stream():
     return _multi_stream
+
+
+# The same parameter is used on two HIP streams within a step by design (G_A2B on the main and on the B->A stream): autograd
+# orders the two gradient accumulations with an event wait, which is what is wanted; its warning about the mismatch is noise here.
+if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 _side = {}          # device -> [stream, list of tensors the pending launches still read]
 
 
