@@ -309,6 +309,10 @@ int rdfc_normal_losses_backward(const float *normal, const float *gt_normal, con
                                 const float *grad4, float *grad_normal, void *stream);
 
 /* addPepperNoise (helper.py:384-402) given the host-drawn mask (0 keep, 1 -> +1, 2 -> -1), in place. */
+/* rdfc_draw_pepper_mask: the same per-pixel distribution drawn on the device (u8 [N][HW]; P(0) = snr, P(1) = P(2) =
+ * (1 - snr) / 2) from a stateless counter-based generator keyed by (seed, counter, pixel): SURVEY 8f rank 4.  A different random
+ * stream than upstream's numpy draw, hence opt-in. */
+int rdfc_draw_pepper_mask(uint8_t *mask, int N, int HW, uint64_t seed, uint64_t counter, float snr, void *stream);
 int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, int HW, void *stream);
 
 #ifdef __cplusplus

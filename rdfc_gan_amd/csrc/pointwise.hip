@@ -350,6 +350,24 @@ __global__ void pepper_kernel(float *img, const uint8_t *mask, int C, int HW, si
     }
 }
 
+// device-side draw of the same mask distribution (P(keep) = snr, P(+1) = P(-1) = (1 - snr) / 2 per pixel, shared by the
+// channels): counter-based, one 64-bit mix (splitmix64) of (seed, call counter, pixel) per pixel -- no state, no host copy.
+// NOT upstream's numpy stream: off by default (RDFCGAN(device_pepper=True)), for training at speed.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void pepper_draw_kernel(uint8_t *__restrict__ mask, size_t npix, unsigned long long seed, unsigned long long counter, float snr) {
+    GRID_STRIDE(i, npix) {
+        const unsigned long long r = mix64(mix64(seed ^ (counter * 0xD1B54A32D192ED03ull)) + i);
+        const float u = (float)(r >> 40) * (1.f / 16777216.f);                 // 24 random bits -> [0, 1)
+        const float half = (1.f - snr) * 0.5f;
+        mask[i] = u < snr ? 0 : (u < snr + half ? 1 : 2);
+    }
+}
+
 }  // namespace
 
 #define DISPATCH(dtype, ...)                                      \
@@ -503,6 +521,15 @@ extern "C" int rdfc_depth_metrics(const float *gt_norm, const float *pred_norm, 
     hipLaunchKernelGGL(depth_metrics_kernel, dim3(N), dim3(MNT), 0, (hipStream_t)stream, gt_norm, pred_norm, evaluate_mask, HW, std,
                        mean, t_valid, out);
     RDFC_LAUNCH_CHECK("rdfc_depth_metrics");
+    return 0;
+}
+
+extern "C" int rdfc_draw_pepper_mask(uint8_t *mask, int N, int HW, uint64_t seed, uint64_t counter, float snr, void *stream) {
+    RDFC_REQUIRE(mask != nullptr && N > 0 && HW > 0 && snr >= 0.f && snr <= 1.f, "rdfc_draw_pepper_mask: bad arguments");
+    const size_t npix = (size_t)N * HW;
+    hipLaunchKernelGGL(pepper_draw_kernel, dim3(nblocks(npix)), dim3(NT), 0, (hipStream_t)stream, mask, npix, (unsigned long long)seed,
+                       (unsigned long long)counter, snr);
+    RDFC_LAUNCH_CHECK("rdfc_draw_pepper_mask");
     return 0;
 }
 

@@ -76,6 +76,8 @@ def _declare_argtypes(lib_):
                     types.append(C.c_size_t)
                 elif re.match(r'^(const )?int64_t\b', a):
                     types.append(C.c_int64)
+                elif re.match(r'^(const )?uint64_t\b', a):
+                    types.append(C.c_uint64)
                 else:
                     types.append(C.c_int)
         fn = getattr(lib_, name)
@@ -530,6 +532,12 @@ def depth_metrics(gt_norm, pred_norm, evaluate_mask=None, std=5.0, mean=5.0, t_v
     out = torch.empty(N, 8, dtype=torch.float32, device=g.device)
     _chk(lib().rdfc_depth_metrics(_p(g), _p(p_), _p(m), N, HW, _f(std), _f(mean), _f(t_valid), _p(out), _st()), 'rdfc_depth_metrics')
     return out
+
+
+def draw_pepper_mask(N, H, W, seed, counter, snr, device):
+    mask = torch.empty(N, 1, H, W, dtype=torch.uint8, device=device)
+    _chk(lib().rdfc_draw_pepper_mask(_p(mask), N, H * W, int(seed) & (2 ** 64 - 1), int(counter), _f(snr), _st()), 'rdfc_draw_pepper_mask')
+    return mask
 
 
 def apply_pepper(img, mask_u8):

@@ -84,12 +84,16 @@ def _cfg_get(node, key, default=None):
 class RDFCGAN:
     def __init__(self, device, distributed, args, is_train=True, fixed_training_samples=None, fixed_testing_samples=None,
                  num_classes=14, out_height=224, out_width=304, label_wall=12, label_floor=5, label_ceiling=3,
-                 normal_provider=None, exact_schedule=False, compute_dtype=None, use_label_net=False, normal_net=None):
+                 normal_provider=None, exact_schedule=False, compute_dtype=None, use_label_net=False, normal_net=None,
+                 device_pepper=False, pepper_seed=0):
         self.device, self.distributed, self.args, self.is_train = device, distributed, args, is_train
         # G_label and the label / normal-consistency terms of loss_G (rdfc_gan.py:89,187-203,238-267): off by default -- the
         # benchmarked hot path is the four-network step; on, the step computes upstream's full objective except that the
         # surface normals still come from `normal_provider` / the batch (G_normal is not part of this build)
         self.use_label_net = bool(use_label_net)
+        # addPepperNoise's mask (helper.py:384-402) drawn on the device instead of from numpy's global stream + a host copy: same
+        # distribution, different random numbers -- off by default so that runs reproduce upstream's draws
+        self.device_pepper, self._pepper_seed, self._pepper_calls = bool(device_pepper), int(pepper_seed), 0
         # G_normal (rdfc_gan.py:88): an NNET-like module (rdfc_gan_amd.normal_net.NNET around the caller's encoder).  With it the
         # normals are predicted -- fake_normal = norm_normalize(G_normal(img)[:, 0:3]) (:190-191, 205-206, 233-234) -- the normal
         # terms back-propagate into it and it gets upstream's AdamW (:141-144)
@@ -250,6 +254,12 @@ class RDFCGAN:
         if getattr(self, '_graph_mode', False):
             # host RNG draw happened before the replay (_draw_pepper_static); an all-zero mask is the "no noise" draw
             self.fake_B = _PepperNoise.apply(self.fake_B, self._pepper_static)
+        elif self.device_pepper:
+            self._pepper_calls += 1
+            if random.uniform(0, 1) < 0.9:                                       # the per-call coin of helper.py:386 stays on the host
+                b, _, h, w = self.fake_B.shape
+                mask = hip.draw_pepper_mask(b, h, w, self._pepper_seed + 7919 * self.local_rank, self._pepper_calls, 0.98, self.device)
+                self.fake_B = _PepperNoise.apply(self.fake_B, mask)
         else:
             mask = draw_pepper_mask(self.fake_B.shape)
             if mask is not None:

@@ -487,3 +487,25 @@ def test_depth_metrics_against_oracle_and_golden(golden):
     got = m.evaluate_normalised(gt2.to(DEV), pd2.to(DEV), None).double().cpu().numpy()
     ref = np.stack([om.image_metrics(om.denormalise(gt2[k].numpy()), om.denormalise(pd2[k].numpy()), acc=np.float64) for k in range(8)])
     np.testing.assert_allclose(got, ref, rtol=5e-5, atol=1e-6)
+
+
+def test_device_pepper_mask_distribution_and_determinism():
+    """rdfc_draw_pepper_mask: the distribution of helper.py:384-402's np.random.choice((0, 1, 2), p=[snr, (1-snr)/2, (1-snr)/2]),
+    stateless in (seed, counter, pixel); RDFCGAN(device_pepper=True) uses it instead of the host draw"""
+    h = hip()
+    a = h.draw_pepper_mask(8, 228, 304, 1234, 1, 0.98, DEV)
+    b = h.draw_pepper_mask(8, 228, 304, 1234, 1, 0.98, DEV)
+    c = h.draw_pepper_mask(8, 228, 304, 1234, 2, 0.98, DEV)
+    d = h.draw_pepper_mask(8, 228, 304, 1235, 1, 0.98, DEV)
+    assert a.shape == (8, 1, 228, 304) and a.dtype == torch.uint8
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+    n = a.numel()
+    f = [float((a == k).sum()) / n for k in (0, 1, 2)]
+    sig = (0.01 * 0.99 / n) ** 0.5
+    assert abs(f[0] - 0.98) < 6 * (0.98 * 0.02 / n) ** 0.5 and abs(f[1] - 0.01) < 6 * sig and abs(f[2] - 0.01) < 6 * sig, f
+    # no structure along rows / between images: per-image replaced fractions scatter like a binomial
+    per = (a != 0).float().mean(dim=(1, 2, 3)).cpu().numpy()
+    assert np.abs(per - 0.02).max() < 6 * (0.02 * 0.98 / (228 * 304)) ** 0.5
+    img = torch.zeros(8, 3, 228, 304, device=DEV)
+    out = h.apply_pepper(img.clone(), a)
+    assert torch.equal(out[:, 0], out[:, 1]) and torch.equal((out[:, 0] == 1), (a[:, 0] == 1)) and torch.equal((out[:, 0] == -1), (a[:, 0] == 2))
