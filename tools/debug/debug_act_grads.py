@@ -1,6 +1,6 @@
 """Debug aid: gradient wrt the OUTPUT of every fused block, HIP (f32) vs CPU oracle (f64)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests', 'golden')]
 import torch, torch.nn as nn
 from cases import gen_inputs, out_weights

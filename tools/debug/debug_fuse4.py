@@ -1,5 +1,5 @@
 import os, sys, math
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests', 'golden')]
 import torch, torch.nn.functional as F
 from cases import gen_inputs, out_weights

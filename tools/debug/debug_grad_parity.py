@@ -1,7 +1,7 @@
 """Debug aid (GPU box): per-parameter gradient error of the HIP RDFGenerator (f32 mode) against the
 CPU oracle on the same weights / inputs, in registration order -- localises a backward bug."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests', 'golden')]
 import torch
 from cases import gen_inputs, out_weights, NLSPN_CFG
