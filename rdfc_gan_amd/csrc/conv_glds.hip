@@ -529,9 +529,7 @@ int launch(const GParams &p, const void *x, const void *w, const float *bias, vo
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
-    if (SPEC) rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d>", TCO, NW, NPROD);
-    else if (JR != 4) rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, 0, %d>", TCO, NW, JR);
-    else rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, NW);
+    rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d, %d>", TCO, NW, NPROD, JR);         // the symbol as rocprofv3 prints it
     // experiment knob: extra (unused) dynamic LDS, e.g. 40960 leaves room for ONE workgroup per CU
     static const int pad_lds = getenv("RDFC_GLDS_PAD_LDS") ? atoi(getenv("RDFC_GLDS_PAD_LDS")) : 0;
     hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, NW, NPROD, JR>), grid, dim3((NW + NPROD) * 64), SMEM + pad_lds, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
