@@ -256,8 +256,9 @@ def main():
                 if inum:
                     out['roofline']['isolated'] = dict(achieved=round(ifl / isec / 1e12, 2), frac=round(ifl / isec / 1e12 / peak, 4),
                                                        avg_launch_us=round(1e6 * isec / inum, 2), launches=inum,
-                                                       note='same kernel on one extra untimed single-stream step; rocprofv3 --kernel-trace serialises the '
-                                                            'streams, so its average matches this figure, not the in-step one')
+                                                       note='same kernel on one extra untimed single-stream step.  Under rocprofv3 the run is host-bound '
+                                                            '(~59 ms per step) and the streams overlap little, so the profiler average of this kernel sits '
+                                                            'near this figure; the in-step one is what the un-profiled, overlapped step measures')
             out['kernels'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), avg_launch_us=round(1e6 * v[1] / v[2], 2),
                                       launches=v[2], share_of_step=round(v[1] / (elapsed * ev_steps / a.steps), 4))
                               for k, v in sorted(sym.items(), key=lambda kv: -kv[1][1])[:8]}
