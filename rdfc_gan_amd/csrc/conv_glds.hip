@@ -43,6 +43,16 @@ constexpr int WRING = 5;
 #else
 constexpr int WRING = 4;
 #endif
+// 128-co tiles: a ring of 3 (weights fetched two phases ahead) makes the workgroup 48 KB of LDS -> THREE per CU (the kernel needs
+// 168 registers): 256->256 @ 57x76 58.4 -> 52.7 us (its 640 workgroups now fit one round), 128->128 @ 114x152 60.2 -> 53.1,
+// 256->128 @ 114x152 98.2 -> 94.0; the 64-co tiles (2 x 21 KB of patch) stay at two per CU either way.  RDFC_GLDS_RING overrides.
+#if defined(RDFC_GLDS_RING)
+template <int TCO> constexpr int ring_of() { return RDFC_GLDS_RING; }
+#elif defined(RDFC_GLDS_DEEP)
+template <int TCO> constexpr int ring_of() { return WRING; }
+#else
+template <int TCO> constexpr int ring_of() { return TCO == 128 ? 3 : WRING; }
+#endif
 
 __device__ inline int lay_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 2)) << 3); }
 
@@ -93,7 +103,8 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
     constexpr int NR = (NPIECE + NT - 1) / NT;                 // patch DMA rounds per slab (3 / 6)
     constexpr int NWP = TCO * 4 / NT;                          // weight DMAs per thread and tap (2 / 1)
     constexpr int WSLOT = TCO * BK * 2;                        // bytes per weight slot
-    constexpr int RING = SPEC ? 5 : WRING;                     // SPEC reads a phase's fragments one phase early: one more slot
+    constexpr int RING = SPEC ? 5 : (JR == 4 && NW == 4 ? ring_of<TCO>() : WRING);   // SPEC reads a phase's fragments one phase early: one more slot
+    constexpr int WLOOK = RING - 1;                            // unspecialised kernel: phases between a weight block's DMA and its use
     constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + RING * WSLOT;
     static_assert(NR <= 6, "patch rounds must be issued at least three phases before the slab ends");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -302,7 +313,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
 #pragma unroll
     for (int r = 0; r < NR; ++r) issue_p(r, 0);
 #pragma unroll
-    for (int h = 0; h < WRING - 1; ++h) issue_w(h);
+    for (int h = 0; h < WLOOK; ++h) issue_w(h);
 
     // phase (cc, TAP): DMAs still allowed in flight at its wait = those issued in the two previous phases
 #if defined(RDFC_GLDS_EXP_NODMA)      /* timing experiment only (wrong results): no DMA in the main loop */
@@ -316,20 +327,20 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
     {                                                                                                          \
         constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
         wait_vm<ALLOW>();                                                                                      \
-        issue_w(it0 + TAP + 3);                                                                                \
+        issue_w(it0 + TAP + WLOOK);                                                                            \
         if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
         compute(it0 + TAP, cc, TAP);                                                                           \
     }
 #elif !defined(RDFC_GLDS_DEEP)
 #define RDFC_GLDS_PHASE(TAP)                                                                                   \
     {                                                                                                          \
-        constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
+        constexpr int ALLOW = (WLOOK - 1) * NWP + (WLOOK >= 3 && ((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0); \
         RDFC_STAMP(TAP, 0)                                                                                     \
         wait_vm<ALLOW>();                                                                                      \
         RDFC_STAMP(TAP, 1)                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                          \
         RDFC_STAMP(TAP, 2)                                                                                     \
-        issue_w(it0 + TAP + 3);                                                                                \
+        issue_w(it0 + TAP + WLOOK);                                                                            \
         if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
         RDFC_STAMP(TAP, 3)                                                                                     \
         {                                                                                                      \
@@ -522,7 +533,7 @@ int launch(const GParams &p, const void *x, const void *w, const float *bias, vo
     constexpr bool SPEC = NPROD > 0;
     constexpr int NT = NW * 64, TR = JR * NW / (TCO / 64);
     constexpr int NPIECE = (TR + 2) * PW * 4, PATCH = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;
-    constexpr int SMEM = 2 * PATCH + (SPEC ? 5 : WRING) * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
+    constexpr int SMEM = 2 * PATCH + (SPEC ? 5 : (JR == 4 && NW == 4 ? ring_of<TCO>() : WRING)) * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW, NPROD, JR>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM + 65536) != hipSuccess) return 0;
