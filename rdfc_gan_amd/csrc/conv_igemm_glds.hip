@@ -43,7 +43,13 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
     constexpr int WCO = TCO / 64, WPX = 4 / WCO;                // waves along co / px: each 64 co x 64 px
     constexpr int NA = TCO * 4 / NT, NB = TPX * 4 / NT;         // DMAs per thread and K-step: weights (2 / 1), pixels (2 / 4)
     constexpr int AB = TCO * BK * 2, SLOT = AB + TPX * BK * 2;  // 16 KB / 20 KB
-    constexpr int RING = TCO == 128 ? 4 : 3, LOOK = RING - 1;   // 64 KB / 60 KB of ring: two workgroups per CU either way
+#ifdef RDFC_IGEMM_GLDS_RING
+    constexpr int RING = RDFC_IGEMM_GLDS_RING, LOOK = RING - 1;
+#else
+    // three slots either way: 48 KB (three workgroups per CU; with four slots and two workgroups 4x4/s2 64->128 @ 228x304 ran 80.9 us,
+    // now 68.5; 128->256 @ 114x152 81.1 -> 74.6) / 60 KB
+    constexpr int RING = 3, LOOK = RING - 1;
+#endif
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     __shared__ int tap_w[MAXTAPS], tap_dy[MAXTAPS], tap_dx[MAXTAPS], ntaps_s;
     __shared__ int pxo[TPX];
@@ -248,7 +254,11 @@ const bf16_t *zero_page() {
 template <int TCO>
 int launch(const IGParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, hipStream_t st) {
     constexpr int TPX = TCO == 128 ? 128 : 256;
-    constexpr int SMEM = (TCO == 128 ? 4 : 3) * (TCO + TPX) * BK * 2;
+#ifdef RDFC_IGEMM_GLDS_RING
+    constexpr int SMEM = RDFC_IGEMM_GLDS_RING * (TCO + TPX) * BK * 2;
+#else
+    constexpr int SMEM = 3 * (TCO + TPX) * BK * 2;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)igemm_glds_kernel<TCO>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;

@@ -56,6 +56,12 @@ template <int ROWB> __device__ inline bf16x8 tr_frag(const unsigned char *img, i
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// k-step ring (slots of dY + X rows filled WG_RING-1 steps ahead)
+#ifndef RDFC_WGRAD_GLDS_RING
+#define RDFC_WGRAD_GLDS_RING 4
+#endif
+constexpr int WG_RING = RDFC_WGRAD_GLDS_RING;
+
 template <int TCO, int NKY>   // NKY = 1: one kernel row (3 taps) per workgroup; NKY = 3: all nine taps (64 x 64 tiles only)
 __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                            float *__restrict__ dw, const bf16_t *__restrict__ zero) {
@@ -115,12 +121,12 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
     int cn = seg0 / (p.Ho * p.segs_per_row);
     int rem = seg0 - cn * p.Ho * p.segs_per_row;
     int coy = rem / p.segs_per_row, csx = rem - coy * p.segs_per_row;
-    auto issue = [&](int s) {                                   // DMAs of k-step s (s >= nseg: zero page only) into ring slot s & 3
+    auto issue = [&](int s) {                                   // DMAs of k-step s (s >= nseg: zero page only) into ring slot s % WG_RING
         const bool live = s < nseg;
         const int ox0 = csx * SEG, iy = coy - p.pad + ky, ix0 = ox0 - p.pad;
         const bf16_t *yb = dy + ((size_t)(cn * p.Ho + coy) * p.Wo + ox0) * p.ldy;
         const bf16_t *xb = x + ((long)(cn * p.Hi + iy) * p.Wi + ix0) * p.ldx;
-        const unsigned slot = lds0 + (s & 3) * SLOT;
+        const unsigned slot = lds0 + (s % WG_RING) * SLOT;
 #pragma unroll
         for (int k = 0; k < NY; ++k) {
             const bool ok = live && ox0 + ypx[k] < p.Wo;
@@ -149,14 +155,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
 #pragma unroll
             for (int j = 0; j < NTF; ++j) acc[t][i][j] = f32x4{0, 0, 0, 0};
 
-    issue(0);
-    issue(1);
-    issue(2);
+#pragma unroll
+    for (int h = 0; h < WG_RING - 1; ++h) issue(h);
     for (int s = 0; s < nseg; ++s) {
-        wait_vm<2 * PER_STEP>();                                // k-steps s+1, s+2 may stay in flight
+        wait_vm<(WG_RING - 2) * PER_STEP>();                    // the k-steps after s that are already issued may stay in flight
         __builtin_amdgcn_s_barrier();
-        issue(s + 3);                                           // slot (s+3)&3 = (s-1)&3: every wave is past its reads (barrier)
-        const unsigned char *Ys = smem + (s & 3) * SLOT, *Xs = Ys + YB;
+        issue(s + WG_RING - 1);                                 // the slot of k-step s-1: every wave is past its reads (barrier)
+        const unsigned char *Ys = smem + (s % WG_RING) * SLOT, *Xs = Ys + YB;
         bf16x8 a[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) a[i] = tr_frag<YROW>(Ys, 0, wr * WTCO + 16 * i, lane);
@@ -204,7 +209,7 @@ const bf16_t *zero_page() {
 
 template <int TCO, int NKY>
 int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
-    constexpr int SMEM = 4 * (SEG * TCO * 2 + ((NKY * XPX * 8 + NT - 1) / NT) * NT * 16);
+    constexpr int SMEM = WG_RING * (SEG * TCO * 2 + ((NKY * XPX * 8 + NT - 1) / NT) * NT * 16);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)wgrad_glds_kernel<TCO, NKY>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
@@ -212,11 +217,15 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     }
     p.tiles_ci = cdiv(p.Ci, 64);
     const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * (3 / NKY);
-    // Split-K factor: fill the chip's 512 workgroup slots (2 per CU) in ONE round -- 528 workgroups measured 1.3x slower
+    // Split-K factor: fill the chip's workgroup slots in ONE round -- 528 workgroups measured 1.3x slower
     // than 480 -- within an atomic budget of 48 MB per launch (sweep on one device, 256->256 @ 57x76: 24 MB / 240
     // workgroups 108 us, 48 MB / 480 workgroups 91 us; under-filling the chip costs more than the extra atomics).
     static const double cap_mb = getenv("RDFC_WGRAD_ATOMIC_MB") ? atof(getenv("RDFC_WGRAD_ATOMIC_MB")) : 48.0;
-    int slices = 512 / tiles;
+    // workgroups the chip holds at once: the 64-co kernel (48 KB of LDS, 104 registers) fits three per CU, the 128-co one two.
+    // Sizing the 64-co launches for 768 instead of 512: 64->64 @ 228x304 87 -> 80 us, 256->128 @ 114x152 154 -> 132, 128->64 @ 228x304 158 -> 141
+    static const int slots_env = getenv("RDFC_WGRAD_SLOTS") ? atoi(getenv("RDFC_WGRAD_SLOTS")) : 0;
+    const int slots = slots_env ? slots_env : (TCO == 64 && NKY == 1 ? 768 : 512);
+    int slices = slots / tiles;
     const int atomic_cap = (int)(cap_mb * 1.0e6 / (4.0 * p.Co * p.Ci * 9));
     if (slices > atomic_cap) slices = atomic_cap;
     if (slices > cdiv(p.total_segs, 8)) slices = cdiv(p.total_segs, 8);
