@@ -154,6 +154,15 @@ int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const 
                         const float *beta, const void *res, const float *sums, void *dx, void *dres,
                         int G, int P, int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype,
                         int act, float slope, const float *prelu, int frozen_stats, void *stream);
+/* One layer's launches behind one call (same kernels, order and stream as the three calls they stand for; the step is partly
+ * launch-bound).  scratch: f32 [G * rdfc_norm_nchunk(P, C, dtype) * 2 * C] (forward) / [... * 3 * C] (backward). */
+int rdfc_norm_forward(const void *x, float *scratch, float *mean, float *rstd, const float *gamma, const float *beta,
+                      const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
+                      float *run_mean, float *run_var, float momentum, int act, float slope, const float *prelu, void *stream);
+int rdfc_norm_backward(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                       const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P, int C,
+                       int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope, const float *prelu,
+                       int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream);
 
 /* One-stage variants of the four calls above: workgroups add their sums to pre-zeroed f64 accumulators with hardware
  * atomics (sums64[G][2][C] = {sum x, sum x^2}, resp. [G][3][C]) and the consumer derives what it needs from them, so the

@@ -689,6 +689,30 @@ extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *m
     return 0;
 }
 
+// ---- composites: the launches of one layer's forward / backward behind ONE call (the step makes ~360 of them and is partly
+//      launch-bound; a ctypes call costs the host ~4-5 us).  Same kernels, same order, same stream.
+//      scratch (f32): forward [G * nchunk * 2 * C] partials; backward [G * nchunk * 3 * C] partials.
+extern "C" int rdfc_norm_forward(const void *x, float *scratch, float *mean, float *rstd, const float *gamma, const float *beta,
+                                 const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
+                                 float *run_mean, float *run_var, float momentum, int act, float slope, const float *prelu,
+                                 void *stream) {
+    if (int e = rdfc_norm_stats(x, scratch, G, P, C, ldx, dtype, stream)) return e;
+    if (int e = rdfc_norm_finalize(scratch, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, momentum, stream)) return e;
+    return rdfc_norm_apply(x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, act, slope, prelu, stream);
+}
+
+extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                                  const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P,
+                                  int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
+                                  const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream) {
+    if (int e = rdfc_norm_bwd_reduce(dz, x, mean, rstd, gamma, beta, res, scratch, G, P, C, lddz, ldx, ldr, dtype, act, slope, prelu,
+                                     stream))
+        return e;
+    if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, dbeta_acc, dgamma_acc, stream)) return e;
+    return rdfc_norm_bwd_apply(dz, x, mean, rstd, gamma, beta, res, sums, dx, dres, G, P, C, lddz, ldx, ldr, lddx, lddr, dtype, act,
+                               slope, prelu, frozen_stats, stream);
+}
+
 // ---- one-stage variants: f64 atomics instead of partial buffers + finalize launches ---------------------------------
 extern "C" int rdfc_norm_stats_acc(const void *x, double *sums64, int G, int P, int C, int ld, int dtype, void *stream) {
     if (int e = check_map("rdfc_norm_stats_acc", G, P, C, dtype, {ld})) return e;

@@ -236,8 +236,8 @@ class _ConvBlock(torch.autograd.Function):
                 mean, rstd = fused
                 hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
             elif _DETERMINISTIC:
-                mean, rstd = hip.norm_stats(y, G, spec.eps, run_mean if upd else None, run_var if upd else None, spec.momentum)
-                hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
+                mean, rstd = hip.norm_forward(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
+                                              run_mean if upd else None, run_var if upd else None, spec.momentum)
             else:
                 mean, rstd = hip.norm_forward_onestage(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
                                                        run_mean if upd else None, run_var if upd else None, spec.momentum)

@@ -316,8 +316,30 @@ def reflect_pad_adjoint(dpad, pad):
 
 
 # --------------------------------------------------------------------------- normalisation
+_nchunk_cache = {}
+
+
 def norm_nchunk(P, Cc, dtype_code):
-    return lib().rdfc_norm_nchunk(P, Cc, dtype_code)
+    key = (P, Cc, dtype_code)
+    n = _nchunk_cache.get(key)
+    if n is None:
+        n = _nchunk_cache[key] = lib().rdfc_norm_nchunk(P, Cc, dtype_code)
+    return n
+
+
+def norm_forward(x, G, eps, gamma, beta, res, z, act='none', slope=0.0, prelu=None, run_mean=None, run_var=None, momentum=0.1):
+    """statistics + finalize + normalise(+residual)(+activation) in one call -> (mean[G,C], rstd[G,C]); z is written"""
+    N, H, W, Cc = x.shape
+    P = N * H * W // G
+    d = dt(x)
+    npart = G * norm_nchunk(P, Cc, d) * 2 * Cc
+    buf = torch.empty(npart + 2 * G * Cc, dtype=torch.float32, device=x.device)      # [partials | mean | rstd]
+    base = buf.data_ptr()
+    _chk(lib().rdfc_norm_forward(_p(x), base, base + 4 * npart, base + 4 * (npart + G * Cc), _p(gamma), _p(beta), _p(res), _p(z), G, P,
+                                 Cc, ld(x), ld(res) if res is not None else 0, ld(z), d, _f(eps), _p(run_mean), _p(run_var),
+                                 _f(momentum), ACT[act], _f(slope), _p(prelu), _st()), 'rdfc_norm_forward')
+    stats = buf[npart:].view(2, G, Cc)
+    return stats[0], stats[1]
 
 
 def norm_stats(x, G, eps, run_mean=None, run_var=None, momentum=0.1):
@@ -408,24 +430,21 @@ def norm_apply(x, mean, rstd, gamma, beta, res, z, act='none', slope=0.0, prelu=
 def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, prelu=None, frozen=False,
                   want_dres=False, acc_beta=None, acc_gamma=None):
     """-> dx, dres (or None), sums[G,3,C] (sum du, sum du*xhat, sum dz*min(u,0)).
-    acc_beta / acc_gamma: f32[C] buffers that additionally receive += sums[0,0] / sums[0,1] (G == 1 only)."""
+    acc_beta / acc_gamma: f32[C] buffers that additionally receive += sums[0,0] / sums[0,1] (G == 1 only).
+    One call: reduce + finalize + apply (rdfc_norm_backward)."""
     N, H, W, Cc = x.shape
     G = mean.shape[0]
     P = N * H * W // G
-    nch = norm_nchunk(P, Cc, dt(x))
-    partial = torch.empty(G * nch * 3 * Cc, dtype=torch.float32, device=x.device)
-    sums = torch.empty(G, 3, Cc, dtype=torch.float32, device=x.device)
-    ldr = ld(res) if res is not None else 0
-    _chk(lib().rdfc_norm_bwd_reduce(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(partial), G, P, Cc,
-                                    ld(dz), ld(x), ldr, dt(x), ACT[act], _f(slope), _p(prelu), _st()), 'rdfc_norm_bwd_reduce')
-    _chk(lib().rdfc_norm_bwd_finalize_acc(_p(partial), _p(sums), G, P, Cc, dt(x), _p(acc_beta), _p(acc_gamma), _st()),
-         'rdfc_norm_bwd_finalize_acc')
+    d = dt(x)
+    npart = G * norm_nchunk(P, Cc, d) * 3 * Cc
+    buf = torch.empty(npart + G * 3 * Cc, dtype=torch.float32, device=x.device)       # [partials | sums]
+    base = buf.data_ptr()
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
     dres = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device) if want_dres else None
-    _chk(lib().rdfc_norm_bwd_apply(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(sums), _p(dx), _p(dres),
-                                   G, P, Cc, ld(dz), ld(x), ldr, Cc, Cc, dt(x), ACT[act], _f(slope), _p(prelu), int(frozen),
-                                   _st()), 'rdfc_norm_bwd_apply')
-    return dx, dres, sums
+    _chk(lib().rdfc_norm_backward(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), base, base + 4 * npart, _p(dx),
+                                  _p(dres), G, P, Cc, ld(dz), ld(x), ld(res) if res is not None else 0, Cc, Cc, d, ACT[act], _f(slope),
+                                  _p(prelu), int(frozen), _p(acc_beta), _p(acc_gamma), _st()), 'rdfc_norm_backward')
+    return dx, dres, buf[npart:].view(G, 3, Cc)
 
 
 def adain_apply(x, mean, rstd, gb, out):
