@@ -136,3 +136,29 @@ def test_label_net_batch_of_one_in_train_mode_raises_like_upstream():
         net(x)
     net.eval()
     assert net(x).shape == (1, LABEL_CASE['classes'], 48, 64)
+
+
+def test_label_net_full_resolution_train_mode_against_oracle():
+    """228x304, batch 2, train mode, f32 mode: 57x76 -> 29x38 trunk maps (odd sizes through the stride-2 stem, the max pool and
+    layer2), the four pyramid bins on a 29x38 map and the x8 logit upsampling, forward and input gradient against the CPU oracle"""
+    from oracle.label_net import PSPNet as Oracle
+    net = build(torch.float32).train()
+    ref = Oracle(LABEL_CASE['classes'])
+    ref.load_state_dict(label_net_weights(ref.state_dict()))
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    ref.train()
+    x = gen_inputs('label_full_train', 2, 228, 304)[0]
+    w = torch.randn(2, LABEL_CASE['classes'], 228, 304, generator=torch.Generator().manual_seed(9))
+    xr = x.clone().requires_grad_(True)
+    o_ref, a_ref = ref(xr)
+    ((o_ref + 0.4 * a_ref) * w).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    o, a = net(xg)
+    ((o + 0.4 * a) * w.to(DEV)).sum().backward()
+    eo, ea = float((o.detach().cpu() - o_ref.detach()).abs().max()), float((a.detach().cpu() - a_ref.detach()).abs().max())
+    g, gr = xg.grad.cpu().double(), xr.grad.double()
+    eg = float((g - gr).norm() / gr.norm())
+    print(f'[parity] out {eo:.2e} aux {ea:.2e} (|max| {float(o_ref.abs().max()):.2f}) grad_in L2 {eg:.2e}')
+    assert eo < 5e-4 and ea < 5e-4 and eg < 2e-2          # f32 mode (measured 2.4e-4 / 1.7e-5 / 8e-3); logits reach |max| ~ 4 through 53 train-mode BatchNorms
