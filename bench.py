@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--exact-schedule', action='store_true', help="run upstream's two dead forwards too")
     ap.add_argument('--label-net', action='store_true', help='SURVEY 8f rank 1 (not the headline workload): G_label (PSPNet) twice '
                     'per step + label cross entropy + normal-consistency terms + its Adam')
+    ap.add_argument('--full-objective', action='store_true', help="--label-net plus G_normal (decoder on HIP behind the tests' stock-PyTorch "
+                    'stand-in encoder): every term of upstream loss_G, six networks, four optimizers (not the headline workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the step into HIP graphs and replay them (single stream; on ROCm 7.2 the '
@@ -137,7 +139,13 @@ def main():
     torch.manual_seed(0)
     random.seed(1234 + rank)
     np.random.seed(1234 + rank)
-    model = RDFCGAN(dev, world > 1, model_cfg(a.nlspn), is_train=True, exact_schedule=a.exact_schedule, use_label_net=a.label_net)
+    kw = {}
+    if a.full_objective:
+        from cases import StandInEncoder
+        from rdfc_gan_amd.normal_net import NNET
+        a.label_net = True
+        kw = dict(normal_net=NNET(a.height, a.width, encoder=StandInEncoder()), out_height=a.height, out_width=a.width)
+    model = RDFCGAN(dev, world > 1, model_cfg(a.nlspn), is_train=True, exact_schedule=a.exact_schedule, use_label_net=a.label_net, **kw)
     model.train()
     batches = [synth_batch(a.batch, a.height, a.width, 1234 + rank * 100 + i, dev) for i in range(2)]
 
@@ -211,7 +219,7 @@ def main():
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * elapsed / a.steps, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.dtype, data='synthetic',
                    config=dict(workload=f'RDFCGAN.optimize_parameters: G_A2B(RDFGenerator, NLSPN {"on" if a.nlspn else "off"}) + '
-                                        f'G_B2A(ResnetGenerator IN2d) + D_A + D_B (PatchGAN){" + G_label (PSPNet-ResNet50) x2 + label / normal terms" if a.label_net else ""}, fwd+bwd+Adam, {a.height}x{a.width}, '
+                                        f'G_B2A(ResnetGenerator IN2d) + D_A + D_B (PatchGAN){" + G_label (PSPNet-ResNet50) x2 + label / normal terms" if a.label_net else ""}{" + G_normal (decoder; stand-in encoder) x3" if a.full_objective else ""}, fwd+bwd+Adam, {a.height}x{a.width}, '
                                         f'batch {a.batch}/GPU, random-init weights',
                                global_batch=world * a.batch, parallelism=f'dp{world}',
                                dead_forwards='executed' if a.exact_schedule else 'elided (result-identical, see DESIGN.md)',
@@ -242,7 +250,7 @@ def main():
             # committed rocprofv3 passes over this same command (tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
             # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and only apply to the default workload
             tfile = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            default_wl = (a.batch, a.height, a.width, a.dtype, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, 'bf16', False, False, False)
+            default_wl = (a.batch, a.height, a.width, a.dtype, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, 'bf16', False, False, False)   # (--full-objective sets label_net)
             if default_wl and os.path.exists(tfile):
                 for k, v in json.load(open(tfile)).items():
                     if top + '(' in k:
