@@ -125,11 +125,16 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (there is no CPU fallback for the HIP path)'
+    # (test hooks: RDFC_BENCH_DEVICE pins every rank to one device and RDFC_BENCH_BACKEND=gloo replaces RCCL, so that the N > 1
+    #  control flow can be exercised with two ranks on a one-GPU box -- tests/test_dp_gpu.py; RCCL itself needs a GPU per rank)
+    if os.environ.get('RDFC_BENCH_DEVICE') is not None:
+        local = int(os.environ['RDFC_BENCH_DEVICE'])
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('RDFC_BENCH_BACKEND', 'nccl')
+        dist.init_process_group(backend, **(dict(device_id=dev) if backend == 'nccl' else {}))
     assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
     from rdfc_gan_amd import functional as Fh

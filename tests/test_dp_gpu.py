@@ -22,3 +22,20 @@ def test_two_ranks_stay_identical(full):
     assert 'max parameter difference between replicas after 2 steps = 0.000e+00' in out, out[-3000:]
     if full:
         assert "optimizers ['D', 'G', 'Nor', 'label']" in out, out[-3000:]
+
+
+def test_bench_multi_rank_control_flow():
+    """bench.py's N > 1 path (barriers, max over ranks, the extra isolated step on every rank, one JSON line from rank 0) with two
+    ranks on the one test GPU over gloo (RDFC_BENCH_DEVICE / RDFC_BENCH_BACKEND hooks; the driver's runs use RCCL, one GPU per rank)"""
+    import json
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', RDFC_BENCH_DEVICE='0', RDFC_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29519', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2',
+           '--height', '64', '--width', '80']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2' and d['scaling'] == 'weak'
+    assert d['value'] > 0 and 'roofline' in d and 'cpu_baseline' not in d            # cpu_baseline: N = 1 only
