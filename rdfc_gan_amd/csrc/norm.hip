@@ -10,6 +10,8 @@
 // deterministic, no atomics.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int NT = 256;
@@ -27,8 +29,10 @@ struct Map {       // geometry shared by the kernels
 inline int chunk_pixels(int P, int C, int vec) {
     const int cvt = C / vec < NT ? (C / vec > 0 ? C / vec : 1) : NT;
     const int rpb = NT / cvt;
+    static const int min_rows = getenv("RDFC_NORM_MIN_ROWS") ? atoi(getenv("RDFC_NORM_MIN_ROWS")) : 8;   // A/B knob
+    static const int want_wg = getenv("RDFC_NORM_WANT_WG") ? atoi(getenv("RDFC_NORM_WANT_WG")) : 512;
     int rows = 32;
-    while (rows > 8 && P / (rows * rpb) < 512) rows >>= 1;
+    while (rows > min_rows && P / (rows * rpb) < want_wg) rows >>= 1;
     int chunk = rows * rpb;
     const int lo = cdiv(P, 4096);
     if (chunk < lo) chunk = cdiv(lo, rpb) * rpb;
