@@ -125,56 +125,46 @@ inline dim3 grid_for(const Map &m, int vec) {
 template <typename T, int K>
 __device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K][Elem<T>::VEC], float *partial,
                                    double *acc64 = nullptr) {
+    // Every thread deposits its K x VEC sums in LDS ([k][thread][v], 16-byte stores), then the K * CVT * VEC outputs are dealt to
+    // ALL 256 threads: output o = (k, channel vector, v) sums its RPB rows (fixed order r = 0 .. RPB-1: reproducible) and is stored
+    // with its neighbours in one coalesced line.  (Before: a butterfly of 24 runtime-offset shuffles plus a tail in which CVT
+    // threads added and stored everything -- 6.6 of bwd_reduce's 21.7 us on a 256-channel 57x76 map, tools/scratch/redexp.sh.)
     constexpr int VEC = Elem<T>::VEC;
-    __shared__ float red[K * NT * VEC];
+    __shared__ __attribute__((aligned(16))) float red[K * NT * VEC];
     const int t = threadIdx.x;
-    const int CVT = min(m.C / VEC - (int)blockIdx.z * NT, NT);
-    const bool wave_tree = CVT < 64 && (64 % CVT) == 0;
-    if (wave_tree) {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                float a = cx.active ? s[k][v] : 0.f;
-                for (int off = CVT; off < 64; off <<= 1) a += __shfl_xor(a, off, 64);
-                s[k][v] = a;
-            }
-        const int lane = t & 63, wave = t >> 6;
-        if (lane < CVT) {
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) red[((k * 4 + wave) * 64 + lane) * VEC + v] = s[k][v];
-        }
-        __syncthreads();
-        if (t < CVT) {
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    float a = 0.f;
-                    for (int w = 0; w < NT / 64; ++w) a += red[((k * 4 + w) * 64 + t) * VEC + v];
-                    if (acc64 != nullptr) unsafeAtomicAdd(&acc64[((size_t)cx.g * K + k) * m.C + cx.c0 + v], (double)a);
-                    else partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + cx.c0 + v] = a;
-                }
-        }
-        return;
-    }
+    const int CVT = min(m.C / VEC - (int)blockIdx.z * NT, NT), RPB = NT / CVT;
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) red[(k * NT + t) * VEC + v] = cx.active ? s[k][v] : 0.f;
+        for (int q = 0; q < VEC / 4; ++q)
+            *reinterpret_cast<f32x4 *>(&red[(k * NT + t) * VEC + 4 * q]) =
+                cx.active ? f32x4{s[k][4 * q], s[k][4 * q + 1], s[k][4 * q + 2], s[k][4 * q + 3]} : f32x4{0, 0, 0, 0};
     __syncthreads();
-    if (cx.active && cx.r0 == 0) {
+    const int per_k = CVT * VEC, nout = K * per_k;
+    const int cbase = (int)blockIdx.z * NT * VEC;
+    for (int o = t; o < nout; o += NT) {
+        const int k = o / per_k, cvv = o - k * per_k;            // cvv = channel-vector * VEC + v: the channel offset inside the slab
+        const int cvt = cvv / VEC, v = cvv - cvt * VEC;
+        float a = 0.f;
+        for (int r = 0; r < RPB; ++r) a += red[(k * NT + r * CVT + cvt) * VEC + v];
+        const int c = cbase + cvv;
+        if (acc64 != nullptr) unsafeAtomicAdd(&acc64[((size_t)cx.g * K + k) * m.C + c], (double)a);
+        else partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + c] = a;
+    }
+}
+
+// VEC consecutive f32 per-channel constants with 16-byte loads (c0 is a multiple of VEC; torch allocations are 256-byte aligned)
+template <int VEC>
+__device__ __forceinline__ void load_consts(const float *__restrict__ p, int idx, float dflt, float (&o)[VEC]) {
+    if (p == nullptr) {
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+        for (int v = 0; v < VEC; ++v) o[v] = dflt;
+        return;
+    }
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                float a = 0.f;
-                for (int r = 0; r < cx.RPB; ++r) a += red[(k * NT + r * CVT + t) * VEC + v];
-                if (acc64 != nullptr) unsafeAtomicAdd(&acc64[((size_t)cx.g * K + k) * m.C + cx.c0 + v], (double)a);
-                else partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + cx.c0 + v] = a;
-            }
+    for (int q = 0; q < VEC / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(p + idx + 4 * q);
+        o[4 * q] = t[0]; o[4 * q + 1] = t[1]; o[4 * q + 2] = t[2]; o[4 * q + 3] = t[3];
     }
 }
 
@@ -286,6 +276,18 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
     Ctx<T> cx(m);
     if (!cx.active) return;
     float sc[VEC], sh[VEC];
+    if (a.sums64 == nullptr) {          // two-stage path (the default): constants by 16-byte loads
+        float gav[VEC], bev[VEC], rsv[VEC], muv[VEC];
+        load_consts<VEC>(a.gamma, cx.c0, 1.f, gav);
+        load_consts<VEC>(a.beta, cx.c0, 0.f, bev);
+        load_consts<VEC>(a.rstd, cx.g * m.C + cx.c0, 1.f, rsv);
+        load_consts<VEC>(a.mean, cx.g * m.C + cx.c0, 0.f, muv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            sc[v] = gav[v] * rsv[v];
+            sh[v] = bev[v] - muv[v] * gav[v] * rsv[v];
+        }
+    } else
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         const int c = cx.c0 + v;
@@ -336,14 +338,15 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
     for (int v = 0; v < VEC; ++v) s[0][v] = s[1][v] = s[2][v] = 0.f;
     if (cx.active) {
         float sc[VEC], sh[VEC], mu[VEC], rs[VEC];
+        float gav[VEC], bev[VEC];
+        load_consts<VEC>(a.gamma, cx.c0, 1.f, gav);
+        load_consts<VEC>(a.beta, cx.c0, 0.f, bev);
+        load_consts<VEC>(a.rstd, cx.g * m.C + cx.c0, 1.f, rs);
+        load_consts<VEC>(a.mean, cx.g * m.C + cx.c0, 0.f, mu);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const int c = cx.c0 + v;
-            const float ga = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
-            rs[v] = a.rstd[cx.g * m.C + c];
-            mu[v] = a.mean[cx.g * m.C + c];
-            sc[v] = ga * rs[v];                 // the forward's (apply_kernel) pre-activation, bit for bit,
-            sh[v] = be - mu[v] * ga * rs[v];    // so the activation mask cannot disagree with the forward
+            sc[v] = gav[v] * rs[v];                       // the forward's (apply_kernel) pre-activation, bit for bit,
+            sh[v] = bev[v] - mu[v] * gav[v] * rs[v];      // so the activation mask cannot disagree with the forward
         }
         const float ns = neg_slope_of(a);
         const bool want_slope_grad = a.act == RDFC_ACT_PRELU;
@@ -404,17 +407,21 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const
     // one-stage path: the f64 sums of rdfc_norm_bwd_reduce_acc; one thread per (group, channel) rounds them to the f32
     // `sums` the two-stage path would have produced (sums_out) and adds the affine gradients to their .grad
     const bool one_stage = sums64 != nullptr;
+    float bev[VEC], s1v[VEC], s2v[VEC];
+    load_consts<VEC>(a.gamma, cx.c0, 1.f, ga);
+    load_consts<VEC>(a.beta, cx.c0, 0.f, bev);
+    load_consts<VEC>(a.rstd, cx.g * m.C + cx.c0, 1.f, rs);
+    load_consts<VEC>(a.mean, cx.g * m.C + cx.c0, 0.f, mu);
+    load_consts<VEC>(one_stage ? nullptr : sums, (cx.g * 3 + 0) * m.C + cx.c0, 0.f, s1v);
+    load_consts<VEC>(one_stage ? nullptr : sums, (cx.g * 3 + 1) * m.C + cx.c0, 0.f, s2v);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         const int c = cx.c0 + v;
-        ga[v] = a.gamma ? a.gamma[c] : 1.f;
-        const float be = a.beta ? a.beta[c] : 0.f;
-        rs[v] = a.rstd[cx.g * m.C + c];
-        mu[v] = a.mean[cx.g * m.C + c];
+        const float be = bev[v];
         sc[v] = ga[v] * rs[v];
         sh[v] = be - mu[v] * ga[v] * rs[v];
-        const float S1 = one_stage ? (float)sums64[((size_t)cx.g * 3 + 0) * m.C + c] : sums[(cx.g * 3 + 0) * m.C + c];
-        const float S2 = one_stage ? (float)sums64[((size_t)cx.g * 3 + 1) * m.C + c] : sums[(cx.g * 3 + 1) * m.C + c];
+        const float S1 = one_stage ? (float)sums64[((size_t)cx.g * 3 + 0) * m.C + c] : s1v[v];
+        const float S2 = one_stage ? (float)sums64[((size_t)cx.g * 3 + 1) * m.C + c] : s2v[v];
         m1[v] = frozen ? 0.f : S1 * invP;
         m2[v] = frozen ? 0.f : S2 * invP;
         if (one_stage && cx.chunk == 0 && cx.r0 == 0) {
