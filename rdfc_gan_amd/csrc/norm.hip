@@ -467,11 +467,8 @@ __global__ __launch_bounds__(NT) void adain_apply_kernel(Map m, const float *__r
     Ctx<T> cx(m);
     if (!cx.active) return;
     float mu[VEC], rs[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        mu[v] = mean[cx.g * m.C + cx.c0 + v];
-        rs[v] = rstd[cx.g * m.C + cx.c0 + v];
-    }
+    load_consts<VEC>(mean, cx.g * m.C + cx.c0, 0.f, mu);
+    load_consts<VEC>(rstd, cx.g * m.C + cx.c0, 1.f, rs);
     const size_t gb = (size_t)cx.g * m.P;
     auto body = [&](int p) {
         Vec16<T> xv, gv, bv, o;
@@ -497,11 +494,8 @@ __global__ __launch_bounds__(NT) void adain_bwd_reduce_kernel(Map m, const float
     for (int v = 0; v < VEC; ++v) s[0][v] = s[1][v] = s[2][v] = 0.f;
     if (cx.active) {
         float mu[VEC], rs[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            mu[v] = mean[cx.g * m.C + cx.c0 + v];
-            rs[v] = rstd[cx.g * m.C + cx.c0 + v];
-        }
+        load_consts<VEC>(mean, cx.g * m.C + cx.c0, 0.f, mu);
+        load_consts<VEC>(rstd, cx.g * m.C + cx.c0, 1.f, rs);
         const size_t gb = (size_t)cx.g * m.P;
         auto body = [&](int p) {
             Vec16<T> dv, xv, gv;
@@ -532,13 +526,14 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(Map m, const float 
     if (!cx.active) return;
     float mu[VEC], rs[VEC], m1[VEC], m2[VEC];
     const float invP = 1.f / (float)m.P;
+    load_consts<VEC>(mean, cx.g * m.C + cx.c0, 0.f, mu);
+    load_consts<VEC>(rstd, cx.g * m.C + cx.c0, 1.f, rs);
+    load_consts<VEC>(sums, (cx.g * 3 + 0) * m.C + cx.c0, 0.f, m1);
+    load_consts<VEC>(sums, (cx.g * 3 + 1) * m.C + cx.c0, 0.f, m2);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-        const int c = cx.c0 + v;
-        mu[v] = mean[cx.g * m.C + c];
-        rs[v] = rstd[cx.g * m.C + c];
-        m1[v] = sums[(cx.g * 3 + 0) * m.C + c] * invP;
-        m2[v] = sums[(cx.g * 3 + 1) * m.C + c] * invP;
+        m1[v] *= invP;
+        m2[v] *= invP;
     }
     const size_t gb = (size_t)cx.g * m.P;
     auto body = [&](int p) {
