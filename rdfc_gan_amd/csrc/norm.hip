@@ -200,18 +200,21 @@ constexpr int FL = 32, FNT = 32 * FL;
 __device__ inline double chunk_sum(const float *__restrict__ partial, int g, int K, int k, int C, int c, int nchunk,
                                    double *red /* [FL][32] */) {
     const int lane = threadIdx.x >> 5, cl = threadIdx.x & 31;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;          // fixed association -> still deterministic, 4 loads in flight
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // fixed association -> still deterministic; 8 loads in flight (a lane has ~17)
     if (c < C) {
+        const float *base = partial + ((size_t)g * nchunk * K + k) * C + c;
+        const size_t stride = (size_t)K * C;
         int j = lane;
-        for (; j + 3 * FL < nchunk; j += 4 * FL) {
-            s0 += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
-            s1 += partial[(((size_t)g * nchunk + j + FL) * K + k) * C + c];
-            s2 += partial[(((size_t)g * nchunk + j + 2 * FL) * K + k) * C + c];
-            s3 += partial[(((size_t)g * nchunk + j + 3 * FL) * K + k) * C + c];
+        for (; j + 7 * FL < nchunk; j += 8 * FL) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = base[(size_t)(j + q * FL) * stride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += v[q];
         }
-        for (; j < nchunk; j += FL) s0 += partial[(((size_t)g * nchunk + j) * K + k) * C + c];
+        for (int q = 0; j < nchunk; j += FL, ++q) a[q & 7] += base[(size_t)j * stride];
     }
-    const double s = (s0 + s1) + (s2 + s3);
+    const double s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
     red[lane * 32 + cl] = s;
     __syncthreads();

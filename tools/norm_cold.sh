@@ -14,6 +14,6 @@ for r in csv.DictReader(open(glob.glob('gpurun_out/prof_nc/*/*kernel_stats.csv')
     for k, t in traffic.items():
         if k in r['Name'] and ('bwd_' + k) not in r['Name']:
             avg = float(r['AverageNs']) / 1e3
-            print(f"{k:14s} {int(r['Calls']):4d} calls  avg {avg:7.1f} us  min {float(r['MinNs'])/1e3:7.1f}  -> {t * mb / avg / 1e3:5.2f} TB/s ({t} maps of {mb:.1f} MB)")
+            print(f"{k:14s} {int(r['Calls']):4d} calls  avg {avg:7.1f} us  min {float(r['MinNs'])/1e3:7.1f}  -> {t * mb / avg:5.2f} TB/s ({t} maps of {mb:.1f} MB)")
 PY
 rm -rf gpurun_out/prof_nc
