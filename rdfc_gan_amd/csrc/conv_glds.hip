@@ -405,12 +405,16 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
     const bool vec_ok = (p.ld_out & 3) == 0;
     float bv[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {                               // four consecutive channels per lane: one 16-byte load, not four scalar ones
+        const int co = co0 + wr * 64 + 16 * i + q4;
+        if (bias != nullptr && co + 3 < p.Cout) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(bias + co);
+            bv[i][0] = t4[0]; bv[i][1] = t4[1]; bv[i][2] = t4[2]; bv[i][3] = t4[3];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + wr * 64 + 16 * i + q4 + r;
-            bv[i][r] = (bias != nullptr && co < p.Cout) ? bias[co] : 0.f;
+            for (int r = 0; r < 4; ++r) bv[i][r] = (bias != nullptr && co + r < p.Cout) ? bias[co + r] : 0.f;
         }
+    }
     // ---- fused normalisation statistics: per-tile partial {sum, sum of squares} of the STORED values, one row per tile in
     //      stats[g][tile][2][Cout] (the fixed-order f64 finalize of norm.hip reads them; no atomics) --------------------
     if (!SPEC && stats != nullptr) {
