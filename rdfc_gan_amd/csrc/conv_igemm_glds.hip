@@ -291,10 +291,11 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     const int ld_in = transposed ? d->ldy : d->ldx;
     if (Cin % BK != 0 || ld_in % 8 != 0 || Cout < 64 || d->KH * d->KW > MAXTAPS) return 0;
-    // K-steps per output tile.  Short reductions stay on the register-staged kernel, whose 4 waves per SIMD hide the
-    // pipeline fill better (A/B on one device: 1x1 192->384, 6 steps: 83 vs 69 us; 3x3/s2 64->128, 18 steps: 58 vs 53 us;
-    // from ~36 steps up this kernel wins: 4x4 256->512 61 vs 89 us, 3x3/s2 512->512 58 vs 96 us).
-    static const int min_steps = getenv("RDFC_IGEMM_GLDS_MINSTEPS") ? atoi(getenv("RDFC_IGEMM_GLDS_MINSTEPS")) : 32;
+    // K-steps per output tile.  With four ring slots (two workgroups per CU) short reductions were better off on the register-staged
+    // kernel (1x1 192->384, 6 steps: 83 vs 69 us); with three slots and three workgroups per CU this kernel wins from 6 steps up
+    // (1x1 192->384 67 -> 63 us forward, 67 -> 57 input gradient; 1x1 384->768 57 -> 49 / 56 -> 47; 1x1 768->1536 60 -> 46;
+    // 3x3/s2 64->128 54 -> 46); 3-step reductions (1x1 96->192) stay where they were.
+    static const int min_steps = getenv("RDFC_IGEMM_GLDS_MINSTEPS") ? atoi(getenv("RDFC_IGEMM_GLDS_MINSTEPS")) : 6;
     if (d->KH * d->KW * (Cin / BK) < min_steps) return 0;
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
