@@ -117,7 +117,7 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the step into HIP graphs and replay them (single stream; on ROCm 7.2 the '
                     'replay costs about as much per node as an eager launch, so the multi-stream eager step is faster)')
-    ap.add_argument('--event-every', type=int, default=4, help='per-kernel HIP events on every n-th timed step (eager mode)')
+    ap.add_argument('--event-every', type=int, default=10, help='per-kernel HIP events on every n-th timed step (eager mode)')
     ap.add_argument('--by-shape', default=None, help='write a per-conv-shape time / TFLOP/s table (debug aid) to this file')
     a = ap.parse_args()
 
