@@ -77,4 +77,4 @@ class HotPathStep:
             L[f'loss_D_{tag}'], L[f'loss_D_{tag}_real'], L[f'loss_D_{tag}_fake'] = ld_, lr_, lf_
         self.opt_D.step()
         self.fake_B, self.fake_A = fake_B.detach(), fake_A.detach()
-        return {k: float(v) for k, v in L.items()}
+        return {k: float(v.detach()) for k, v in L.items()}

@@ -128,7 +128,7 @@ __device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K]
     // Every thread deposits its K x VEC sums in LDS ([k][thread][v], 16-byte stores), then the K * CVT * VEC outputs are dealt to
     // ALL 256 threads: output o = (k, channel vector, v) sums its RPB rows (fixed order r = 0 .. RPB-1: reproducible) and is stored
     // with its neighbours in one coalesced line.  (Before: a butterfly of 24 runtime-offset shuffles plus a tail in which CVT
-    // threads added and stored everything -- 6.6 of bwd_reduce's 21.7 us on a 256-channel 57x76 map, tools/scratch/redexp.sh.)
+    // threads added and stored everything -- 6.6 of bwd_reduce's 21.7 us on a 256-channel 57x76 map.)
     constexpr int VEC = Elem<T>::VEC;
     __shared__ __attribute__((aligned(16))) float red[K * NT * VEC];
     const int t = threadIdx.x;

@@ -48,7 +48,7 @@ def invalidate_packed_weights():
 
 
 def _packed(weight, dtype, scale):
-    key = (weight.data_ptr(), weight._version, _weights_epoch, dtype, scale)
+    key = (weight.data_ptr(), weight._version, _weights_epoch, dtype, scale, tuple(weight.shape))
     hit = _pack_cache.get(key)
     if hit is None:
         w = weight.detach()
@@ -125,14 +125,15 @@ def net_stream(device):
 def join_side_stream():
     """make the current stream wait for everything launched on the helper streams (weight gradients on the side stream,
     the branch / net streams they may have been forked from); release the tensors kept alive for them"""
-    for dev, (stream, keep) in _side.items():
+    for dev in set(_side) | set(_branch) | set(_net):       # (RDFC_WGRAD_STREAM=0 leaves _side empty: the others still join)
         cur = torch.cuda.current_stream(dev)
         for extra in (_branch.get(dev), _net.get(dev)):
             if extra is not None and extra != cur:
                 cur.wait_stream(extra)
-        if keep:
-            cur.wait_stream(stream)
-            keep.clear()
+        side = _side.get(dev)
+        if side is not None and side[1]:
+            cur.wait_stream(side[0])
+            side[1].clear()
 
 
 def _wgrad(d, a, b, weight, O, I, k, scale):

@@ -41,6 +41,8 @@ def _count_batch(norm, k):
     d = norm.__dict__
     if '_rdfc_pending_batches' not in d:
         norm.register_state_dict_pre_hook(_flush_batch_counter)
+        # a loaded num_batches_tracked replaces the count: batches counted before the load must not be added to it
+        norm.register_load_state_dict_post_hook(lambda module, incompatible: module.__dict__.__setitem__('_rdfc_pending_batches', 0))
         d['_rdfc_pending_batches'] = 0
     d['_rdfc_pending_batches'] += k
 

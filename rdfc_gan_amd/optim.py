@@ -28,10 +28,14 @@ def _pview(buf, off, p):
 
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-3, betas=(0.5, 0.999), eps=1e-8, weight_decay=None):
-        """weight_decay=None: torch.optim.Adam; a number: torch.optim.AdamW (decoupled decay, upstream's optimizer_Normal)"""
+        """weight_decay=None: torch.optim.Adam (rdfc_gan.py:135-140); a number: torch.optim.AdamW with that decoupled decay
+        (upstream's optimizer_Normal, :141-144).  Which of the two update rules runs is fixed here, at construction
+        (`self._adamw`); `param_groups[0]['weight_decay']` always holds a number (0 for Adam), as torch.optim.Adam's own
+        state_dict does, so that checkpoints go both ways and a loaded state_dict cannot switch the kernel."""
         params = [p for p in params]
         assert params, 'optimizer got an empty parameter list'
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._adamw = weight_decay is not None
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=float(weight_decay or 0.0)))
         dev = params[0].device
         self._params = params
         n = sum(p.numel() for p in params)
@@ -120,10 +124,12 @@ class FlatAdam(torch.optim.Optimizer):
         if not self.flat.is_cuda:
             raise RuntimeError('FlatAdam.step runs the HIP kernel rdfc_adam_step: parameters must live on the GPU '
                                '(there is no CPU fallback)')
-        if g.get('weight_decay') is not None:
+        if self._adamw:
+            if self._hyper is not None:
+                raise RuntimeError('the AdamW update is not capturable (host-side lr / step arguments): graph mode covers Adam only')
             self.steps += 1
             hip.adamw_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
-                           g['weight_decay'], self.steps, 1.0 / world)
+                           float(g.get('weight_decay') or 0.0), self.steps, 1.0 / world)
         elif self._hyper is not None:
             self._hyper[1:2] += 1.0           # device-side step count (captured with the update)
             hip.adam_step_dev(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._hyper, g['betas'][0],
@@ -162,6 +168,11 @@ class FlatAdam(torch.optim.Optimizer):
         if self._hyper is not None:
             self._hyper[1] = float(self.steps)
         for k_, v in sd['param_groups'][0].items():
+            if k_ == 'weight_decay':            # a number in every torch checkpoint; None only in round-1 files of this class
+                v = float(v or 0.0)
+                if not self._adamw and v != 0.0:
+                    raise ValueError('checkpoint carries weight_decay != 0 for an optimizer built as plain Adam '
+                                     '(coupled L2 decay is not implemented by rdfc_adam_step)')
             if k_ != 'params':
                 self.param_groups[0][k_] = v
 

@@ -247,6 +247,13 @@ class RDFCGAN:
 
     def forward(self):
         hip.reset_sums(self.device)         # zeroed f64 scratch of the one-stage normalisation reductions: rewound per step
+        # The B->A half (G_B2A(real_B)) shares nothing with the A->B half in this method when only the four hot-path networks
+        # run: it forks HERE, not behind everything the main stream has enqueued by then.  (G_label / G_normal are used by
+        # both halves -- running statistics, packed weights -- so with them the fork stays behind the A->B half.)
+        fork = None
+        if self._net_streams_on() and not self.use_label_net and self.G_normal is None:
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream(self.device))
         self.fake_normal_realA = self._normal('real_A', self.real_A)
         if self.use_label_net:
             # :187 (a fifth stream for this pass -- it depends on nothing but the image -- measured slower: 71-73 vs 67.7 ms per step)
@@ -268,7 +275,7 @@ class RDFCGAN:
         if self.exact_schedule:
             with torch.no_grad():
                 self.G_B2A(self.fake_B)                                          # dead forward (:197)
-        with self._net_stream_ctx():                                             # B->A does not depend on A->B: own stream
+        with self._net_stream_ctx(fork):                                         # B->A does not depend on A->B: own stream
             self.fake_A = self.G_B2A(self.real_B)
             self.fake_normal_fakeA = self._normal('fake_A', self.fake_A)
             if self.use_label_net:
@@ -285,12 +292,15 @@ class RDFCGAN:
         return _NET_STREAMS and Fh.multi_stream() and self.device.type == 'cuda' and not self.exact_schedule
 
     @contextlib.contextmanager
-    def _net_stream_ctx(self, join_before=False):
+    def _net_stream_ctx(self, fork_event=None):
         if not self._net_streams_on():
             yield
             return
         main, side = torch.cuda.current_stream(self.device), Fh.net_stream(self.device)
-        side.wait_stream(main)
+        if fork_event is not None:
+            side.wait_event(fork_event)
+        else:
+            side.wait_stream(main)
         with torch.cuda.stream(side):
             yield
 

@@ -13,7 +13,7 @@ def load(tag):
     f = glob.glob(f'gpurun_out/prof_{tag}/*/*kernel_stats.csv')[0]
     return {r['Name']: (int(r['Calls']), float(r['TotalDurationNs'])) for r in csv.DictReader(open(f))}
 b, l = load('base'), load('label')
-steps = 8 + 1
+steps = 6 + 2        # --steps 6 --warmup 2, --no-kernel-events: no extra isolated step
 rows = []
 for k, (n, t) in l.items():
     n0, t0 = b.get(k, (0, 0.0))
