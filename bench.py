@@ -138,6 +138,7 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the step into HIP graphs and replay them (single stream; on ROCm 7.2 the '
                     'replay costs about as much per node as an eager launch, so the multi-stream eager step is faster)')
+    ap.add_argument('--graph-multi-stream', action='store_true', help='with --graph: capture the helper streams fork/join too (experimental: segfaults in hipStreamEndCapture on ROCm 7.2)')
     ap.add_argument('--event-every', type=int, default=10, help='per-kernel HIP events on every n-th timed step (eager mode)')
     ap.add_argument('--by-shape', default=None, help='write a per-conv-shape time / TFLOP/s table (debug aid) to this file')
     a = ap.parse_args()
@@ -187,10 +188,10 @@ def main():
     graphed = a.graph
     for i in range(a.warmup):
         if graphed and i == 1:
-            model.enable_graph(True)
+            model.enable_graph(True, multi_stream=a.graph_multi_stream)
         one_step(i)
     if graphed and a.warmup < 2:
-        model.enable_graph(True)
+        model.enable_graph(True, multi_stream=a.graph_multi_stream)
         one_step(a.warmup)                 # capture + first replay (untimed)
     torch.cuda.synchronize()
     if world > 1:
@@ -266,7 +267,7 @@ def main():
                                step_gflop_per_pair=round(gflop_pair, 1)),
                    loss_readback='every step (reference API)' if not a.no_sync_losses else 'none in the timed region',
                    host_enqueue_ms_per_step=round(1e3 * (unsynced[1] if unsynced else enqueue) / a.steps, 3),
-                   unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 4 streams' if not graphed else 'hip graphs (3 per step)',
+                   unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 3 streams (main, depth branch / D_B, weight gradients), batched calls' if not graphed else ('hip graphs (3 per step), ' + ('fork/join over the helper streams captured' if a.graph_multi_stream else 'one stream')),
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
         if prof:

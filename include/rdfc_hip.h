@@ -131,6 +131,12 @@ int rdfc_norm_finalize(const float *partial, float *mean, float *rstd, int G, in
 /* rdfc_norm_finalize for partials with an explicit chunk count (rdfc_conv2d_forward_stats). */
 int rdfc_norm_finalize_n(const float *partial, int nchunk, float *mean, float *rstd, int G, int P, int C, float eps,
                          float *run_mean, float *run_var, float momentum, void *stream);
+/* BatchNorm over G stacked batches (G consecutive calls of one nn.BatchNorm2d, run as ONE launch over the concatenated
+ * batch): statistics per group; the running statistics advance once per group, in group order, with
+ * group_momentum[g] (HOST array of G floats, G <= 8) -- what G separate forwards leave behind.  nchunk 0: derived from
+ * (P, C, dtype) like rdfc_norm_finalize; > 0: explicit (rdfc_conv2d_forward_stats partials). */
+int rdfc_norm_finalize_seq(const float *partial, int nchunk, float *mean, float *rstd, int G, int P, int C, int dtype, float eps,
+                           float *run_mean, float *run_var, const float *group_momentum, void *stream);
 /* z = act(gamma*(x-mean)*rstd + beta + res).  gamma/beta f32[C] or NULL (1/0); res may be NULL.
  * prelu: device pointer to the slope when act == RDFC_ACT_PRELU. */
 int rdfc_norm_apply(const void *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
@@ -144,7 +150,7 @@ int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *mean, const
                          void *stream);
 /* sums[G][3][C] from the partials (fixed order => deterministic). */
 int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, int dtype, void *stream);
-/* Same; additionally dbeta_acc[C] += sum du and dgamma_acc[C] += sum du*xhat (either may be NULL; G must be 1):
+/* Same; additionally dbeta_acc[C] += sum du and dgamma_acc[C] += sum du*xhat over every group (either may be NULL):
  * the affine gradients of a BatchNorm land in the parameters' persistent .grad without an autograd add each. */
 int rdfc_norm_bwd_finalize_acc(const float *partial, float *sums, int G, int P, int C, int dtype, float *dbeta_acc,
                                float *dgamma_acc, void *stream);
@@ -159,6 +165,11 @@ int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const 
 int rdfc_norm_forward(const void *x, float *scratch, float *mean, float *rstd, const float *gamma, const float *beta,
                       const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
                       float *run_mean, float *run_var, float momentum, int act, float slope, const float *prelu, void *stream);
+/* rdfc_norm_forward with rdfc_norm_finalize_seq in the middle (BatchNorm over G stacked batches). */
+int rdfc_norm_forward_seq(const void *x, float *scratch, float *mean, float *rstd, const float *gamma, const float *beta,
+                          const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
+                          float *run_mean, float *run_var, const float *group_momentum, int act, float slope,
+                          const float *prelu, void *stream);
 int rdfc_norm_backward(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
                        const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P, int C,
                        int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope, const float *prelu,
@@ -323,6 +334,24 @@ int rdfc_normal_losses_backward(const float *normal, const float *gt_normal, con
  * stream than upstream's numpy draw, hence opt-in. */
 int rdfc_draw_pepper_mask(uint8_t *mask, int N, int HW, uint64_t seed, uint64_t counter, float snr, void *stream);
 int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, int HW, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Small elementwise operators that keep stock-framework arithmetic off the path.
+ * ------------------------------------------------------------------------------ */
+/* hipMemsetAsync(p, 0, bytes) on `stream`. */
+int rdfc_zero(void *p, size_t bytes, void *stream);
+/* backward of addPepperNoise's in-place assignment (helper.py:384-402): out = mask == 0 ? g : 0; g/out [N][C][HW] f32,
+ * mask [N][HW] u8. */
+int rdfc_mask_keep(const float *g, const uint8_t *mask, float *out, int N, int C, int HW, void *stream);
+/* out[i] = x[i] * (*scalar) * k; scalar: device f32 (NULL = 1): a stored loss gradient times the loss's cotangent
+ * (gan_loss.py:6-42 backward). */
+int rdfc_scale_dev(const float *x, const float *scalar, float k, float *out, size_t n, void *stream);
+/* helper.py:404-408 norm_normalize on channels 0..2 of an NCHW f32 map with Csrc >= 3 channels -> [N][3][HW]. */
+int rdfc_unit_normals(const float *src, float *dst, int N, int Csrc, int HW, void *stream);
+/* dst[P][C] (pixel stride ld_dst) = sum over n <= 4 pixel-major maps srcs[k] (HOST array of device pointers, pixel strides
+ * lds[k], HOST array): the gradient of an activation with several consumers in one pass (stands in for autograd's
+ * pairwise adds: encoder features feeding the next stage and a skip connection, rdf_generator.py:286-398). */
+int rdfc_sum_maps(int n, const void *const *srcs, const int *lds, void *dst, int P, int C, int ld_dst, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

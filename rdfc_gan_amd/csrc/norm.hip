@@ -244,6 +244,41 @@ __global__ __launch_bounds__(FNT) void stats_finalize_kernel(Map m, int nchunk, 
     }
 }
 
+// BatchNorm over G stacked batches (several calls of the same layer run as one launch, rdfc_gan.py's batched schedule):
+// every group gets its own statistics; the running statistics advance once per group, in group order, each with its own
+// momentum -- exactly what G separate forwards would leave behind.
+constexpr int MAXSEQ = 8;
+struct Moms { float m[MAXSEQ]; };
+__global__ __launch_bounds__(FNT) void stats_finalize_seq_kernel(Map m, int nchunk, const float *__restrict__ partial,
+                                                                float *__restrict__ mean, float *__restrict__ rstd, float eps,
+                                                                float *run_mean, float *run_var, Moms moms) {
+    __shared__ double red[FL * 32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const bool writer = threadIdx.x < 32 && c < m.C;
+    double rm = 0, rv = 0;
+    if (writer && run_mean != nullptr) {
+        rm = run_mean[c];
+        rv = run_var[c];
+    }
+    for (int g = 0; g < m.G; ++g) {
+        const double s1 = chunk_sum(partial, g, 2, 0, m.C, c, nchunk, red);
+        const double s2 = chunk_sum(partial, g, 2, 1, m.C, c, nchunk, red);
+        if (!writer) continue;
+        const double mu = s1 / m.P;
+        double var = s2 / m.P - mu * mu;
+        if (var < 0) var = 0;
+        mean[g * m.C + c] = (float)mu;
+        rstd[g * m.C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        const double unb = m.P > 1 ? var * m.P / (m.P - 1) : var, mom = moms.m[g];
+        rm = (double)(float)((1.0 - mom) * rm + mom * mu);          // rounded to f32 per update, like G separate launches
+        rv = (double)(float)((1.0 - mom) * rv + mom * unb);
+    }
+    if (writer && run_mean != nullptr) {
+        run_mean[c] = (float)rm;
+        run_var[c] = (float)rv;
+    }
+}
+
 struct ApplyArgs {
     const float *mean, *rstd, *gamma, *beta, *prelu;
     int act;            // none | relu | lrelu | prelu only: all piecewise linear -> act(u) = u > 0 ? u : u * neg_slope
@@ -661,6 +696,19 @@ extern "C" int rdfc_norm_finalize_n(const float *partial, int nchunk, float *mea
     return 0;
 }
 
+extern "C" int rdfc_norm_finalize_seq(const float *partial, int nchunk, float *mean, float *rstd, int G, int P, int C, int dtype,
+                                      float eps, float *run_mean, float *run_var, const float *group_momentum, void *stream) {
+    RDFC_REQUIRE(G > 0 && G <= MAXSEQ && P > 0 && C > 0, "rdfc_norm_finalize_seq: 1 <= G <= %d groups", MAXSEQ);
+    RDFC_REQUIRE(run_mean == nullptr || group_momentum != nullptr, "rdfc_norm_finalize_seq: running statistics need the per-group momenta");
+    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Moms moms{};
+    for (int g = 0; g < G; ++g) moms.m[g] = group_momentum ? group_momentum[g] : 0.f;
+    hipLaunchKernelGGL(stats_finalize_seq_kernel, dim3(cdiv(C, 32)), dim3(FNT), 0, (hipStream_t)stream, m,
+                       nchunk > 0 ? nchunk : cdiv(P, m.chunk), partial, mean, rstd, eps, run_mean, run_var, moms);
+    RDFC_LAUNCH_CHECK("rdfc_norm_finalize_seq");
+    return 0;
+}
+
 extern "C" int rdfc_norm_apply(const void *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
                                const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype,
                                int act, float slope, const float *prelu, void *stream) {
@@ -689,8 +737,7 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
 
 extern "C" int rdfc_norm_bwd_finalize_acc(const float *partial, float *sums, int G, int P, int C, int dtype, float *dbeta_acc,
                                           float *dgamma_acc, void *stream) {
-    RDFC_REQUIRE(G == 1 || (dbeta_acc == nullptr && dgamma_acc == nullptr),
-                 "rdfc_norm_bwd_finalize_acc: in-place affine gradients need one statistics group (batch norm)");
+    // (G > 1 with accumulators: BatchNorm over G stacked batches -- every group's sums are added, atomically)
     hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), G * 3), dim3(FNT), 0, (hipStream_t)stream, G, C, 3,
                        cdiv(P, chunk_pixels(P, C, dtype == RDFC_BF16 ? 8 : 4)), partial, sums, dbeta_acc, dgamma_acc);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_finalize");
@@ -724,6 +771,15 @@ extern "C" int rdfc_norm_forward(const void *x, float *scratch, float *mean, flo
                                  void *stream) {
     if (int e = rdfc_norm_stats(x, scratch, G, P, C, ldx, dtype, stream)) return e;
     if (int e = rdfc_norm_finalize(scratch, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, momentum, stream)) return e;
+    return rdfc_norm_apply(x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, act, slope, prelu, stream);
+}
+
+extern "C" int rdfc_norm_forward_seq(const void *x, float *scratch, float *mean, float *rstd, const float *gamma, const float *beta,
+                                     const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
+                                     float *run_mean, float *run_var, const float *group_momentum, int act, float slope,
+                                     const float *prelu, void *stream) {
+    if (int e = rdfc_norm_stats(x, scratch, G, P, C, ldx, dtype, stream)) return e;
+    if (int e = rdfc_norm_finalize_seq(scratch, 0, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, group_momentum, stream)) return e;
     return rdfc_norm_apply(x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, act, slope, prelu, stream);
 }
 

@@ -368,6 +368,70 @@ __global__ void pepper_draw_kernel(uint8_t *__restrict__ mask, size_t npix, unsi
     }
 }
 
+// ---- small elementwise kernels that keep stock-PyTorch arithmetic off the path ------------------------------------------
+// salt/pepper backward: the in-place assignment upstream cuts the gradient at the replaced pixels (helper.py:384-402)
+__global__ void mask_keep_kernel(const float *__restrict__ g, const uint8_t *__restrict__ mask, float *__restrict__ out, int C, int HW, size_t total) {
+    GRID_STRIDE(i, total) {
+        const size_t n = i / ((size_t)C * HW);
+        out[i] = mask[n * HW + i % HW] == 0 ? g[i] : 0.f;
+    }
+}
+
+// out = x * (*scalar) * k  (the cotangent of a loss is a 0-dim device tensor; k: a host factor)
+__global__ void scale_dev_kernel(const float *__restrict__ x, const float *__restrict__ scalar, float k, float *__restrict__ out, size_t n) {
+    const float sc = (scalar ? *scalar : 1.f) * k;
+    GRID_STRIDE(i, n) out[i] = x[i] * sc;
+}
+
+// helper.py:404-408 norm_normalize: v / (sqrt(sum_c v_c^2) + 1e-10) over the first three channels of an NCHW map
+__global__ void unit_normals_kernel(const float *__restrict__ src, float *__restrict__ dst, int Csrc, int HW, size_t npix) {
+    GRID_STRIDE(i, npix) {
+        const size_t n = i / HW, p = i % HW;
+        const float *s = src + n * Csrc * HW + p;
+        const float a = s[0], b = s[(size_t)HW], c = s[2 * (size_t)HW];
+        const float inv = 1.f / (sqrtf(a * a + b * b + c * c) + 1e-10f);
+        float *d = dst + n * 3 * HW + p;
+        d[0] = a * inv; d[(size_t)HW] = b * inv; d[2 * (size_t)HW] = c * inv;
+    }
+}
+
+// dst = sum of up to four pixel-major maps (each with its own pixel stride): the gradient of an activation that feeds
+// several consumers, in ONE pass (autograd would add them pairwise with stock elementwise kernels, after making
+// channel-slice cotangents contiguous)
+struct SumSrc { const void *p[4]; int ld[4]; int n; };
+template <typename T>
+__global__ void sum_maps_kernel(SumSrc s, T *__restrict__ dst, int C, int ld_dst, size_t total /* P * C / VEC */) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    GRID_STRIDE(i, total) {
+        const size_t px = i / cv;
+        const int c = (int)(i % cv) * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int k = 0; k < s.n; ++k) {
+            Vec16<T> x;
+            x.load(reinterpret_cast<const T *>(s.p[k]) + px * s.ld[k] + c);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += x.get(v);
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.set(v, acc[v]);
+        o.store(dst + px * ld_dst + c);
+    }
+}
+template <typename T>
+__global__ void sum_maps_scalar_kernel(SumSrc s, T *__restrict__ dst, int C, int ld_dst, size_t total /* P * C */) {
+    GRID_STRIDE(i, total) {
+        const size_t px = i / C;
+        const int c = (int)(i % C);
+        float acc = 0.f;
+        for (int k = 0; k < s.n; ++k) acc += Elem<T>::ld(reinterpret_cast<const T *>(s.p[k]) + px * s.ld[k] + c);
+        Elem<T>::st(dst + px * ld_dst + c, acc);
+    }
+}
+
 }  // namespace
 
 #define DISPATCH(dtype, ...)                                      \
@@ -537,5 +601,61 @@ extern "C" int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, 
     const size_t total = (size_t)N * C * HW;
     hipLaunchKernelGGL(pepper_kernel, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, img, mask, C, HW, total);
     RDFC_LAUNCH_CHECK("rdfc_apply_pepper");
+    return 0;
+}
+
+extern "C" int rdfc_zero(void *p, size_t bytes, void *stream) {
+    if (bytes == 0) return 0;
+    RDFC_REQUIRE(p != nullptr, "rdfc_zero: null pointer");
+    if (hipMemsetAsync(p, 0, bytes, (hipStream_t)stream) != hipSuccess) {
+        rdfc_set_error("rdfc_zero: hipMemsetAsync failed");
+        return 2;
+    }
+    return 0;
+}
+
+extern "C" int rdfc_mask_keep(const float *g, const uint8_t *mask, float *out, int N, int C, int HW, void *stream) {
+    const size_t total = (size_t)N * C * HW;
+    hipLaunchKernelGGL(mask_keep_kernel, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, g, mask, out, C, HW, total);
+    RDFC_LAUNCH_CHECK("rdfc_mask_keep");
+    return 0;
+}
+
+extern "C" int rdfc_scale_dev(const float *x, const float *scalar, float k, float *out, size_t n, void *stream) {
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, x, scalar, k, out, n);
+    RDFC_LAUNCH_CHECK("rdfc_scale_dev");
+    return 0;
+}
+
+extern "C" int rdfc_unit_normals(const float *src, float *dst, int N, int Csrc, int HW, void *stream) {
+    RDFC_REQUIRE(Csrc >= 3, "rdfc_unit_normals: needs at least three channels");
+    const size_t npix = (size_t)N * HW;
+    hipLaunchKernelGGL(unit_normals_kernel, dim3(nblocks(npix)), dim3(NT), 0, (hipStream_t)stream, src, dst, Csrc, HW, npix);
+    RDFC_LAUNCH_CHECK("rdfc_unit_normals");
+    return 0;
+}
+
+extern "C" int rdfc_sum_maps(int n, const void *const *srcs, const int *lds, void *dst, int P, int C, int ld_dst, int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_sum_maps", dtype);
+    RDFC_REQUIRE(n >= 1 && n <= 4 && P > 0 && C > 0 && ld_dst >= C, "rdfc_sum_maps: 1..4 sources, ld_dst >= C");
+    SumSrc s{};
+    s.n = n;
+    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    bool v = C % vec == 0 && ld_dst % vec == 0;
+    for (int k = 0; k < n; ++k) {
+        RDFC_REQUIRE(srcs[k] != nullptr && lds[k] >= C, "rdfc_sum_maps: bad source %d", k);
+        s.p[k] = srcs[k];
+        s.ld[k] = lds[k];
+        v = v && lds[k] % vec == 0 && ((uintptr_t)srcs[k] & 15) == 0;
+    }
+    v = v && ((uintptr_t)dst & 15) == 0;
+    if (v) {
+        const size_t total = (size_t)P * (C / vec);
+        DISPATCH(dtype, hipLaunchKernelGGL(sum_maps_kernel<T>, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, s, (T *)dst, C, ld_dst, total));
+    } else {
+        const size_t total = (size_t)P * C;
+        DISPATCH(dtype, hipLaunchKernelGGL(sum_maps_scalar_kernel<T>, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, s, (T *)dst, C, ld_dst, total));
+    }
+    RDFC_LAUNCH_CHECK("rdfc_sum_maps");
     return 0;
 }

@@ -167,11 +167,14 @@ def _wgrad(d, a, b, weight, O, I, k, scale):
 class ConvSpec:
     """static description of one conv block (shared by forward and backward)"""
     __slots__ = ('k', 'stride', 'pad', 'transposed', 'out_pad', 'norm', 'act', 'slope', 'eps', 'momentum',
-                 'out_f32', 'wscale', 'dil')
+                 'out_f32', 'wscale', 'dil', 'group_momenta')
 
     def __init__(self, k, stride=1, pad=0, transposed=False, out_pad=0, norm='none', act='none', slope=0.0,
-                 eps=1e-5, momentum=0.1, out_f32=False, wscale=1.0, dil=1):
+                 eps=1e-5, momentum=0.1, out_f32=False, wscale=1.0, dil=1, group_momenta=None):
+        """group_momenta (BatchNorm only): the batch is G = len(group_momenta) stacked batches of as many separate calls of
+        this layer -- statistics per group, running statistics advanced once per group with its momentum"""
         assert dil == 1 or not transposed
+        self.group_momenta = tuple(group_momenta) if group_momenta is not None and len(group_momenta) > 1 else None
         self.k, self.stride, self.pad, self.transposed, self.out_pad, self.dil = k, stride, pad, transposed, out_pad, dil
         self.norm, self.act, self.slope, self.eps, self.momentum = norm, act, slope, eps, momentum
         self.out_f32, self.wscale = out_f32, wscale
@@ -205,11 +208,14 @@ class _ConvBlock(torch.autograd.Function):
         y = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32 if out_f32 else dtype, device=x.device)
         fused = None                # (mean, rstd) when the conv's epilogue produced the normalisation statistics
         live_stats = has_norm and not (spec.norm == 'bn' and not training)
+        gm = spec.group_momenta if spec.norm == 'bn' and training else None
+        if gm is not None:
+            assert N % len(gm) == 0, f'batch {N} does not split into {len(gm)} stacked batches'
         if not spec.transposed:
             d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
                               act=epi_act, slope=spec.slope, out_f32=out_f32)
             G_ = N if spec.norm == 'in' else 1
-            if live_stats and _DETERMINISTIC and hip.conv_stats_nchunk(d, G_) > 0:
+            if live_stats and gm is None and _DETERMINISTIC and hip.conv_stats_nchunk(d, G_) > 0:
                 upd = spec.norm == 'bn' and run_mean is not None
                 fused = hip.conv_forward_stats(d, x, wf, bias, y, G_, spec.eps, run_mean if upd else None,
                                                run_var if upd else None, spec.momentum)
@@ -224,7 +230,7 @@ class _ConvBlock(torch.autograd.Function):
         if not has_norm:
             ctx.save_for_backward(x, weight, y if spec.act != 'none' else None)
             return y
-        G = N if spec.norm == 'in' else 1
+        G = N if spec.norm == 'in' else (len(gm) if gm is not None else 1)
         if spec.norm == 'bn' and not training:
             mean = run_mean.view(1, -1).float()
             rstd = torch.rsqrt(run_var.view(1, -1).float() + spec.eps)
@@ -236,9 +242,9 @@ class _ConvBlock(torch.autograd.Function):
             if fused is not None:
                 mean, rstd = fused
                 hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
-            elif _DETERMINISTIC:
+            elif _DETERMINISTIC or gm is not None:
                 mean, rstd = hip.norm_forward(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
-                                              run_mean if upd else None, run_var if upd else None, spec.momentum)
+                                              run_mean if upd else None, run_var if upd else None, spec.momentum, group_momenta=gm)
             else:
                 mean, rstd = hip.norm_forward_onestage(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
                                                        run_mean if upd else None, run_var if upd else None, spec.momentum)
@@ -256,14 +262,14 @@ class _ConvBlock(torch.autograd.Function):
             dz = dz if dz.dtype == x.dtype else dz.to(x.dtype)
             frozen = spec.norm == 'bn' and not ctx.training
             # affine gradients straight into persistent .grad buffers (FlatAdam's) when there is one statistics group
-            direct = (gamma is not None and beta is not None and mean.shape[0] == 1 and ctx.needs_input_grad[3]
+            direct = (gamma is not None and beta is not None and ctx.needs_input_grad[3]
                       and ctx.needs_input_grad[4] and _accumulable(gamma.grad) and _accumulable(beta.grad))
-            nb = hip.norm_backward if _DETERMINISTIC else hip.norm_backward_onestage
+            nb = hip.norm_backward if (_DETERMINISTIC or mean.shape[0] > 1) else hip.norm_backward_onestage
             dy, g_res, sums = nb(dz, y, mean, rstd, gamma, beta, res, spec.act, spec.slope, prelu,
                               frozen=frozen, want_dres=res is not None and ctx.needs_input_grad[5],
                               acc_beta=beta.grad if direct else None, acc_gamma=gamma.grad if direct else None)
             if gamma is not None and not direct:
-                g_gamma, g_beta = sums[0, 1], sums[0, 0]
+                g_gamma, g_beta = (sums[0, 1], sums[0, 0]) if sums.shape[0] == 1 else (sums[:, 1].sum(0), sums[:, 0].sum(0))
             if prelu is not None:
                 g_prelu = sums[:, 2].sum().view(1)
         else:
@@ -400,6 +406,45 @@ def cat(a, b):
     return _Cat.apply(a, b)
 
 
+class _FanOut(torch.autograd.Function):
+    """An activation with n consumers: n aliases forward, ONE rdfc_sum_maps pass backward (autograd would add the
+    cotangents pairwise with stock elementwise kernels, after copying channel-slice cotangents contiguous)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.meta = (tuple(x.shape), x.dtype, x.device)
+        return tuple(x.view(x.shape) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        shape, dtype, dev = ctx.meta
+        live = []
+        for g in gs:
+            if g is None:
+                continue
+            if g.dtype != dtype:
+                g = g.to(dtype)
+            if g.stride(3) != 1 and g.shape[3] != 1:
+                g = g.contiguous()
+            live.append(g)
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        out = None
+        while len(live) > 4:
+            out = hip.sum_maps(live[:4])
+            live = [out] + live[4:]
+        return hip.sum_maps(live), None
+
+
+def fanout(x, n):
+    """x -> n aliases whose gradients are summed by one HIP pass"""
+    if n <= 1 or not x.requires_grad:
+        return (x,) * n
+    return _FanOut.apply(x, n)
+
+
 class _ReflectPad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pad):
@@ -481,7 +526,7 @@ class _WeightedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         grad, = ctx.saved_tensors
-        return grad * g, None, None, None
+        return hip.scale_dev(grad, g), None, None, None
 
 
 def weighted_loss(pred, target, weight, kind):

@@ -151,31 +151,46 @@ class RDFGenerator(nn.Module):
         if two:
             side.wait_stream(main)
         with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
+            # Every activation with several consumers goes through Fh.fanout: its cotangents are summed by one HIP pass.
+            nh = 3 if self.use_nlspn_refine else 2          # heads on the last decoder feature / the stem feature
             d1 = Fh.cat(self.depth_branch_en1_rgb(nrm), self.depth_branch_en1_depth(dep))
-            d = [None, d1]
+            d1, *d1_heads = Fh.fanout(d1, 1 + nh)
+            d, skip = [None, d1], {}
             for idx in range(2, 7):
-                d.append(D.forward_encoder_layer(d[-1], idx))
-            dfs, ready = [d[6]], []               # depth-decoder features, one per fusion level (+ an event each)
+                nxt = D.forward_encoder_layer(d[-1], idx)
+                if idx < 6:                                  # en2..en5 feed the next stage and a decoder skip connection
+                    nxt, skip[idx] = Fh.fanout(nxt, 2)
+                d.append(nxt)
+            df, ff = Fh.fanout(d[6], 2)                      # depth-decoder feature: next level | the RGB branch's fusion layer
+            dfs, ready = [ff], []                            # the fusion inputs, one per level (+ an event each)
             if two:
                 ready.append(torch.cuda.Event())
                 ready[-1].record(side)
             for lvl in (5, 4, 3, 2):
-                dfs.append(cat(D.forward_decoder_layer(dfs[-1], layer_idx=lvl), d[lvl]))
+                nxt = cat(D.forward_decoder_layer(df, layer_idx=lvl), skip[lvl])
+                if lvl == 2:
+                    heads = Fh.fanout(nxt, nh)               # the last decoder feature only feeds the heads
+                    break
+                df, ff = Fh.fanout(nxt, 2)
+                dfs.append(ff)
                 if two:
                     ready.append(torch.cuda.Event())
                     ready[-1].record(side)
-            df = dfs[-1]
-            pred_init = self._head(self.id_dec0, cat(self.id_dec1(df), d1), 'tanh')
-            confidence = self.cf_dec0(cat(self.cf_dec1(df), d1))
+            pred_init = self._head(self.id_dec0, cat(self.id_dec1(heads[0]), d1_heads[0]), 'tanh')
+            confidence = self.cf_dec0(cat(self.cf_dec1(heads[1]), d1_heads[1]))
             if self.use_nlspn_refine:
-                guide = self.gd_dec0(cat(self.gd_dec1(df), d1))
-                depth_map_2 = self.nlspn_refine_module(pred_init, guide, confidence, depth)
+                guide = self.gd_dec0(cat(self.gd_dec1(heads[2]), d1_heads[2]))
+                confidence, conf_prop = Fh.fanout(confidence, 2)
+                depth_map_2 = self.nlspn_refine_module(pred_init, guide, conf_prop, depth)
             else:
                 depth_map_2 = pred_init
-        r1 = self.rgb_branch_en1(nrm)
-        r = [None, r1]
+        r1, r1a, r1b = Fh.fanout(self.rgb_branch_en1(nrm), 3)
+        r, rskip = [None, r1], {}
         for idx in range(2, 7):
-            r.append(R.forward_encoder_layer(r[-1], idx))
+            nxt = R.forward_encoder_layer(r[-1], idx)
+            if idx < 6:
+                nxt, rskip[idx] = Fh.fanout(nxt, 2)
+            r.append(nxt)
         if two:
             for t in dfs + [depth_map_2, confidence]:
                 t.record_stream(main)             # allocated on the side stream, read on the main one
@@ -183,9 +198,10 @@ class RDFGenerator(nn.Module):
         for k, (lvl, fuse) in enumerate(zip((5, 4, 3, 2), (self.fuse_layer1, self.fuse_layer2, self.fuse_layer3, self.fuse_layer4))):
             if two:
                 main.wait_event(ready[k])         # the RGB decoder trails the depth decoder by one level
-            rf = cat(R.forward_decoder_layer(fuse(rf, dfs[k]), layer_idx=lvl), r[lvl])
-        depth_map_1 = self._head(self.rgb_pred_dec0, cat(self.rgb_pred_dec1(rf), r1), 'tanh')
-        confidence_map_1 = self.rgb_conf_dec0(cat(self.rgb_conf_dec1(rf), r1))
+            rf = cat(R.forward_decoder_layer(fuse(rf, dfs[k]), layer_idx=lvl), rskip[lvl])
+        rfa, rfb = Fh.fanout(rf, 2)
+        depth_map_1 = self._head(self.rgb_pred_dec0, cat(self.rgb_pred_dec1(rfa), r1a), 'tanh')
+        confidence_map_1 = self.rgb_conf_dec0(cat(self.rgb_conf_dec1(rfb), r1b))
         if two:
             main.wait_stream(side)                # depth heads (and NLSPN) done
         depth_map_2, pred = Fh.fusion_head(depth_map_1, confidence_map_1, depth_map_2, confidence)
@@ -212,8 +228,9 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x):
         cb = self.conv_block
+        x, xr = Fh.fanout(x, 2)
         y = run_conv(Fh.reflect_pad(x, 1), cb[1], cb[2], cb[3])
-        return run_conv(Fh.reflect_pad(y, 1), cb[5], cb[6], None, res=x)      # out = x + conv_block(x)
+        return run_conv(Fh.reflect_pad(y, 1), cb[5], cb[6], None, res=xr)     # out = x + conv_block(x)
 
 
 class ResnetGenerator(nn.Module):

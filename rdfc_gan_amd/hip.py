@@ -269,6 +269,13 @@ def conv_wgrad(d, x, dy, into=None, stream=None):
     return dw
 
 
+def zero_(t):
+    """hipMemsetAsync on the current stream (a contiguous tensor or a contiguous slice of one)"""
+    assert t.is_contiguous()
+    _chk(lib().rdfc_zero(_p(t), C.c_size_t(t.numel() * t.element_size()), _st()), 'rdfc_zero')
+    return t
+
+
 # --------------------------------------------------------------------------- layout
 def nchw_to_pm(src, dtype, out=None):
     N, Cc, H, W = src.shape
@@ -327,14 +334,36 @@ def norm_nchunk(P, Cc, dtype_code):
     return n
 
 
-def norm_forward(x, G, eps, gamma, beta, res, z, act='none', slope=0.0, prelu=None, run_mean=None, run_var=None, momentum=0.1):
-    """statistics + finalize + normalise(+residual)(+activation) in one call -> (mean[G,C], rstd[G,C]); z is written"""
+_mom_arrays = {}
+
+
+def _momenta(group_momenta):
+    """host float[G] for rdfc_norm_*_seq (cached per value tuple)"""
+    key = tuple(float(m) for m in group_momenta)
+    a = _mom_arrays.get(key)
+    if a is None:
+        a = _mom_arrays[key] = (C.c_float * len(key))(*key)
+    return a
+
+
+def norm_forward(x, G, eps, gamma, beta, res, z, act='none', slope=0.0, prelu=None, run_mean=None, run_var=None, momentum=0.1,
+                 group_momenta=None):
+    """statistics + finalize + normalise(+residual)(+activation) in one call -> (mean[G,C], rstd[G,C]); z is written.
+    group_momenta (G floats): BatchNorm over G stacked batches -- the running statistics advance once per group, in order"""
     N, H, W, Cc = x.shape
     P = N * H * W // G
     d = dt(x)
     npart = G * norm_nchunk(P, Cc, d) * 2 * Cc
     buf = torch.empty(npart + 2 * G * Cc, dtype=torch.float32, device=x.device)      # [partials | mean | rstd]
     base = buf.data_ptr()
+    if group_momenta is not None:
+        assert len(group_momenta) == G
+        _chk(lib().rdfc_norm_forward_seq(_p(x), base, base + 4 * npart, base + 4 * (npart + G * Cc), _p(gamma), _p(beta), _p(res), _p(z),
+                                         G, P, Cc, ld(x), ld(res) if res is not None else 0, ld(z), d, _f(eps), _p(run_mean),
+                                         _p(run_var), _momenta(group_momenta), ACT[act], _f(slope), _p(prelu), _st()),
+             'rdfc_norm_forward_seq')
+        stats = buf[npart:].view(2, G, Cc)
+        return stats[0], stats[1]
     _chk(lib().rdfc_norm_forward(_p(x), base, base + 4 * npart, base + 4 * (npart + G * Cc), _p(gamma), _p(beta), _p(res), _p(z), G, P,
                                  Cc, ld(x), ld(res) if res is not None else 0, ld(z), d, _f(eps), _p(run_mean), _p(run_var),
                                  _f(momentum), ACT[act], _f(slope), _p(prelu), _st()), 'rdfc_norm_forward')
@@ -557,6 +586,48 @@ def draw_pepper_mask(N, H, W, seed, counter, snr, device):
     mask = torch.empty(N, 1, H, W, dtype=torch.uint8, device=device)
     _chk(lib().rdfc_draw_pepper_mask(_p(mask), N, H * W, int(seed) & (2 ** 64 - 1), int(counter), _f(snr), _st()), 'rdfc_draw_pepper_mask')
     return mask
+
+
+def mask_keep(g, mask_u8):
+    """g [N,C,H,W] f32 * (mask == 0): the backward of apply_pepper"""
+    N, Cc, H, W = g.shape
+    g = g.contiguous()
+    out = torch.empty_like(g)
+    _chk(lib().rdfc_mask_keep(_p(g), _p(mask_u8), _p(out), N, Cc, H * W, _st()), 'rdfc_mask_keep')
+    return out
+
+
+def scale_dev(x, scalar, k=1.0):
+    """x (f32, contiguous) * scalar (0-dim device f32 tensor or None) * k"""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    if scalar is not None:
+        scalar = scalar.reshape(()).to(torch.float32)
+    out = torch.empty_like(x)
+    _chk(lib().rdfc_scale_dev(_p(x), _p(scalar), _f(k), _p(out), C.c_size_t(x.numel()), _st()), 'rdfc_scale_dev')
+    return out
+
+
+def unit_normals(v):
+    """helper.py:404-408 on channels 0..2 of an NCHW f32 map (no gradient)"""
+    v = v.detach().contiguous().float()
+    N, Cs, H, W = v.shape
+    out = torch.empty(N, 3, H, W, dtype=torch.float32, device=v.device)
+    _chk(lib().rdfc_unit_normals(_p(v), _p(out), N, Cs, H * W, _st()), 'rdfc_unit_normals')
+    return out
+
+
+def sum_maps(maps, out=None):
+    """sum of 1..4 pixel-major maps [N,H,W,C] (each may be a channel slice of a wider map) in one pass"""
+    m0 = maps[0]
+    N, H, W, Cc = m0.shape
+    if out is None:
+        out = torch.empty(N, H, W, Cc, dtype=m0.dtype, device=m0.device)
+    n = len(maps)
+    assert 1 <= n <= 4 and all(m.shape == m0.shape and m.dtype == m0.dtype for m in maps)
+    ptrs = (C.c_void_p * n)(*[m.data_ptr() for m in maps])
+    lds = (C.c_int * n)(*[ld(m) for m in maps])
+    _chk(lib().rdfc_sum_maps(n, ptrs, lds, _p(out), N * H * W, Cc, ld(out), dt(m0), _st()), 'rdfc_sum_maps')
+    return out
 
 
 def apply_pepper(img, mask_u8):

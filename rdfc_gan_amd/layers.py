@@ -4,6 +4,8 @@ forward runs the fused HIP blocks (rdfc_gan_amd.functional).
 The torch.nn layers inside these containers (nn.Conv2d, nn.BatchNorm2d, ...) only own
 parameters / buffers -- their own forward is never called.
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -13,6 +15,21 @@ from .functional import ConvSpec
 # >1 while one forward stands in for several identical ones (rdfc_gan.py elides upstream's dead
 # forwards): BatchNorm running statistics advance as if the forward had run BN_STAT_REPEAT times.
 BN_STAT_REPEAT = 1
+# Several calls of one network run as ONE pass over the concatenated batch (rdfc_gan.py's batched schedule): BN_GROUP_REPEATS
+# = (r_0, ..., r_{G-1}) says that the batch is G stacked batches and that group g stands for r_g identical upstream forwards.
+# BatchNorm then takes its statistics per group and advances the running statistics once per group, in order.
+BN_GROUP_REPEATS = None
+
+@contextlib.contextmanager
+def bn_groups(repeats):
+    """layers run inside see a batch made of len(repeats) stacked batches (see BN_GROUP_REPEATS)"""
+    global BN_GROUP_REPEATS
+    old, BN_GROUP_REPEATS = BN_GROUP_REPEATS, tuple(int(r) for r in repeats)
+    try:
+        yield
+    finally:
+        BN_GROUP_REPEATS = old
+
 
 _ACTS = {nn.ReLU: ('relu', 0.0), nn.LeakyReLU: ('lrelu', None), nn.PReLU: ('prelu', 0.0), nn.Tanh: ('tanh', 0.0),
          nn.Sigmoid: ('sigmoid', 0.0)}
@@ -54,7 +71,7 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
     """conv (nn.Conv2d | nn.ConvTranspose2d) [+ norm (BatchNorm2d | InstanceNorm2d)] [+ res] [+ act module]"""
     # the static description of the block is the same on every call of the same modules: cache it (a train step runs
     # ~180 blocks, each used to rebuild its ConvSpec from a dozen attribute lookups)
-    key = (id(conv), id(norm), id(act), out_f32, BN_STAT_REPEAT, getattr(act, 'negative_slope', None))
+    key = (id(conv), id(norm), id(act), out_f32, BN_STAT_REPEAT, getattr(act, 'negative_slope', None), BN_GROUP_REPEATS)
     hit = _spec_cache.get(key)
     if hit is not None and hit[0] is conv and hit[1] is norm and hit[2] is act:
         _c, _n, _a, spec, nname, prelu = hit
@@ -64,7 +81,7 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
             gamma, beta, rm, rv = norm.weight, norm.bias, norm.running_mean, norm.running_var
             training = norm.training
             if training and norm.num_batches_tracked is not None:
-                _count_batch(norm, BN_STAT_REPEAT)
+                _count_batch(norm, sum(BN_GROUP_REPEATS) if BN_GROUP_REPEATS else BN_STAT_REPEAT)
         return Fh.conv_block(x, conv.weight, conv.bias, gamma, beta, res, prelu, spec=spec, training=training,
                              run_mean=rm, run_var=rv)
     transposed = isinstance(conv, nn.ConvTranspose2d)
@@ -81,17 +98,23 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
     assert conv.kernel_size[0] == conv.kernel_size[1] and conv.dilation[0] == conv.dilation[1] and conv.groups == 1
     assert conv.padding[0] == conv.padding[1] and conv.stride[0] == conv.stride[1]
     momentum = getattr(norm, 'momentum', 0.1) or 0.1
-    if BN_STAT_REPEAT != 1:
+    gmom = None
+    if BN_GROUP_REPEATS and nname == 'bn':
+        assert BN_STAT_REPEAT == 1
+        gmom = tuple(1.0 - (1.0 - momentum) ** r for r in BN_GROUP_REPEATS)
+        if len(gmom) == 1:
+            momentum, gmom = gmom[0], None
+    elif BN_STAT_REPEAT != 1:
         momentum = 1.0 - (1.0 - momentum) ** BN_STAT_REPEAT
     spec = ConvSpec(k, s, p, transposed, conv.output_padding[0] if transposed else 0, nname, aname, slope,
-                    eps=getattr(norm, 'eps', 1e-5), momentum=momentum, out_f32=out_f32, dil=conv.dilation[0])
+                    eps=getattr(norm, 'eps', 1e-5), momentum=momentum, out_f32=out_f32, dil=conv.dilation[0], group_momenta=gmom)
     gamma = beta = rm = rv = None
     training = True
     if nname == 'bn':
         gamma, beta, rm, rv = norm.weight, norm.bias, norm.running_mean, norm.running_var
         training = norm.training
         if training and norm.num_batches_tracked is not None:
-            _count_batch(norm, BN_STAT_REPEAT)
+            _count_batch(norm, sum(BN_GROUP_REPEATS) if BN_GROUP_REPEATS else BN_STAT_REPEAT)
     _spec_cache[key] = (conv, norm, act, spec, nname, prelu)
     return Fh.conv_block(x, conv.weight, conv.bias, gamma, beta, res, prelu, spec=spec, training=training,
                          run_mean=rm, run_var=rv)
@@ -149,8 +172,9 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
+        x, xr = Fh.fanout(x, 2)                     # conv1 and the identity / downsample path
         y = run_conv(x, self.conv1, self.bn1, self.relu)
-        idt = x if self.downsample is None else run_conv(x, self.downsample[0], self.downsample[1], None)
+        idt = xr if self.downsample is None else run_conv(xr, self.downsample[0], self.downsample[1], None)
         return run_conv(y, self.conv2, self.bn2, self.relu, res=idt)
 
 

@@ -72,7 +72,50 @@ class _PepperNoise(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         mask, = ctx.saved_tensors
-        return g * (mask == 0).to(g.dtype), None
+        return hip.mask_keep(g, mask), None
+
+
+def _stack2(a, b):
+    """[a | b] along the batch (module inputs: NCHW f32, no gradient needed into `a`/`b` except through autograd's cat)"""
+    return _Stack2.apply(a, b)
+
+
+class _Stack2(torch.autograd.Function):
+    """torch.cat((a, b), 0) with device-to-device copies (no elementwise kernel) and a zero-copy backward"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+        out[:a.shape[0]].copy_(a)
+        out[a.shape[0]:].copy_(b)
+        ctx.na = a.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.na], g[ctx.na:]
+
+
+class _SplitBatch(torch.autograd.Function):
+    """x -> (x[:B], x[B:]) as views; the backward writes the two cotangents into one buffer (copies / memset, no kernels)"""
+
+    @staticmethod
+    def forward(ctx, x, B):
+        ctx.meta = (tuple(x.shape), x.dtype, x.device, B)
+        x = x.contiguous()
+        return x[:B], x[B:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        shape, dtype, dev, B = ctx.meta
+        g = torch.empty(shape, dtype=dtype, device=dev)
+        for part, src in ((g[:B], ga), (g[B:], gb)):
+            if src is None:
+                hip.zero_(part)
+            else:
+                part.copy_(src)
+        return g, None
 
 
 def _cfg_get(node, key, default=None):
@@ -85,7 +128,7 @@ class RDFCGAN:
     def __init__(self, device, distributed, args, is_train=True, fixed_training_samples=None, fixed_testing_samples=None,
                  num_classes=14, out_height=224, out_width=304, label_wall=12, label_floor=5, label_ceiling=3,
                  normal_provider=None, exact_schedule=False, compute_dtype=None, use_label_net=False, normal_net=None,
-                 device_pepper=False, pepper_seed=0):
+                 device_pepper=False, pepper_seed=0, batch_calls=None):
         self.device, self.distributed, self.args, self.is_train = device, distributed, args, is_train
         # G_label and the label / normal-consistency terms of loss_G (rdfc_gan.py:89,187-203,238-267): off by default -- the
         # benchmarked hot path is the four-network step; on, the step computes upstream's full objective except that the
@@ -103,6 +146,13 @@ class RDFCGAN:
         self.out_height, self.out_width = out_height, out_width
         self.normal_provider = normal_provider
         self.exact_schedule = exact_schedule
+        # Batched schedule (four-network hot path only): each network's two forward / backward passes per step run as ONE pass
+        # over the two inputs stacked along the batch -- G_A2B([real_A | fake_A]), G_B2A([real_B | fake_B]), D([real | fake]) --
+        # with BatchNorm statistics per half (layers.BN_GROUP_REPEATS): half as many, twice as large launches for the same
+        # per-sample arithmetic.  G_A2B never reads its `rgb` argument (rdf_generator.py:282), so its second pass does not
+        # depend on fake_A unless the surface normals are computed from it: None = on when the normals come from the batch
+        # (gt_normal); True = also with a `normal_provider`, which is then called with img=None for the fake_A tags.
+        self.batch_calls = batch_calls
         if compute_dtype is not None:
             Fh.set_compute_dtype(compute_dtype)
         self.init_model()
@@ -187,6 +237,7 @@ class RDFCGAN:
         if self.use_label_net or self.G_normal is not None:
             self.norm_mask = data['normal_masks'].to(dev) if 'normal_masks' in data else None
         self._batch = data
+        self._unit_gt = None
 
     def _set_input_static(self, data):
         """graph mode: the captured step reads its batch from fixed device buffers; a new batch is copied into them"""
@@ -209,15 +260,22 @@ class RDFCGAN:
         st['image_loss_weight'].copy_(self.mask / (self.mask.sum() + 1e-6))
         self.image_loss_weight = st['image_loss_weight']
         self._batch = data
+        self._unit_gt = None
 
     def _normal(self, tag, img):
         if self.G_normal is not None:
             return norm_normalize(self.G_normal(img)[:, 0:3])
         if self.normal_provider is not None:
-            return norm_normalize(self.normal_provider(tag, img)[:, 0:3])
+            v = self.normal_provider(tag, img)
+            return norm_normalize(v[:, 0:3]) if v.requires_grad or not v.is_cuda else hip.unit_normals(v)
         if self.gt_normal is None:
             raise RuntimeError('no normal_provider and no gt_normal in the batch: the hot path takes surface normals as input')
-        return norm_normalize(self.gt_normal[:, 0:3])
+        if not self.gt_normal.is_cuda:
+            return norm_normalize(self.gt_normal[:, 0:3])
+        hit = self.__dict__.get('_unit_gt')        # same batch, same normals: normalised once per set_input
+        if hit is None or hit[0] is not self.gt_normal:
+            hit = self._unit_gt = (self.gt_normal, hip.unit_normals(self.gt_normal))
+        return hit[1]
 
     # ---- inference (forward_test :168-182) -----------------------------------------------------------
     @torch.no_grad()
@@ -245,8 +303,45 @@ class RDFCGAN:
                 for p in m.parameters():
                     p.requires_grad = requires_grad
 
+    def _batched(self):
+        if self.exact_schedule or self.use_label_net or self.G_normal is not None or self.batch_calls is False:
+            return False
+        return True if self.batch_calls else self.normal_provider is None
+
+    def _forward_batched(self):
+        """forward() of the batched schedule: fake_B | rec_B from one G_A2B pass, fake_A | rec_A from one G_B2A pass"""
+        B = self.real_B.shape[0]
+        self.fake_normal_realA = self._normal('real_A', self.real_A)
+        self.fake_normal_fakeA = self._normal('fake_A', None)
+        normal_again = self._normal('fake_A_again', None)
+        # group 0 = G_A2B(real_A, ...) of forward() (:193); group 1 = G_A2B(fake_A, ...): the dead forward (:207) and the
+        # recomputation in backward_G (:234) see the same batch statistics -> two running-statistics updates
+        with layers.bn_groups((1, 2)):
+            out = self.G_A2B(None, _stack2(self.aux_A, self.aux_A), _stack2(self.fake_normal_realA, normal_again))['pred_depth']
+        fake_B, self.rec_B = _SplitBatch.apply(out, B)
+        self.fake_B = self._pepper(fake_B)
+        # G_B2A is InstanceNorm only: nothing in it couples the samples of a batch
+        out = self.G_B2A(_stack2(self.real_B, self.fake_B))
+        self.fake_A, self.rec_A = _SplitBatch.apply(out, B)
+
+    def _pepper(self, fake_B):
+        if getattr(self, '_graph_mode', False):
+            # host RNG draw happened before the replay (_draw_pepper_static); an all-zero mask is the "no noise" draw
+            return _PepperNoise.apply(fake_B, self._pepper_static)
+        if self.device_pepper:
+            self._pepper_calls += 1
+            if random.uniform(0, 1) < 0.9:                                       # the per-call coin of helper.py:386 stays on the host
+                b, _, h, w = fake_B.shape
+                mask = hip.draw_pepper_mask(b, h, w, self._pepper_seed + 7919 * self.local_rank, self._pepper_calls, 0.98, self.device)
+                return _PepperNoise.apply(fake_B, mask)
+            return fake_B
+        mask = draw_pepper_mask(fake_B.shape)
+        return fake_B if mask is None else _PepperNoise.apply(fake_B, self._mask_to_device(mask))
+
     def forward(self):
-        hip.reset_sums(self.device)         # zeroed f64 scratch of the one-stage normalisation reductions: rewound per step
+        hip.reset_sums(self.device)
+        if self._batched():
+            return self._forward_batched()         # zeroed f64 scratch of the one-stage normalisation reductions: rewound per step
         # The B->A half (G_B2A(real_B)) shares nothing with the A->B half in this method when only the four hot-path networks
         # run: it forks HERE, not behind everything the main stream has enqueued by then.  (G_label / G_normal are used by
         # both halves -- running statistics, packed weights -- so with them the fork stays behind the A->B half.)
@@ -258,20 +353,7 @@ class RDFCGAN:
         if self.use_label_net:
             # :187 (a fifth stream for this pass -- it depends on nothing but the image -- measured slower: 71-73 vs 67.7 ms per step)
             self.fake_label_realA_list = self.G_label(self.real_A)
-        self.fake_B = self.G_A2B(self.real_A, self.aux_A, self.fake_normal_realA)['pred_depth']
-        if getattr(self, '_graph_mode', False):
-            # host RNG draw happened before the replay (_draw_pepper_static); an all-zero mask is the "no noise" draw
-            self.fake_B = _PepperNoise.apply(self.fake_B, self._pepper_static)
-        elif self.device_pepper:
-            self._pepper_calls += 1
-            if random.uniform(0, 1) < 0.9:                                       # the per-call coin of helper.py:386 stays on the host
-                b, _, h, w = self.fake_B.shape
-                mask = hip.draw_pepper_mask(b, h, w, self._pepper_seed + 7919 * self.local_rank, self._pepper_calls, 0.98, self.device)
-                self.fake_B = _PepperNoise.apply(self.fake_B, mask)
-        else:
-            mask = draw_pepper_mask(self.fake_B.shape)
-            if mask is not None:
-                self.fake_B = _PepperNoise.apply(self.fake_B, self._mask_to_device(mask))
+        self.fake_B = self._pepper(self.G_A2B(self.real_A, self.aux_A, self.fake_normal_realA)['pred_depth'])
         if self.exact_schedule:
             with torch.no_grad():
                 self.G_B2A(self.fake_B)                                          # dead forward (:197)
@@ -312,7 +394,26 @@ class RDFCGAN:
                 if t is not None:
                     t.record_stream(main)        # allocated on the side stream, read on the main one
 
+    def _backward_G_batched(self):
+        a = self.args
+        lam_A, lam_B, lam_1 = _cfg_get(a, 'lambda_A', 100.0), _cfg_get(a, 'lambda_B', 100.0), _cfg_get(a, 'lambda_L1', 100.0)
+        with self._net_stream_ctx():                  # the two discriminators are independent: D_B on the second stream
+            loss_G_B2A = self.criterionGAN(self.disc_B(self.fake_A), True)
+        loss_G_A2B = self.criterionGAN(self.disc_A(self.fake_B), True)
+        loss_B2A_L1 = self.criterionL1(self.fake_A, self.real_A, weight=self.image_loss_weight) * lam_1 * 3
+        loss_cycle_B2A = self.criterionCycle(self.rec_B, self.real_B, weight=self.image_loss_weight) * lam_B
+        loss_A2B_L1 = self.criterionL1(self.fake_B, self.real_B, weight=self.image_loss_weight) * lam_1 * 5
+        loss_cycle_A2B = self.criterionCycle(self.rec_A, self.real_A) * lam_A
+        self._join_net_stream((loss_G_B2A,))
+        loss_G = loss_G_A2B + loss_cycle_A2B + loss_cycle_B2A + loss_G_B2A + loss_A2B_L1 + loss_B2A_L1
+        loss_G.backward()
+        return dict(loss_G=loss_G, loss_G_A2B=loss_G_A2B, loss_G_B2A=loss_G_B2A, loss_B2A_L1=loss_B2A_L1,
+                    loss_A2B_L1=loss_B2A_L1,          # upstream logs B2A under this key (rdfc_gan.py:276)
+                    loss_cycle_A=loss_cycle_A2B, loss_cycle_B=loss_cycle_B2A)
+
     def backward_G(self):
+        if self._batched():
+            return self._backward_G_batched()
         a = self.args
         lam_A, lam_B, lam_1 = _cfg_get(a, 'lambda_A', 100.0), _cfg_get(a, 'lambda_B', 100.0), _cfg_get(a, 'lambda_L1', 100.0)
         self._join_net_stream((self.fake_A, self.fake_normal_fakeA))             # forward()'s B->A half
@@ -367,6 +468,17 @@ class RDFCGAN:
         return out
 
     def backward_D_basic(self, model_D, real, fake):
+        if self._batched():
+            # D(real) then D(fake.detach()) as one pass over [real | fake]: BatchNorm statistics (and running-statistics
+            # updates, in upstream's order) per half
+            with layers.bn_groups((1, 1)):
+                pred = model_D(_stack2(real, fake.detach()))
+            pred_real, pred_fake = _SplitBatch.apply(pred, real.shape[0])
+            loss_D_real = self.criterionGAN(pred_real, True)
+            loss_D_fake = self.criterionGAN(pred_fake, False)
+            loss_D = (loss_D_real + loss_D_fake) * 0.5
+            loss_D.backward()
+            return loss_D_real, loss_D_fake, loss_D
         loss_D_real = self.criterionGAN(model_D(real), True)
         loss_D_fake = self.criterionGAN(model_D(fake.detach()), False)
         loss_D = (loss_D_real + loss_D_fake) * 0.5
@@ -383,12 +495,18 @@ class RDFCGAN:
 
     # ---- HIP-graph mode: the step is captured once as three graphs (G step | D step | Adam) and replayed; the
     #      data-parallel all-reduces stay eager between them, the host only draws the pepper mask and copies the batch in
-    def enable_graph(self, enabled=True):
+    def enable_graph(self, enabled=True, multi_stream=False):
+        """multi_stream=False (default): everything is captured on one stream.  True (experimental): the capture keeps the
+        eager step's fork / join structure (RDFGenerator's depth branch, D_B's pass, every weight gradient on helper streams;
+        the event waits between them become edges of the graph).  Measured on ROCm 7.2 / MI355X (round 2): with any ONE
+        helper stream captured the replay works but is no faster than eager launches (46-56 ms per step against 40-44:
+        hipGraphLaunch costs the host about as much per node as a launch), and with all of them hipStreamEndCapture
+        segfaults -- graph mode is therefore not the benchmark's default."""
         if enabled and (self.use_label_net or self.G_normal is not None):
             raise NotImplementedError('graph mode captures the four-network step only')
         self._graph_mode = bool(enabled)
         self._graphs = None
-        Fh.set_multi_stream(not enabled)        # the capture is single-stream; the eager step spreads over four streams
+        Fh.set_multi_stream(multi_stream or not enabled)
         if enabled:
             for o in self.optimizers.values():
                 o.make_capturable()
@@ -435,8 +553,11 @@ class RDFCGAN:
     def _seg_D(self):
         self.set_requires_grad([self.disc_A, self.disc_B], True)
         self.optimizer_D.zero_grad()
+        with self._net_stream_ctx():                  # as in the eager step: D_B's step on the second stream
+            stats_DB = self.backward_D_B2A()
         stats = self.backward_D_A2B()
-        stats.update(self.backward_D_B2A())
+        self._join_net_stream(tuple(stats_DB.values()))
+        stats.update(stats_DB)
         Fh.join_side_stream()
         return stats
 

