@@ -348,6 +348,11 @@ int rdfc_mask_keep(const float *g, const uint8_t *mask, float *out, int N, int C
 int rdfc_scale_dev(const float *x, const float *scalar, float k, float *out, size_t n, void *stream);
 /* helper.py:404-408 norm_normalize on channels 0..2 of an NCHW f32 map with Csrc >= 3 channels -> [N][3][HW]. */
 int rdfc_unit_normals(const float *src, float *dst, int N, int Csrc, int HW, void *stream);
+/* out[i] = weights[i] * *terms[i] (i < n <= 16), out[n] = post * (sequential f32 sum of them, in order): loss_G and its logged
+ * terms (rdfc_gan.py:252-288) / loss_D = (real + fake) * 0.5 (:292-300) in one launch.  terms: HOST array of device
+ * pointers, weights: HOST array.  _backward: out[i] = *grad_total * post * weights[i] (grad_total NULL = 1). */
+int rdfc_combine_scalars(int n, const float *const *terms, const float *weights, float post, float *out, void *stream);
+int rdfc_combine_scalars_backward(int n, const float *weights, float post, const float *grad_total, float *out, void *stream);
 /* dst[P][C] (pixel stride ld_dst) = sum over n <= 4 pixel-major maps srcs[k] (HOST array of device pointers, pixel strides
  * lds[k], HOST array): the gradient of an activation with several consumers in one pass (stands in for autograd's
  * pairwise adds: encoder features feeding the next stage and a skip connection, rdf_generator.py:286-398). */

@@ -395,6 +395,26 @@ __global__ void unit_normals_kernel(const float *__restrict__ src, float *__rest
     }
 }
 
+// loss_G = sum_i w_i * l_i (rdfc_gan.py:252-267) and its logged terms in one launch; sequential f32 adds in the given order
+// (what the chain of 0-dim tensor ops upstream computes), then * post
+constexpr int MAXTERMS = 16;
+struct Terms { const float *p[MAXTERMS]; float w[MAXTERMS]; int n; float post; };
+__global__ void combine_kernel(Terms t, float *__restrict__ out /* [n + 1] */) {
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float acc = 0.f;
+    for (int i = 0; i < t.n; ++i) {
+        const float v = *t.p[i] * t.w[i];
+        out[i] = v;
+        acc = i == 0 ? v : acc + v;
+    }
+    out[t.n] = acc * t.post;
+}
+__global__ void combine_bwd_kernel(Terms t, const float *__restrict__ g, float *__restrict__ out /* [n] */) {
+    const int i = threadIdx.x;
+    if (i < t.n) out[i] = (g ? *g : 1.f) * t.post * t.w[i];
+}
+
 // dst = sum of up to four pixel-major maps (each with its own pixel stride): the gradient of an activation that feeds
 // several consumers, in ONE pass (autograd would add them pairwise with stock elementwise kernels, after making
 // channel-slice cotangents contiguous)
@@ -657,5 +677,31 @@ extern "C" int rdfc_sum_maps(int n, const void *const *srcs, const int *lds, voi
         DISPATCH(dtype, hipLaunchKernelGGL(sum_maps_scalar_kernel<T>, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, s, (T *)dst, C, ld_dst, total));
     }
     RDFC_LAUNCH_CHECK("rdfc_sum_maps");
+    return 0;
+}
+
+extern "C" int rdfc_combine_scalars(int n, const float *const *terms, const float *weights, float post, float *out, void *stream) {
+    RDFC_REQUIRE(n >= 1 && n <= MAXTERMS && terms != nullptr && weights != nullptr && out != nullptr, "rdfc_combine_scalars: 1..%d terms", MAXTERMS);
+    Terms t{};
+    t.n = n;
+    t.post = post;
+    for (int i = 0; i < n; ++i) {
+        RDFC_REQUIRE(terms[i] != nullptr, "rdfc_combine_scalars: null term %d", i);
+        t.p[i] = terms[i];
+        t.w[i] = weights[i];
+    }
+    hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, out);
+    RDFC_LAUNCH_CHECK("rdfc_combine_scalars");
+    return 0;
+}
+
+extern "C" int rdfc_combine_scalars_backward(int n, const float *weights, float post, const float *grad_total, float *out, void *stream) {
+    RDFC_REQUIRE(n >= 1 && n <= MAXTERMS && weights != nullptr && out != nullptr, "rdfc_combine_scalars_backward: 1..%d terms", MAXTERMS);
+    Terms t{};
+    t.n = n;
+    t.post = post;
+    for (int i = 0; i < n; ++i) t.w[i] = weights[i];
+    hipLaunchKernelGGL(combine_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, grad_total, out);
+    RDFC_LAUNCH_CHECK("rdfc_combine_scalars_backward");
     return 0;
 }

@@ -378,7 +378,7 @@ class _CropCat(torch.autograd.Function):
             if os.environ.get('RDFC_DEBUG_CONTIG'):
                 g_fd = g_fd.contiguous()
         else:
-            g_fd = torch.zeros(N, Hd, Wd, Cd, dtype=dout.dtype, device=dout.device)
+            g_fd = hip.zero_(torch.empty(N, Hd, Wd, Cd, dtype=dout.dtype, device=dout.device))
             hip.copy_window(dout[..., :Cd], g_fd)
         return g_fd, g_fe
 
@@ -443,6 +443,60 @@ def fanout(x, n):
     if n <= 1 or not x.requires_grad:
         return (x,) * n
     return _FanOut.apply(x, n)
+
+
+class _FanOutFlat(torch.autograd.Function):
+    """fanout for tensors of any layout-free shape (upstream's NCHW f32 images between the networks)"""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view(x.shape) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        while len(live) > 1:
+            live = [hip.sum_flat(live[:4])] + live[4:]
+        return live[0], None
+
+
+def fanout_flat(x, n):
+    if n <= 1 or not x.requires_grad or not x.is_cuda:
+        return (x,) * n
+    return _FanOutFlat.apply(x.contiguous(), n)
+
+
+class _CombineLosses(torch.autograd.Function):
+    """total = post * sum_i w_i * l_i (sequential f32 adds, in order) plus the scaled terms, one launch each way"""
+
+    @staticmethod
+    def forward(ctx, weights, post, *terms):
+        out = hip.combine_scalars(terms, weights, post)
+        ctx.meta = (tuple(weights), post, terms[0].device)
+        total, scaled = out[len(terms)], out[:len(terms)]
+        ctx.mark_non_differentiable(scaled)           # logged values only
+        return total, scaled
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        weights, post, dev = ctx.meta
+        g = hip.combine_scalars_backward(weights, post, g_total, dev)
+        return (None, None) + tuple(g[i] for i in range(len(weights)))
+
+
+def combine_losses(terms, post=1.0):
+    """terms: [(0-dim loss tensor, python weight), ...] -> (total, f32[n] of the weighted terms, detached, for logging)"""
+    ts = [t for t, _ in terms]
+    ws = [float(w) for _, w in terms]
+    if not ts[0].is_cuda:
+        scaled = [t * w for t, w in zip(ts, ws)]
+        total = scaled[0]
+        for v in scaled[1:]:
+            total = total + v
+        return total * post if post != 1.0 else total, torch.stack([v.detach() for v in scaled])
+    return _CombineLosses.apply(ws, post, *ts)
 
 
 class _ReflectPad(torch.autograd.Function):

@@ -616,6 +616,16 @@ def unit_normals(v):
     return out
 
 
+def sum_flat(tensors):
+    """sum of 2..4 contiguous tensors of one shape / dtype (f32 | compute dtype) in one pass"""
+    t0 = tensors[0]
+    n = t0.numel()
+    vec = 8 if t0.dtype != torch.float32 else 4
+    Cc = vec if n % vec == 0 else 1
+    views = [t.contiguous().view(1, 1, n // Cc, Cc) for t in tensors]
+    return sum_maps(views).view(t0.shape)
+
+
 def sum_maps(maps, out=None):
     """sum of 1..4 pixel-major maps [N,H,W,C] (each may be a channel slice of a wider map) in one pass"""
     m0 = maps[0]
@@ -627,6 +637,26 @@ def sum_maps(maps, out=None):
     ptrs = (C.c_void_p * n)(*[m.data_ptr() for m in maps])
     lds = (C.c_int * n)(*[ld(m) for m in maps])
     _chk(lib().rdfc_sum_maps(n, ptrs, lds, _p(out), N * H * W, Cc, ld(out), dt(m0), _st()), 'rdfc_sum_maps')
+    return out
+
+
+def combine_scalars(terms, weights, post=1.0):
+    """terms: 0-dim f32 device tensors -> f32[n + 1] = (w_i * l_i ..., post * sum)"""
+    n = len(terms)
+    ts = [t.detach().reshape(()).float() for t in terms]
+    out = torch.empty(n + 1, dtype=torch.float32, device=ts[0].device)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ws = (C.c_float * n)(*[float(w) for w in weights])
+    _chk(lib().rdfc_combine_scalars(n, ptrs, ws, _f(post), _p(out), _st()), 'rdfc_combine_scalars')
+    return out
+
+
+def combine_scalars_backward(weights, post, grad_total, device):
+    n = len(weights)
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    ws = (C.c_float * n)(*[float(w) for w in weights])
+    g = grad_total.reshape(()).float() if grad_total is not None else None
+    _chk(lib().rdfc_combine_scalars_backward(n, ws, _f(post), _p(g), _p(out), _st()), 'rdfc_combine_scalars_backward')
     return out
 
 

@@ -78,7 +78,10 @@ class FlatAdam(torch.optim.Optimizer):
         # (no join of the helper streams here: step() / the all-reduce joined them before they read the gradients, and the
         # other optimizer's weight gradients may keep running under this one's backward)
         self.wait_grads()
-        self.flat_grad.zero_()
+        if self.flat_grad.is_cuda:
+            hip.zero_(self.flat_grad)       # hipMemsetAsync
+        else:
+            self.flat_grad.zero_()
         for p in self._params:        # autograd may have replaced a view when grads were None
             if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr() or \
                     p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * 4:

@@ -320,9 +320,12 @@ class RDFCGAN:
             out = self.G_A2B(None, _stack2(self.aux_A, self.aux_A), _stack2(self.fake_normal_realA, normal_again))['pred_depth']
         fake_B, self.rec_B = _SplitBatch.apply(out, B)
         self.fake_B = self._pepper(fake_B)
+        # fake_B feeds G_B2A, D_A and the L1 term; fake_A feeds D_B and its L1 term: their cotangents are summed by one HIP pass
+        fB_cyc, self._fB_D, self._fB_L1 = Fh.fanout_flat(self.fake_B, 3)
         # G_B2A is InstanceNorm only: nothing in it couples the samples of a batch
-        out = self.G_B2A(_stack2(self.real_B, self.fake_B))
+        out = self.G_B2A(_stack2(self.real_B, fB_cyc))
         self.fake_A, self.rec_A = _SplitBatch.apply(out, B)
+        self._fA_D, self._fA_L1 = Fh.fanout_flat(self.fake_A, 2)
 
     def _pepper(self, fake_B):
         if getattr(self, '_graph_mode', False):
@@ -398,18 +401,21 @@ class RDFCGAN:
         a = self.args
         lam_A, lam_B, lam_1 = _cfg_get(a, 'lambda_A', 100.0), _cfg_get(a, 'lambda_B', 100.0), _cfg_get(a, 'lambda_L1', 100.0)
         with self._net_stream_ctx():                  # the two discriminators are independent: D_B on the second stream
-            loss_G_B2A = self.criterionGAN(self.disc_B(self.fake_A), True)
-        loss_G_A2B = self.criterionGAN(self.disc_A(self.fake_B), True)
-        loss_B2A_L1 = self.criterionL1(self.fake_A, self.real_A, weight=self.image_loss_weight) * lam_1 * 3
-        loss_cycle_B2A = self.criterionCycle(self.rec_B, self.real_B, weight=self.image_loss_weight) * lam_B
-        loss_A2B_L1 = self.criterionL1(self.fake_B, self.real_B, weight=self.image_loss_weight) * lam_1 * 5
-        loss_cycle_A2B = self.criterionCycle(self.rec_A, self.real_A) * lam_A
-        self._join_net_stream((loss_G_B2A,))
-        loss_G = loss_G_A2B + loss_cycle_A2B + loss_cycle_B2A + loss_G_B2A + loss_A2B_L1 + loss_B2A_L1
+            gan_B2A = self.criterionGAN(self.disc_B(self._fA_D), True)
+        gan_A2B = self.criterionGAN(self.disc_A(self._fB_D), True)
+        l1_B2A = self.criterionL1(self._fA_L1, self.real_A, weight=self.image_loss_weight)
+        cyc_B2A = self.criterionCycle(self.rec_B, self.real_B, weight=self.image_loss_weight)
+        l1_A2B = self.criterionL1(self._fB_L1, self.real_B, weight=self.image_loss_weight)
+        cyc_A2B = self.criterionCycle(self.rec_A, self.real_A)
+        self._join_net_stream((gan_B2A,))
+        # loss_G = loss_G_A2B + loss_cycle_A2B + loss_cycle_B2A + loss_G_B2A + loss_A2B_L1 + loss_B2A_L1 (:252-254), the
+        # lambda factors folded into one f32 product per term ((x * lambda_L1) * 5 upstream: at most one rounding apart)
+        loss_G, terms = Fh.combine_losses([(gan_A2B, 1.0), (cyc_A2B, lam_A), (cyc_B2A, lam_B), (gan_B2A, 1.0),
+                                           (l1_A2B, lam_1 * 5), (l1_B2A, lam_1 * 3)])
         loss_G.backward()
-        return dict(loss_G=loss_G, loss_G_A2B=loss_G_A2B, loss_G_B2A=loss_G_B2A, loss_B2A_L1=loss_B2A_L1,
-                    loss_A2B_L1=loss_B2A_L1,          # upstream logs B2A under this key (rdfc_gan.py:276)
-                    loss_cycle_A=loss_cycle_A2B, loss_cycle_B=loss_cycle_B2A)
+        return dict(loss_G=loss_G, loss_G_A2B=terms[0], loss_G_B2A=terms[3], loss_B2A_L1=terms[5],
+                    loss_A2B_L1=terms[5],             # upstream logs B2A under this key (rdfc_gan.py:276)
+                    loss_cycle_A=terms[1], loss_cycle_B=terms[2])
 
     def backward_G(self):
         if self._batched():
@@ -476,7 +482,7 @@ class RDFCGAN:
             pred_real, pred_fake = _SplitBatch.apply(pred, real.shape[0])
             loss_D_real = self.criterionGAN(pred_real, True)
             loss_D_fake = self.criterionGAN(pred_fake, False)
-            loss_D = (loss_D_real + loss_D_fake) * 0.5
+            loss_D, _ = Fh.combine_losses([(loss_D_real, 1.0), (loss_D_fake, 1.0)], post=0.5)    # (real + fake) * 0.5
             loss_D.backward()
             return loss_D_real, loss_D_fake, loss_D
         loss_D_real = self.criterionGAN(model_D(real), True)

@@ -606,3 +606,28 @@ def test_small_elementwise_ops():
     z = torch.ones(5, 7, device=DEV)
     h.zero_(z[1:3])
     assert float(z.sum()) == 21.0
+
+
+def test_combine_losses_and_flat_fanout():
+    from rdfc_gan_amd import functional as Fh
+    vals = [0.37, 12.5, 3.25e-3, 0.9]
+    ws = [1.0, 100.0, 500.0, 300.0]
+    ts = [torch.tensor(v, device=DEV, requires_grad=True) for v in vals]
+    total, scaled = Fh.combine_losses(list(zip(ts, ws)), post=0.5)
+    ref = torch.tensor(0.0)
+    acc = None
+    for v, w in zip(vals, ws):
+        term = torch.tensor(v) * w
+        acc = term if acc is None else acc + term
+    assert float(total) == float(acc * 0.5)                                   # sequential f32 adds, in order
+    assert torch.equal(scaled.cpu(), torch.tensor([torch.tensor(v) * w for v, w in zip(vals, ws)]))
+    assert not scaled.requires_grad
+    (total * 3.0).backward()
+    for t, w in zip(ts, ws):
+        assert float(t.grad) == pytest.approx(1.5 * w, rel=1e-6)
+    x = rnd(2, 3, 9, 11, seed=4).to(DEV).requires_grad_(True)
+    a, b, c = Fh.fanout_flat(x, 3)
+    (a.sum() * 2 + (b * b).sum() + c[:, :1].sum() * 7).backward()
+    exp = 2 + 2 * x.detach()
+    exp[:, :1] += 7
+    assert torch.allclose(x.grad, exp, rtol=1e-6, atol=1e-6)
