@@ -29,7 +29,7 @@ for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
 
 # forward GFLOP per pair (2*MAC over conv / conv-transpose / linear) at 228x304
 GFLOP_FWD = dict(G_A2B=209.64, G_B2A=73.28, D_A=6.49, D_B=6.56, G_label=72.49)   # G_label: train mode, both heads
-PEAK_TFLOPS = dict(bf16=2500.0, f32=157.3)        # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = dict(bf16=2500.0, f16=2500.0, f32=157.3)        # dense MFMA peaks, MI355X_MICROARCH.md
 
 
 def step_gflop_per_pair(exact_schedule, scale=1.0, label_net=False):
@@ -125,7 +125,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='pairs per GPU')
     ap.add_argument('--height', type=int, default=228)
     ap.add_argument('--width', type=int, default=304)
-    ap.add_argument('--dtype', choices=('bf16', 'f32'), default='bf16')
+    ap.add_argument('--dtype', choices=('bf16', 'f16', 'f32'), default='bf16')
     ap.add_argument('--nlspn', action='store_true', help='BASELINE configs[2]: NLSPN refinement on')
     ap.add_argument('--exact-schedule', action='store_true', help="run upstream's two dead forwards too")
     ap.add_argument('--label-net', action='store_true', help='SURVEY 8f rank 1 (not the headline workload): G_label (PSPNet) twice '
@@ -162,7 +162,7 @@ def main():
     from rdfc_gan_amd import functional as Fh
     from rdfc_gan_amd import hip
     from rdfc_gan_amd.rdfc_gan import RDFCGAN
-    Fh.set_compute_dtype(torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
+    Fh.set_compute_dtype(dict(bf16=torch.bfloat16, f16=torch.float16, f32=torch.float32)[a.dtype])
     torch.manual_seed(0)
     random.seed(1234 + rank)
     np.random.seed(1234 + rank)

@@ -13,9 +13,10 @@
  *     base[((n*H + y)*W + x) * ld + c], ld >= C (ld > C addresses a channel slice of
  *     a wider map, which is how channel concatenation is done without a copy pass).
  *     1-channel maps are therefore bit-identical to upstream's NCHW tensors.
- *   - dtype: RDFC_F32 (exact-f32 MFMA path, parity mode) or RDFC_BF16 (bf16 storage,
- *     bf16 MFMA, f32 accumulation).  Statistics, scales, losses, weight gradients
- *     and optimizer state are always f32.
+ *   - dtype: RDFC_F32 (exact-f32 MFMA path, parity mode), RDFC_BF16 (bf16 storage,
+ *     bf16 MFMA, f32 accumulation) or RDFC_F16 (IEEE half storage, f16 MFMA, f32
+ *     accumulation: BASELINE config "fp16 activations with fp32 loss accumulate").
+ *     Statistics, scales, losses, weight gradients and optimizer state are always f32.
  *
  * Each group below cites the upstream interface it stands in for (paths relative to
  * RDFC-GAN/).  The python side (rdfc_gan_amd/) binds this file with ctypes; a
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-enum { RDFC_F32 = 0, RDFC_BF16 = 1 };
+enum { RDFC_F32 = 0, RDFC_BF16 = 1, RDFC_F16 = 2 };
 enum { RDFC_ACT_NONE = 0, RDFC_ACT_RELU = 1, RDFC_ACT_LRELU = 2, RDFC_ACT_TANH = 3, RDFC_ACT_SIGMOID = 4,
        RDFC_ACT_PRELU = 5 /* slope read from device memory */ };
 
@@ -60,7 +61,7 @@ typedef struct rdfc_conv_desc {
     int32_t KH, KW;             /* kernel                                            */
     int32_t sh, sw, ph, pw, dh, dw;
     int32_t ldx, ldy;           /* pixel strides (elements) of x / y                 */
-    int32_t dtype;              /* RDFC_F32 | RDFC_BF16: storage + MFMA type of x,y,w */
+    int32_t dtype;              /* RDFC_F32 | RDFC_BF16 | RDFC_F16: storage + MFMA type of x,y,w */
     int32_t act;                /* epilogue activation applied after bias (forward)  */
     float   slope;              /* LeakyReLU slope                                   */
     int32_t out_f32;            /* 1: result stored as f32 regardless of dtype       */
@@ -334,6 +335,38 @@ int rdfc_normal_losses_backward(const float *normal, const float *gt_normal, con
  * stream than upstream's numpy draw, hence opt-in. */
 int rdfc_draw_pepper_mask(uint8_t *mask, int N, int HW, uint64_t seed, uint64_t counter, float snr, void *stream);
 int rdfc_apply_pepper(float *img, const uint8_t *mask, int N, int C, int HW, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * NLSPN refinement (rdf_generator/nlspn/nlspn_model.py), fused around the single-channel 3x3 deformable gather.
+ * All maps f32, NCHW planes [B][c][H][W] as upstream's ModulatedDeformConvFunction takes them, except offset_aff.
+ * ------------------------------------------------------------------------------ */
+/* NLPSN._get_offset_affinity (nlspn_model.py:68-138) behind the guidance conv: offset_aff = conv_offset_aff(guidance),
+ * pixel-major [B][H][W][24] (pixel stride ld, dtype f32 | bf16; channels 2k, 2k+1 = (dh, dw) of neighbour k, 16+k = its raw
+ * affinity) -> offset [B][18][H][W] (zero reference tap inserted at tap 4, :77-80), aff [B][9][H][W]: tanh / scale
+ * (affinity 2 'TC', 3 'TGASS': / (scale + 1e-8), :84-87), x the eight 1x1 deformable confidence gathers with detached
+ * offsets (confidence != NULL, :96-118; w_conf / b_conf: device scalars, NULL = 1 / 0), / max-clamped abs-sum (0 'AS',
+ * 1 'ASS', 3, :121-128), reference weight 1 - sum (:130-136).  conf_samples [B][8][H][W] receives the gathered
+ * confidences (kept for the backward). */
+int rdfc_nlspn_affinity_forward(const void *offset_aff, int ld, int dtype, const float *confidence, const float *scale,
+                                const float *w_conf, const float *b_conf, int affinity, int B, int H, int W, float *offset,
+                                float *aff, float *conf_samples, void *stream);
+/* its backward: grad_offset [B][18][H][W] (may be NULL) and grad_aff [B][9][H][W] -> grad_offset_aff (pixel-major, stride
+ * ldg, same dtype as offset_aff), grad_confidence [B][H][W] (may be NULL; zero-filled here, then scattered into),
+ * grad_scale (device f32, may be NULL; zero-filled here). */
+int rdfc_nlspn_affinity_backward(const void *offset_aff, int ld, int dtype, const float *conf_samples, const float *scale,
+                                 const float *w_conf, int affinity, int B, int H, int W, const float *grad_offset,
+                                 const float *grad_aff, void *grad_offset_aff, int ldg, float *grad_confidence,
+                                 float *grad_scale, void *stream);
+/* NLPSN.forward's propagation loop (:166-173, preserve_input = False): T steps of
+ *   feat <- ModulatedDeformConvFunction(feat, offset, aff, w, b, stride 1, pad 1, dil 1, groups 1, deformable_groups 1)
+ * feats [T+1][B][H][W]: slot 0 receives a copy of feat0, slot i the map after step i (the saved inputs of the backward;
+ * slot T is the result).  weight f32[9], bias f32[1] or NULL: device pointers (the module's frozen `w`, `b`). */
+int rdfc_nlspn_propagate_forward(const float *feat0, const float *offset, const float *aff, const float *weight, const float *bias,
+                                 int B, int H, int W, int T, float *feats, void *stream);
+/* backward of the loop.  grads [T+1][B][H][W]: slot T holds the cotangent of the result on entry; slots T-1 .. 0 are filled
+ * (slot 0 = gradient of feat0).  grad_offset / grad_aff (both or neither): the sums over all T steps, one pass. */
+int rdfc_nlspn_propagate_backward(const float *feats, const float *offset, const float *aff, const float *weight, int B, int H, int W,
+                                  int T, float *grads, float *grad_offset, float *grad_aff, void *stream);
 
 /* ------------------------------------------------------------------------------
  * Small elementwise operators that keep stock-framework arithmetic off the path.

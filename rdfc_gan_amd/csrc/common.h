@@ -10,6 +10,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -20,7 +23,15 @@ void rdfc_set_error(const char *fmt, ...);
 // name of the kernel instantiation the last conv entry point launched (rdfc_last_kernel(), used by bench.py to
 // attribute HIP-event times to one kernel symbol that can be matched against rocprofv3's kernel trace)
 void rdfc_note_kernel(const char *fmt, ...);
-template <typename T> inline const char *tname() { return sizeof(T) == 2 ? "__bf16" : "float"; }
+template <typename T> inline const char *tname() { return sizeof(T) == 4 ? "float" : (__is_same(T, _Float16) ? "_Float16" : "__bf16"); }
+// dtype helpers (RDFC_BF16 and RDFC_F16 share every layout: 2-byte elements, 8 per 16-byte vector)
+static inline bool rdfc_is16(int dtype) { return dtype == RDFC_BF16 || dtype == RDFC_F16; }
+static inline bool rdfc_dtype_ok(int dtype) { return dtype == RDFC_F32 || rdfc_is16(dtype); }
+static inline int rdfc_vec(int dtype) { return rdfc_is16(dtype) ? 8 : 4; }
+#define RDFC_DISPATCH(dtype, ...)                                      \
+    if ((dtype) == RDFC_BF16) { using T = bf16_t; __VA_ARGS__; }      \
+    else if ((dtype) == RDFC_F16) { using T = f16_t; __VA_ARGS__; }   \
+    else { using T = float; __VA_ARGS__; }
 #define RDFC_REQUIRE(cond, ...)            \
     do {                                   \
         if (!(cond)) {                     \
@@ -52,6 +63,32 @@ template <> struct Elem<bf16_t> {
     __device__ static void st(bf16_t *p, float v) { *p = (bf16_t)v; }
 };
 
+template <> struct Elem<f16_t> {
+    static constexpr int VEC = 8;
+    __device__ static float ld(const f16_t *p) { return (float)*p; }
+    __device__ static void st(f16_t *p, float v) { *p = (f16_t)v; }
+};
+
+// The LDS-DMA kernels move 2-byte elements as opaque bits (typed bf16_t) and only care about the format in three places:
+// the MFMA instruction, float -> element in the epilogue, element -> float in a prologue.  DT = RDFC_BF16 | RDFC_F16.
+template <int DT> __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (DT == RDFC_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <int DT> __device__ __forceinline__ bf16_t cvt16(float v) {
+    if constexpr (DT == RDFC_F16) return __builtin_bit_cast(bf16_t, (f16_t)v);
+    else return (bf16_t)v;
+}
+template <int DT> __device__ __forceinline__ float f32of(bf16_t x) {
+    if constexpr (DT == RDFC_F16) return (float)__builtin_bit_cast(f16_t, x);
+    else return (float)x;
+}
+template <typename T> struct DtOf { static constexpr int value = RDFC_BF16; };
+template <> struct DtOf<f16_t> { static constexpr int value = RDFC_F16; };
+template <> struct DtOf<float> { static constexpr int value = RDFC_F32; };
+
 // 16-byte vector of T <-> floats
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
@@ -75,6 +112,19 @@ template <> struct Vec16<bf16_t> {
     }
     __device__ float get(int i) const { return (float)v[i]; }
     __device__ void set(int i, float f) { v[i] = (bf16_t)f; }
+};
+
+template <> struct Vec16<f16_t> {
+    f16x8 v;
+    __device__ void load(const f16_t *p) { v = *reinterpret_cast<const f16x8 *>(p); }
+    __device__ void load_nt(const f16_t *p) { v = __builtin_nontemporal_load(reinterpret_cast<const f16x8 *>(p)); }
+    __device__ void store(f16_t *p) const { *reinterpret_cast<f16x8 *>(p) = v; }
+    __device__ void store_nt(f16_t *p) const { __builtin_nontemporal_store(v, reinterpret_cast<f16x8 *>(p)); }
+    __device__ void zero() {
+        for (int i = 0; i < 8; ++i) v[i] = (f16_t)0.0f;
+    }
+    __device__ float get(int i) const { return (float)v[i]; }
+    __device__ void set(int i, float f) { v[i] = (f16_t)f; }
 };
 
 // ---- activations ------------------------------------------------------------------

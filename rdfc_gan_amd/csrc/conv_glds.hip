@@ -87,7 +87,7 @@ __device__ unsigned long long g_stamps[8][9][6];
 // is back 125, 16 MFMAs 280 -- 600 in all, the matrix pipe busy 43 %.  Here a consumer's phase is barrier + MFMAs.
 // JR: pixel rows (of 16) per wave: 4 -> a wave owns 64 co x 64 px; 8 -> 64 co x 128 px (32 MFMAs per phase and barrier against 12
 // fragment reads, and the tap's weights serve twice the pixels: 45 % fewer DMA'd bytes and L2 requests per MFMA; 128 accumulators)
-template <int TCO, int NW, int NPROD = 0, int JR = 4>
+template <int TCO, int NW, int NPROD = 0, int JR = 4, int DT = RDFC_BF16>     // DT: RDFC_BF16 | RDFC_F16 (2-byte elements moved as opaque bits)
 __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds_kernel(GParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
                                                                   const float *__restrict__ bias, void *__restrict__ yout,
                                                                   const bf16_t *__restrict__ zero, float *__restrict__ stats) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < JR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < JR; ++j) acc[i][j] = mma16<DT>(a[i], b[j], acc[i][j]);
     };
     auto compute = [&](int it, int cc, int tap) {
         bf16x8 a[4], b[JR];
@@ -432,7 +432,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[i][j][r] + bv[i][r];
-                        if (!p.out_f32) v = (float)(bf16_t)v;
+                        if (!p.out_f32) v = f32of<DT>(cvt16<DT>(v));
                         s1[i][r] += v;
                         s2[i][r] += v * v;
                     }
@@ -501,11 +501,11 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
                     bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
                     if (vec_ok && co + 3 < p.Cout) {
                         bf16x4 o;
-                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        for (int r = 0; r < 4; ++r) o[r] = cvt16<DT>(v[r]);
                         *reinterpret_cast<bf16x4 *>(y) = o;
                     } else
                         for (int r = 0; r < 4; ++r)
-                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                            if (co + r < p.Cout) y[r] = cvt16<DT>(v[r]);
                 }
             }
         }
@@ -532,7 +532,7 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO, int NW, int NPROD = 0, int JR = 4>
+template <int TCO, int NW, int NPROD = 0, int JR = 4, int DT = RDFC_BF16>
 int launch(const GParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, float *stats, hipStream_t st) {
     constexpr bool SPEC = NPROD > 0;
     constexpr int NT = NW * 64, TR = JR * NW / (TCO / 64);
@@ -540,14 +540,14 @@ int launch(const GParams &p, const void *x, const void *w, const float *bias, vo
     constexpr int SMEM = 2 * PATCH + (SPEC ? 5 : (JR == 4 && NW == 4 ? ring_of<TCO>() : WRING)) * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW, NPROD, JR>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM + 65536) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW, NPROD, JR, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM + 65536) != hipSuccess) return 0;
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
-    rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d, %d>", TCO, NW, NPROD, JR);         // the symbol as rocprofv3 prints it
+    rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d, %d, %d>", TCO, NW, NPROD, JR, DT);         // the symbol as rocprofv3 prints it
     // experiment knob: extra (unused) dynamic LDS, e.g. 40960 leaves room for ONE workgroup per CU
     static const int pad_lds = getenv("RDFC_GLDS_PAD_LDS") ? atoi(getenv("RDFC_GLDS_PAD_LDS")) : 0;
-    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, NW, NPROD, JR>), grid, dim3((NW + NPROD) * 64), SMEM + pad_lds, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
+    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, NW, NPROD, JR, DT>), grid, dim3((NW + NPROD) * 64), SMEM + pad_lds, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
     return 1;
 }
 
@@ -555,7 +555,7 @@ int launch(const GParams &p, const void *x, const void *w, const float *bias, vo
 
 static bool glds_shape_ok(const rdfc_conv_desc *d, int transposed) {
     static const int mode = getenv("RDFC_GLDS") ? atoi(getenv("RDFC_GLDS")) : 1;
-    if (!mode || d->dtype != RDFC_BF16) return false;
+    if (!mode || !rdfc_is16(d->dtype)) return false;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->ph == d->pw && d->ph <= 1 && d->dh == 1 && d->dw == 1)) return false;
     if (Cin % BK != 0 || d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return false;
@@ -586,6 +586,11 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
               Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
               d->act, d->slope, d->out_f32, 0, 0, stats != nullptr ? G : 0};
     p.tiles_x = cdiv(p.W, TC);
+    if (d->dtype == RDFC_F16) {                      // f16: the default variants only (the A/B variants below are bf16 experiments)
+        p.tiles_y = cdiv(p.H, Cout > 64 ? 8 : 16);
+        return Cout > 64 ? launch<128, 4, 0, 4, RDFC_F16>(p, in, w, bias, out, zero, stats, st)
+                         : launch<64, 4, 0, 4, RDFC_F16>(p, in, w, bias, out, zero, stats, st);
+    }
     if (Cout > 64) {
         // 8 waves on 128 co x (16x16) px, one workgroup per CU: 43 % fewer DMA instructions per MFMA (the weights of a tap
         // serve twice the pixels).  Faster when its grid is one partial round or many rounds (512 ch @ 29x38, 192

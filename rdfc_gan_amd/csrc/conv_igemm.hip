@@ -36,12 +36,12 @@ struct IgemmParams {
 constexpr int BK = 32;
 constexpr int MAXTAPS = 64;
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    // one v_mfma_f32_16x16x32_bf16 covers BK
+template <typename T> struct Mma {
+    // 2-byte elements (bf16 | f16): one v_mfma_f32_16x16x32_{bf16,f16} covers BK
     template <int MT, int NT>
-    __device__ static void step(const bf16_t *As, const bf16_t *Bs, int ldk, int arow, int brow, int lane,
+    __device__ static void step(const T *As_, const T *Bs_, int ldk, int arow, int brow, int lane,
                                 f32x4 (&acc)[MT][NT]) {
+        const bf16_t *As = reinterpret_cast<const bf16_t *>(As_), *Bs = reinterpret_cast<const bf16_t *>(Bs_);
         bf16x8 a[MT], b[NT];
         const int r = lane & 15, kq = (lane >> 4) * 8;
 #pragma unroll
@@ -51,7 +51,7 @@ template <> struct Mma<bf16_t> {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) acc[i][j] = mma16<DtOf<T>::value>(a[i], b[j], acc[i][j]);
     }
 };
 template <> struct Mma<float> {
@@ -296,11 +296,11 @@ __global__ __launch_bounds__(NTHREADS, NTHREADS == 512 && sizeof(T) == 2 ? 4 : 1
                     bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
                     if (vec_ok && co + 3 < p.Cout) {
                         bf16x4 o;
-                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        for (int r = 0; r < 4; ++r) o[r] = cvt16<DtOf<T>::value>(v[r]);
                         *reinterpret_cast<bf16x4 *>(y) = o;
                     } else {
                         for (int r = 0; r < 4; ++r)
-                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                            if (co + r < p.Cout) y[r] = cvt16<DtOf<T>::value>(v[r]);
                     }
                 }
             }
@@ -338,7 +338,7 @@ int launch_T(const IgemmParams &p, const void *x, const void *w, const float *bi
 
 int check_desc(const rdfc_conv_desc *d, const char *who) {
     RDFC_REQUIRE(d != nullptr, "%s: null descriptor", who);
-    RDFC_REQUIRE(d->dtype == RDFC_F32 || d->dtype == RDFC_BF16, "%s: bad dtype %d", who, d->dtype);
+    RDFC_REQUIRE(rdfc_dtype_ok(d->dtype), "%s: bad dtype %d", who, d->dtype);
     RDFC_REQUIRE(d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->Ci > 0 && d->Ho > 0 && d->Wo > 0 && d->Co > 0,
                  "%s: non-positive dimension", who);
     RDFC_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= MAXTAPS, "%s: kernel %dx%d unsupported (max %d taps)", who,
@@ -348,7 +348,7 @@ int check_desc(const rdfc_conv_desc *d, const char *who) {
     RDFC_REQUIRE((double)d->N * d->Hi * d->Wi * d->ldx < 2147483647.0 && (double)d->N * d->Ho * d->Wo * d->ldy < 2147483647.0 &&
                      (double)d->Co * d->KH * d->KW * d->Ci < 2147483647.0,
                  "%s: maps of 2^31 elements or more need 64-bit offsets (not built)", who);
-    const int vec = d->dtype == RDFC_BF16 ? 8 : 4;
+    const int vec = rdfc_vec(d->dtype);
     RDFC_REQUIRE(d->Ci % BK != 0 || d->ldx % vec == 0, "%s: ldx=%d must be a multiple of %d for vector loads", who, d->ldx, vec);
     RDFC_REQUIRE(d->Co % BK != 0 || d->ldy % vec == 0, "%s: ldy=%d must be a multiple of %d for vector loads", who, d->ldy, vec);
     return 0;
@@ -387,6 +387,7 @@ extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const
     } else if (rdfc_try_igemm_glds(d, 0, x, w_fwd, bias, y, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 0, x, w_fwd, bias, y, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, w_fwd, bias, y, st);
+    else if (d->dtype == RDFC_F16) launch_T<f16_t>(p, x, w_fwd, bias, y, st);
     else launch_T<float>(p, x, w_fwd, bias, y, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_forward");
     return 0;
@@ -425,6 +426,7 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
     } else if (rdfc_try_igemm_glds(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, dy, w_bwd, bias, dx, st);
+    else if (d->dtype == RDFC_F16) launch_T<f16_t>(p, dy, w_bwd, bias, dx, st);
     else launch_T<float>(p, dy, w_bwd, bias, dx, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_dgrad");
     return 0;

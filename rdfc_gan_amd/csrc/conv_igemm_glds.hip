@@ -35,7 +35,7 @@ __device__ inline void glds16(const void *gsrc, unsigned lds_base) {
 }
 template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TCO>
+template <int TCO, int DT = RDFC_BF16>
 __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
                                                            const float *__restrict__ bias, void *__restrict__ yout,
                                                            const bf16_t *__restrict__ zero) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma16<DT>(a[i], b[j], acc[i][j]);
         }
         wait_vm<0>();
     }
@@ -231,11 +231,11 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
                     bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
                     if (vec_ok && co + 3 < p.Cout) {
                         bf16x4 o;
-                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        for (int r = 0; r < 4; ++r) o[r] = cvt16<DT>(v[r]);
                         *reinterpret_cast<bf16x4 *>(y) = o;
                     } else
                         for (int r = 0; r < 4; ++r)
-                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                            if (co + r < p.Cout) y[r] = cvt16<DT>(v[r]);
                 }
             }
         }
@@ -255,7 +255,7 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO>
+template <int TCO, int DT = RDFC_BF16>
 int launch(const IGParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, hipStream_t st) {
     constexpr int TPX = TCO == 128 ? 128 : 256;
 #ifdef RDFC_IGEMM_GLDS_RING
@@ -265,7 +265,7 @@ int launch(const IGParams &p, const void *x, const void *w, const float *bias, v
 #endif
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)igemm_glds_kernel<TCO>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)igemm_glds_kernel<TCO, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     int Pmax, nz = 1;
@@ -275,8 +275,8 @@ int launch(const IGParams &p, const void *x, const void *w, const float *bias, v
         nz = p.sh * p.sw;
         Pmax = p.N * ((p.Hout + p.sh - 1) / p.sh) * ((p.Wout + p.sw - 1) / p.sw);
     }
-    rdfc_note_kernel("igemm_glds_kernel<%d>", TCO);
-    hipLaunchKernelGGL((igemm_glds_kernel<TCO>), dim3(cdiv(Pmax, TPX), cdiv(p.Cout, TCO), nz), dim3(NT), SMEM, st, p, (const bf16_t *)x,
+    rdfc_note_kernel("igemm_glds_kernel<%d, %d>", TCO, DT);
+    hipLaunchKernelGGL((igemm_glds_kernel<TCO, DT>), dim3(cdiv(Pmax, TPX), cdiv(p.Cout, TCO), nz), dim3(NT), SMEM, st, p, (const bf16_t *)x,
                        (const bf16_t *)w, bias, y, zero);
     return 1;
 }
@@ -287,7 +287,7 @@ int launch(const IGParams &p, const void *x, const void *w, const float *bias, v
 int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                         hipStream_t st) {
     static const int mode = getenv("RDFC_IGEMM_GLDS") ? atoi(getenv("RDFC_IGEMM_GLDS")) : 1;
-    if (!mode || d->dtype != RDFC_BF16) return 0;
+    if (!mode || !rdfc_is16(d->dtype)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     const int ld_in = transposed ? d->ldy : d->ldx;
     if (Cin % BK != 0 || ld_in % 8 != 0 || Cout < 64 || d->KH * d->KW > MAXTAPS) return 0;
@@ -302,6 +302,8 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
     IGParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, Cin, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo, Cout,
                d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw, ld_in, transposed ? d->ldx : d->ldy, transposed,
                d->act, d->slope, d->out_f32};
+    if (d->dtype == RDFC_F16)
+        return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, st);
     if (Cout > 64 || mode == 3) return launch<128>(p, in, w, bias, out, zero, st);
     return launch<64>(p, in, w, bias, out, zero, st);
 }

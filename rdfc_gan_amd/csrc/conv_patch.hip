@@ -40,16 +40,15 @@ constexpr int BK = 32;
 //         free for every starting row (brute-forced over all offsets; the padded 80-byte rows used before were a
 //         2-way conflict on every read: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).
 //   f32 (parity mode): 144-byte padded rows, no swizzle.
-template <typename T> struct Lay;
-template <> struct Lay<bf16_t> {
+template <typename T> struct Lay {          // 2-byte elements (bf16 | f16)
     static constexpr int LDK = BK;
     __device__ static int off(int row, int chunk) { return row * LDK + ((chunk ^ ((row >> 1) & 2)) << 3); }
     typedef bf16x8 frag;
     static constexpr int KSUB = 1;
-    __device__ static frag ld(const bf16_t *tile, int row, int lane, int) {
+    __device__ static frag ld(const T *tile, int row, int lane, int) {
         return *reinterpret_cast<const bf16x8 *>(tile + off(row, lane >> 4));
     }
-    __device__ static f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    __device__ static f32x4 mma(frag a, frag b, f32x4 c) { return mma16<DtOf<T>::value>(a, b, c); }
 };
 template <> struct Lay<float> {
     static constexpr int LDK = BK + 4;
@@ -234,11 +233,11 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? (NTHREADS == 512 ? 4 : 2
                     bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
                     if (vec_ok && co + 3 < p.Cout) {
                         bf16x4 o;
-                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        for (int r = 0; r < 4; ++r) o[r] = cvt16<DtOf<T>::value>(v[r]);
                         *reinterpret_cast<bf16x4 *>(y) = o;
                     } else
                         for (int r = 0; r < 4; ++r)
-                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                            if (co + r < p.Cout) y[r] = cvt16<DtOf<T>::value>(v[r]);
                 }
             }
         }
@@ -396,11 +395,11 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 2 ? (NTHREADS == 512 ? 2 : 2
                     bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
                     if (vec_ok && co + 3 < p.Cout) {
                         bf16x4 o;
-                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        for (int r = 0; r < 4; ++r) o[r] = cvt16<DtOf<T>::value>(v[r]);
                         *reinterpret_cast<bf16x4 *>(y) = o;
                     } else
                         for (int r = 0; r < 4; ++r)
-                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                            if (co + r < p.Cout) y[r] = cvt16<DtOf<T>::value>(v[r]);
                 }
             }
         }
@@ -477,6 +476,7 @@ int rdfc_try_conv3x3_patch(const rdfc_conv_desc *d, int transposed, const void *
                   Cin, Cout, transposed ? d->ldy : d->ldx, transposed ? d->ldx : d->ldy, transposed,
                   transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad, d->act, d->slope, d->out_f32, 9 * Cin, 0, 0, 0, 0};
     if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, in, w, bias, out, st);
+    else if (d->dtype == RDFC_F16) launch_T<f16_t>(p, in, w, bias, out, st);
     else launch_T<float>(p, in, w, bias, out, st);
     return 1;
 }

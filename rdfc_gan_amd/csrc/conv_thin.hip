@@ -25,11 +25,13 @@ struct ThinParams {
 
 constexpr int WAVES = 4;
 
-__device__ inline float dot2(unsigned a, unsigned b, float c) {       // c + a.lo*b.lo + a.hi*b.hi (bf16 pairs)
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+template <int DT> __device__ inline float dot2(unsigned a, unsigned b, float c) {       // c + a.lo*b.lo + a.hi*b.hi (bf16 | f16 pairs)
+    if constexpr (DT == RDFC_F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+    else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
 }
 
-template <int CO>
+template <int CO, int DT = RDFC_BF16>
 __global__ __launch_bounds__(WAVES * 64) void thin_out_kernel(ThinParams p, const bf16_t *__restrict__ in,
                                                               const bf16_t *__restrict__ w, const float *__restrict__ bias,
                                                               void *__restrict__ out) {
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(WAVES * 64) void thin_out_kernel(ThinParams p, cons
             for (int co = 0; co < CO; ++co) {
                 const u32x4 wv = wl[co * p.items_pad + item];
                 const unsigned w0 = wv.x, w1 = wv.y, w2 = wv.z, w3 = wv.w;
-                acc[co] = dot2(x0, w0, acc[co]);
-                acc[co] = dot2(x1, w1, acc[co]);
-                acc[co] = dot2(x2, w2, acc[co]);
-                acc[co] = dot2(x3, w3, acc[co]);
+                acc[co] = dot2<DT>(x0, w0, acc[co]);
+                acc[co] = dot2<DT>(x1, w1, acc[co]);
+                acc[co] = dot2<DT>(x2, w2, acc[co]);
+                acc[co] = dot2<DT>(x3, w3, acc[co]);
             }
         }
 #pragma unroll
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(WAVES * 64) void thin_out_kernel(ThinParams p, cons
             v = act_fwd(v, p.act, p.slope);
             const size_t off = (size_t)pu * p.ld_out + lane;
             if (p.out_f32) reinterpret_cast<float *>(out)[off] = v;
-            else reinterpret_cast<bf16_t *>(out)[off] = (bf16_t)v;
+            else reinterpret_cast<bf16_t *>(out)[off] = cvt16<DT>(v);
         }
     }
 }
@@ -116,7 +118,7 @@ struct TileParams {
     int tiles_x, tiles_y, PH, PW, row_bytes;
 };
 
-template <int CO, int CH>
+template <int CO, int CH, int DT = RDFC_BF16>
 __global__ __launch_bounds__(256) void thin_tile_kernel(TileParams p, const bf16_t *__restrict__ in, const bf16_t *__restrict__ w,
                                                         const float *__restrict__ bias, void *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -164,10 +166,10 @@ __global__ __launch_bounds__(256) void thin_tile_kernel(TileParams p, const bf16
 #pragma unroll
                         for (int v = 0; v < VPC; ++v) {
                             const u32x4 wv = wp[v];
-                            acc[co] = dot2(xv[v].x, wv.x, acc[co]);
-                            acc[co] = dot2(xv[v].y, wv.y, acc[co]);
-                            acc[co] = dot2(xv[v].z, wv.z, acc[co]);
-                            acc[co] = dot2(xv[v].w, wv.w, acc[co]);
+                            acc[co] = dot2<DT>(xv[v].x, wv.x, acc[co]);
+                            acc[co] = dot2<DT>(xv[v].y, wv.y, acc[co]);
+                            acc[co] = dot2<DT>(xv[v].z, wv.z, acc[co]);
+                            acc[co] = dot2<DT>(xv[v].w, wv.w, acc[co]);
                         }
                     }
                 }
@@ -184,29 +186,36 @@ __global__ __launch_bounds__(256) void thin_tile_kernel(TileParams p, const bf16
                 if (bias != nullptr) v += bias[co];
                 v = act_fwd(v, p.act, p.slope);
                 if (p.out_f32) reinterpret_cast<float *>(out)[off + co] = v;
-                else reinterpret_cast<bf16_t *>(out)[off + co] = (bf16_t)v;
+                else reinterpret_cast<bf16_t *>(out)[off + co] = cvt16<DT>(v);
             }
         }
     }
 }
 
 template <int CO, int CH>
-void launch_tile(TileParams p, const void *in, const void *w, const float *bias, void *out, hipStream_t st) {
+void launch_tile(TileParams p, const void *in, const void *w, const float *bias, void *out, hipStream_t st, int dtype) {
     constexpr int PIX = CH * 2 + 16;
     p.row_bytes = (p.PW * PIX + 255) / 256 * 256;
     const size_t smem = (size_t)p.PH * p.row_bytes;
-    rdfc_note_kernel("thin_tile_kernel<%d, %d>", CO, CH);
-    hipLaunchKernelGGL((thin_tile_kernel<CO, CH>), dim3(p.tiles_x * p.tiles_y * p.N), dim3(256), smem, st, p, (const bf16_t *)in,
-                       (const bf16_t *)w, bias, out);
+    rdfc_note_kernel("thin_tile_kernel<%d, %d, %d>", CO, CH, dtype);
+    if (dtype == RDFC_F16)
+        hipLaunchKernelGGL((thin_tile_kernel<CO, CH, RDFC_F16>), dim3(p.tiles_x * p.tiles_y * p.N), dim3(256), smem, st, p, (const bf16_t *)in,
+                           (const bf16_t *)w, bias, out);
+    else
+        hipLaunchKernelGGL((thin_tile_kernel<CO, CH, RDFC_BF16>), dim3(p.tiles_x * p.tiles_y * p.N), dim3(256), smem, st, p, (const bf16_t *)in,
+                           (const bf16_t *)w, bias, out);
 }
 
 template <int CO>
-void launch(const ThinParams &p, const void *in, const void *w, const float *bias, void *out, hipStream_t st) {
+void launch(const ThinParams &p, const void *in, const void *w, const float *bias, void *out, hipStream_t st, int dtype) {
     const size_t smem = (size_t)p.items_pad * 8 + (size_t)CO * p.items_pad * 16;
     int blocks = cdiv(p.P, WAVES);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    rdfc_note_kernel("thin_out_kernel<%d>", CO);
-    hipLaunchKernelGGL(thin_out_kernel<CO>, dim3(blocks), dim3(WAVES * 64), smem, st, p, (const bf16_t *)in, (const bf16_t *)w, bias, out);
+    rdfc_note_kernel("thin_out_kernel<%d, %d>", CO, dtype);
+    if (dtype == RDFC_F16)
+        hipLaunchKernelGGL((thin_out_kernel<CO, RDFC_F16>), dim3(blocks), dim3(WAVES * 64), smem, st, p, (const bf16_t *)in, (const bf16_t *)w, bias, out);
+    else
+        hipLaunchKernelGGL((thin_out_kernel<CO, RDFC_BF16>), dim3(blocks), dim3(WAVES * 64), smem, st, p, (const bf16_t *)in, (const bf16_t *)w, bias, out);
 }
 
 }  // namespace
@@ -215,7 +224,7 @@ void launch(const ThinParams &p, const void *in, const void *w, const float *bia
 int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                        hipStream_t st) {
     static const bool off = getenv("RDFC_NO_THIN") != nullptr;
-    if (off || d->dtype != RDFC_BF16) return 0;
+    if (off || !rdfc_is16(d->dtype)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     const int ld_in = transposed ? d->ldy : d->ldx, ld_out = transposed ? d->ldx : d->ldy;
     if (Cout > 4 || Cin % 8 != 0 || ld_in % 8 != 0) return 0;
@@ -264,17 +273,17 @@ int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, 
         t.PH = 16 + d->KH - 1; t.PW = 16 + d->KW - 1; t.row_bytes = 0;
         const bool c32 = Cin % 32 == 0;
         if ((size_t)t.PH * ((t.PW * (c32 ? 80 : 48) + 255) / 256 * 256) <= 64 * 1024) {
-            if (co_t == 1) c32 ? launch_tile<1, 32>(t, in, w, bias, out, st) : launch_tile<1, 16>(t, in, w, bias, out, st);
-            else if (co_t == 2) c32 ? launch_tile<2, 32>(t, in, w, bias, out, st) : launch_tile<2, 16>(t, in, w, bias, out, st);
-            else c32 ? launch_tile<4, 32>(t, in, w, bias, out, st) : launch_tile<4, 16>(t, in, w, bias, out, st);
+            if (co_t == 1) c32 ? launch_tile<1, 32>(t, in, w, bias, out, st, d->dtype) : launch_tile<1, 16>(t, in, w, bias, out, st, d->dtype);
+            else if (co_t == 2) c32 ? launch_tile<2, 32>(t, in, w, bias, out, st, d->dtype) : launch_tile<2, 16>(t, in, w, bias, out, st, d->dtype);
+            else c32 ? launch_tile<4, 32>(t, in, w, bias, out, st, d->dtype) : launch_tile<4, 16>(t, in, w, bias, out, st, d->dtype);
             return 1;
         }
     }
     if ((size_t)p.items_pad * 8 + (size_t)co_t * p.items_pad * 16 > 64 * 1024) return 0;
     // one wave per pixel only pays on small maps (grid of the MFMA kernels too small); larger ones stay on MFMA
     if (p.P >= tile_min) return 0;
-    if (co_t == 1) launch<1>(p, in, w, bias, out, st);
-    else if (co_t == 2) launch<2>(p, in, w, bias, out, st);
-    else launch<4>(p, in, w, bias, out, st);
+    if (co_t == 1) launch<1>(p, in, w, bias, out, st, d->dtype);
+    else if (co_t == 2) launch<2>(p, in, w, bias, out, st, d->dtype);
+    else launch<4>(p, in, w, bias, out, st, d->dtype);
     return 1;
 }

@@ -26,7 +26,7 @@ struct TIParams {
     float slope;
 };
 
-template <int MF>   // output-channel fragments per wave: Cout <= 16 * MF
+template <int MF, int DT = RDFC_BF16>   // output-channel fragments per wave: Cout <= 16 * MF
 __global__ __launch_bounds__(256) void thin_in_kernel(TIParams p, const bf16_t *__restrict__ t, const bf16_t *__restrict__ w,
                                                       const float *__restrict__ bias, void *__restrict__ yout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(TIParams p, const bf16_t *
                     for (int e = 0; e < 8; ++e) bvv[e] = (short)Tl[pbase[j] + koff[ks][e]];
                     const bf16x8 b = __builtin_bit_cast(bf16x8, bvv);
 #pragma unroll
-                    for (int i = 0; i < MF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MF; ++i) acc[i][j] = mma16<DT>(a[i], b, acc[i][j]);
                 }
             }
         }
@@ -145,11 +145,11 @@ __global__ __launch_bounds__(256) void thin_in_kernel(TIParams p, const bf16_t *
                     bf16_t *y = reinterpret_cast<bf16_t *>(yout) + po + co;
                     if ((p.ld_out & 3) == 0 && co + 3 < p.Cout) {
                         bf16x4 o;
-                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        for (int r = 0; r < 4; ++r) o[r] = cvt16<DT>(v[r]);
                         *reinterpret_cast<bf16x4 *>(y) = o;
                     } else
                         for (int r = 0; r < 4; ++r)
-                            if (co + r < p.Cout) y[r] = (bf16_t)v[r];
+                            if (co + r < p.Cout) y[r] = cvt16<DT>(v[r]);
                 }
             }
         }
@@ -157,13 +157,14 @@ __global__ __launch_bounds__(256) void thin_in_kernel(TIParams p, const bf16_t *
 }
 
 template <int MF>
-int launch(const TIParams &p, const void *t, const void *w, const float *bias, void *y, hipStream_t st) {
+int launch(const TIParams &p, const void *t, const void *w, const float *bias, void *y, hipStream_t st, int dtype) {
     const int KP = p.KS * 32, WLD = KP + 8;
     const size_t smem = (size_t)16 * MF * WLD * 2 + ((size_t)p.PH * p.PW * p.ct + 8) * 2;
     if (smem > 64 * 1024) return 0;
     int blocks = p.ntiles < 1024 ? p.ntiles : 1024;
-    rdfc_note_kernel("thin_in_kernel<%d>", MF);
-    hipLaunchKernelGGL((thin_in_kernel<MF>), dim3(blocks), dim3(256), smem, st, p, (const bf16_t *)t, (const bf16_t *)w, bias, y);
+    rdfc_note_kernel("thin_in_kernel<%d, %d>", MF, dtype);
+    if (dtype == RDFC_F16) hipLaunchKernelGGL((thin_in_kernel<MF, RDFC_F16>), dim3(blocks), dim3(256), smem, st, p, (const bf16_t *)t, (const bf16_t *)w, bias, y);
+    else hipLaunchKernelGGL((thin_in_kernel<MF, RDFC_BF16>), dim3(blocks), dim3(256), smem, st, p, (const bf16_t *)t, (const bf16_t *)w, bias, y);
     return 1;
 }
 
@@ -173,7 +174,7 @@ int launch(const TIParams &p, const void *t, const void *w, const float *bias, v
 int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st) {
     static const bool off = getenv("RDFC_NO_THIN_IN") != nullptr;
-    if (off || d->dtype != RDFC_BF16) return 0;
+    if (off || !rdfc_is16(d->dtype)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     if (Cin > 4 || Cout < 16 || Cout > 128) return 0;
     if (d->act == RDFC_ACT_TANH || d->act == RDFC_ACT_SIGMOID) return 0;
@@ -212,10 +213,10 @@ int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *i
     p.act = d->act;
     p.out_f32 = d->out_f32;
     p.slope = d->slope;
-    if (Cout <= 16) return launch<1>(p, in, w, bias, out, st);
-    if (Cout <= 32) return launch<2>(p, in, w, bias, out, st);
-    if (Cout <= 48) return launch<3>(p, in, w, bias, out, st);
-    if (Cout <= 64) return launch<4>(p, in, w, bias, out, st);
-    if (Cout <= 96) return launch<6>(p, in, w, bias, out, st);
-    return launch<8>(p, in, w, bias, out, st);
+    if (Cout <= 16) return launch<1>(p, in, w, bias, out, st, d->dtype);
+    if (Cout <= 32) return launch<2>(p, in, w, bias, out, st, d->dtype);
+    if (Cout <= 48) return launch<3>(p, in, w, bias, out, st, d->dtype);
+    if (Cout <= 64) return launch<4>(p, in, w, bias, out, st, d->dtype);
+    if (Cout <= 96) return launch<6>(p, in, w, bias, out, st, d->dtype);
+    return launch<8>(p, in, w, bias, out, st, d->dtype);
 }

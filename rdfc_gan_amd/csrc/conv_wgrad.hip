@@ -37,11 +37,11 @@ __device__ inline bf16x8 tr_frag(const bf16_t *img, int ld, int cbase, int lane)
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <typename T> struct WMma;
-template <> struct WMma<bf16_t> {
+template <typename T> struct WMma {       // 2-byte elements (bf16 | f16)
     template <int MT, int NT>
-    __device__ static void step(const bf16_t *Ys, const bf16_t *Xs, int ldy, int ldx, int arow, int bcol, int lane,
+    __device__ static void step(const T *Ys_, const T *Xs_, int ldy, int ldx, int arow, int bcol, int lane,
                                 f32x4 (&acc)[MT][NT]) {
+        const bf16_t *Ys = reinterpret_cast<const bf16_t *>(Ys_), *Xs = reinterpret_cast<const bf16_t *>(Xs_);
         bf16x8 a[MT], b[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) a[i] = tr_frag(Ys, ldy, arow + 16 * i, lane);
@@ -50,7 +50,7 @@ template <> struct WMma<bf16_t> {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) acc[i][j] = mma16<DtOf<T>::value>(a[i], b[j], acc[i][j]);
     }
 };
 template <> struct WMma<float> {
@@ -258,7 +258,7 @@ int rdfc_try_wgrad_thin(const rdfc_conv_desc *d, const void *x, const void *dy, 
 
 extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream) {
     RDFC_REQUIRE(d != nullptr, "rdfc_conv2d_wgrad: null descriptor");
-    RDFC_REQUIRE(d->dtype == RDFC_F32 || d->dtype == RDFC_BF16, "rdfc_conv2d_wgrad: bad dtype %d", d->dtype);
+    RDFC_REQUIRE(rdfc_dtype_ok(d->dtype), "rdfc_conv2d_wgrad: bad dtype %d", d->dtype);
     RDFC_REQUIRE(d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->Ci > 0 && d->Ho > 0 && d->Wo > 0 && d->Co > 0,
                  "rdfc_conv2d_wgrad: non-positive dimension");
     RDFC_REQUIRE(d->ldx >= d->Ci && d->ldy >= d->Co, "rdfc_conv2d_wgrad: ld smaller than channel count");
@@ -274,6 +274,7 @@ extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const v
     } else if (rdfc_try_wgrad_gather_glds(d, x, dy, dw_packed, st)) {
     } else if (w9 && rdfc_try_wgrad9(d, x, dy, dw_packed, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, x, dy, dw_packed, st);
+    else if (d->dtype == RDFC_F16) launch_T<f16_t>(p, x, dy, dw_packed, st);
     else launch_T<float>(p, x, dy, dw_packed, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_wgrad");
     return 0;

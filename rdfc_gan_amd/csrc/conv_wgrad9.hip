@@ -36,12 +36,13 @@ __device__ inline bf16x8 tr_frag(const bf16_t *img, int ld, int row0, int cbase,
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <typename T> struct F9;
-template <> struct F9<bf16_t> {
+template <typename T> struct F9 {           // 2-byte elements (bf16 | f16)
     typedef bf16x8 frag;
     static constexpr int KSUB = 1;
-    __device__ static frag ld(const bf16_t *img, int ld_, int row0, int cbase, int lane, int) { return tr_frag(img, ld_, row0, cbase, lane); }
-    __device__ static f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    __device__ static frag ld(const T *img, int ld_, int row0, int cbase, int lane, int) {
+        return tr_frag(reinterpret_cast<const bf16_t *>(img), ld_, row0, cbase, lane);
+    }
+    __device__ static f32x4 mma(frag a, frag b, f32x4 c) { return mma16<DtOf<T>::value>(a, b, c); }
 };
 template <> struct F9<float> {
     typedef float frag;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NTH, sizeof(T) == 2 ? 2 : 1) void wgrad9_kernel(W9P
 int rdfc_try_wgrad9(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st) {
     if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return 0;
     if (d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
-    const int vec = d->dtype == RDFC_BF16 ? 8 : 4;
+    const int vec = rdfc_vec(d->dtype);
     if (d->Co % vec || d->Ci % vec || d->ldx % vec || d->ldy % vec || d->Co < 32 || d->Ci < 32) return 0;
     // measured (tools/ab_env2.sh, one device): +8..45 % over the per-tap kernel's 64x64 tile on the full-resolution
     // 64/32-channel layers; the per-tap 128x128 8-wave tile stays faster for >= 128 x >= 128 channels
@@ -201,8 +202,9 @@ int rdfc_try_wgrad9(const rdfc_conv_desc *d, const void *x, const void *dy, floa
     p.segs_per_slice = cdiv(p.total_segs, slices);
     slices = cdiv(p.total_segs, p.segs_per_slice);
     dim3 grid(slices, tiles);
-    rdfc_note_kernel("wgrad9_kernel<%s>", d->dtype == RDFC_BF16 ? "__bf16" : "float");
+    rdfc_note_kernel("wgrad9_kernel<%s>", d->dtype == RDFC_BF16 ? "__bf16" : (d->dtype == RDFC_F16 ? "_Float16" : "float"));
     if (d->dtype == RDFC_BF16) hipLaunchKernelGGL(wgrad9_kernel<bf16_t>, grid, dim3(NTH), 0, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw);
+    else if (d->dtype == RDFC_F16) hipLaunchKernelGGL(wgrad9_kernel<f16_t>, grid, dim3(NTH), 0, st, p, (const f16_t *)x, (const f16_t *)dy, dw);
     else hipLaunchKernelGGL(wgrad9_kernel<float>, grid, dim3(NTH), 0, st, p, (const float *)x, (const float *)dy, dw);
     return 1;
 }

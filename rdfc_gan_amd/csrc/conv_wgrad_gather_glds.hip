@@ -53,7 +53,7 @@ template <int ROWB> __device__ inline bf16x8 tr_frag(const unsigned char *img, i
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int TCO, int KWT>   // KWT = taps per kernel row (1, 3 or 4)
+template <int TCO, int KWT, int DT = RDFC_BF16>   // KWT = taps per kernel row (1, 3 or 4)
 __global__ __launch_bounds__(NT, 2) void wgrad_gather_glds_kernel(WGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                                   float *__restrict__ dw, const bf16_t *__restrict__ zero) {
     constexpr int TCI = 64;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gather_glds_kernel(WGParams p, co
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTF; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
+                for (int j = 0; j < NTF; ++j) acc[t][i][j] = mma16<DT>(a[i], b[j], acc[t][i][j]);
         }
     }
     wait_vm<0>();
@@ -181,12 +181,12 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO, int KWT>
+template <int TCO, int KWT, int DT = RDFC_BF16>
 int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
     constexpr int SMEM = (KWT == 4 ? 3 : 4) * (SEG * TCO * 2 + KWT * SEG * 128);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wgrad_gather_glds_kernel<TCO, KWT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)wgrad_gather_glds_kernel<TCO, KWT, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     p.tiles_ci = cdiv(p.Ci, 64);
@@ -199,17 +199,17 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     if (slices < 1) slices = 1;
     p.segs_per_slice = cdiv(p.total_segs, slices);
     slices = cdiv(p.total_segs, p.segs_per_slice);
-    rdfc_note_kernel("wgrad_gather_glds_kernel<%d, %d>", TCO, KWT);
-    hipLaunchKernelGGL((wgrad_gather_glds_kernel<TCO, KWT>), dim3(slices, tiles), dim3(NT), SMEM, st, p, (const bf16_t *)x,
+    rdfc_note_kernel("wgrad_gather_glds_kernel<%d, %d, %d>", TCO, KWT, DT);
+    hipLaunchKernelGGL((wgrad_gather_glds_kernel<TCO, KWT, DT>), dim3(slices, tiles), dim3(NT), SMEM, st, p, (const bf16_t *)x,
                        (const bf16_t *)dy, dw, zero);
     return 1;
 }
 
-template <int TCO>
+template <int TCO, int DT = RDFC_BF16>
 int launch_kw(const WGParams &p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
-    if (p.KW == 1) return launch<TCO, 1>(p, x, dy, dw, zero, st);
-    if (p.KW == 3) return launch<TCO, 3>(p, x, dy, dw, zero, st);
-    if (p.KW == 4) return launch<TCO, 4>(p, x, dy, dw, zero, st);
+    if (p.KW == 1) return launch<TCO, 1, DT>(p, x, dy, dw, zero, st);
+    if (p.KW == 3) return launch<TCO, 3, DT>(p, x, dy, dw, zero, st);
+    if (p.KW == 4) return launch<TCO, 4, DT>(p, x, dy, dw, zero, st);
     return 0;
 }
 
@@ -218,7 +218,7 @@ int launch_kw(const WGParams &p, const void *x, const void *dy, float *dw, const
 // Called by rdfc_conv2d_wgrad (conv_wgrad.hip) after the stride-1 3x3 kernel; returns 1 if it took the launch.
 int rdfc_try_wgrad_gather_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st) {
     static const int mode = getenv("RDFC_WGRAD_GATHER_GLDS") ? atoi(getenv("RDFC_WGRAD_GATHER_GLDS")) : 1;
-    if (!mode || d->dtype != RDFC_BF16) return 0;
+    if (!mode || !rdfc_is16(d->dtype)) return 0;
     if (d->sh != d->sw || d->dh != d->dw || d->ph != d->pw || d->KH != d->KW) return 0;
     if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8) return 0;
     const int spr = cdiv(d->Wo, SEG);
@@ -231,6 +231,6 @@ int rdfc_try_wgrad_gather_glds(const rdfc_conv_desc *d, const void *x, const voi
     if (zero == nullptr) return 0;
     WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->KH, d->KW, d->sh, d->ph, d->dh, d->ldx, d->ldy, spr,
                d->N * d->Ho * spr, 0, 0};
-    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return launch_kw<128>(p, x, dy, dw, zero, st);
-    return launch_kw<64>(p, x, dy, dw, zero, st);
+    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return d->dtype == RDFC_F16 ? launch_kw<128, RDFC_F16>(p, x, dy, dw, zero, st) : launch_kw<128>(p, x, dy, dw, zero, st);
+    return d->dtype == RDFC_F16 ? launch_kw<64, RDFC_F16>(p, x, dy, dw, zero, st) : launch_kw<64>(p, x, dy, dw, zero, st);
 }

@@ -62,7 +62,7 @@ template <int ROWB> __device__ inline bf16x8 tr_frag(const unsigned char *img, i
 #endif
 constexpr int WG_RING = RDFC_WGRAD_GLDS_RING;
 
-template <int TCO, int NKY>   // NKY = 1: one kernel row (3 taps) per workgroup; NKY = 3: all nine taps (64 x 64 tiles only)
+template <int TCO, int NKY, int DT = RDFC_BF16>   // NKY = 1: one kernel row (3 taps) per workgroup; NKY = 3: all nine taps (64 x 64 tiles only)
 __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                            float *__restrict__ dw, const bf16_t *__restrict__ zero) {
     constexpr int TCI = 64;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf1
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTF; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
+                for (int j = 0; j < NTF; ++j) acc[t][i][j] = mma16<DT>(a[i], b[j], acc[t][i][j]);
         }
     }
     wait_vm<0>();
@@ -207,12 +207,12 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO, int NKY>
+template <int TCO, int NKY, int DT = RDFC_BF16>
 int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
     constexpr int SMEM = WG_RING * (SEG * TCO * 2 + ((NKY * XPX * 8 + NT - 1) / NT) * NT * 16);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wgrad_glds_kernel<TCO, NKY>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)wgrad_glds_kernel<TCO, NKY, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     p.tiles_ci = cdiv(p.Ci, 64);
@@ -232,7 +232,7 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     if (slices < 1) slices = 1;
     p.segs_per_slice = cdiv(p.total_segs, slices);
     slices = cdiv(p.total_segs, p.segs_per_slice);
-    rdfc_note_kernel("wgrad_glds_kernel<%d, %d>", TCO, NKY);
+    rdfc_note_kernel("wgrad_glds_kernel<%d, %d, %d>", TCO, NKY, DT);
     static const bool xcd_group = !(getenv("RDFC_WGRAD_XCD") && atoi(getenv("RDFC_WGRAD_XCD")) == 0);
     p.tiles = tiles;
     // measured (tools/wgrad_xcd_ab.sh): 64->64 @ 228x304 (3 tiles) 95 -> 89 us; with 12-24 tiles per slice the slice count
@@ -240,7 +240,7 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     // shows the re-reads (3x on the 64-channel layers) either way; the Infinity Cache serves them at full rate.
     p.xcd_group = xcd_group && tiles <= 3 && slices >= 8;
     const dim3 grid = p.xcd_group ? dim3(cdiv(slices, 8) * 8 * tiles, 1) : dim3(slices, tiles);
-    hipLaunchKernelGGL((wgrad_glds_kernel<TCO, NKY>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw, zero);
+    hipLaunchKernelGGL((wgrad_glds_kernel<TCO, NKY, DT>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw, zero);
     return 1;
 }
 
@@ -249,7 +249,7 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
 // Called by rdfc_conv2d_wgrad (conv_wgrad.hip) before the register-staged kernels; returns 1 if it took the launch.
 int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st) {
     static const int mode = getenv("RDFC_WGRAD_GLDS") ? atoi(getenv("RDFC_WGRAD_GLDS")) : 1;
-    if (!mode || d->dtype != RDFC_BF16) return 0;
+    if (!mode || !rdfc_is16(d->dtype)) return 0;
     if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return 0;
     if (d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
     if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8) return 0;
@@ -259,11 +259,11 @@ int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, 
     if (zero == nullptr) return 0;
     WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0};
     // 128-co tiles from 256 output channels up; below that the 64-co tile's larger grid wins (128->128: 82 vs 92 us)
-    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return launch<128, 1>(p, x, dy, dw, zero, st);
+    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return d->dtype == RDFC_F16 ? launch<128, 1, RDFC_F16>(p, x, dy, dw, zero, st) : launch<128, 1>(p, x, dy, dw, zero, st);
     // all nine taps per workgroup (dY and X staged once instead of once per kernel row): measured SLOWER on the
     // full-resolution 64-channel layers (120 vs 97 us: 36 MFMAs against 40 transposing reads per k-step, 244 VGPRs), so
     // L2 traffic is not what bounds them; kept behind RDFC_WGRAD_GLDS_NINE=1 for A/B runs
     static const int nine = getenv("RDFC_WGRAD_GLDS_NINE") ? atoi(getenv("RDFC_WGRAD_GLDS_NINE")) : 0;
-    if (nine && d->Co * d->Ci <= 128 * 64) return launch<64, 3>(p, x, dy, dw, zero, st);
-    return launch<64, 1>(p, x, dy, dw, zero, st);
+    if (nine && d->Co * d->Ci <= 128 * 64) return d->dtype == RDFC_F16 ? launch<64, 3, RDFC_F16>(p, x, dy, dw, zero, st) : launch<64, 3>(p, x, dy, dw, zero, st);
+    return d->dtype == RDFC_F16 ? launch<64, 1, RDFC_F16>(p, x, dy, dw, zero, st) : launch<64, 1>(p, x, dy, dw, zero, st);
 }

@@ -42,7 +42,7 @@ __device__ inline bf16x8 tr_frag(const bf16_t *img, int ld, int cbase, int lane)
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int MF, int NF>
+template <int MF, int NF, int DT = RDFC_BF16>
 __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWParams p, const bf16_t *__restrict__ wide,
                                                          const bf16_t *__restrict__ thin, float *__restrict__ dw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWParams p, const bf
             for (int j = 0; j < 8; ++j) av[j] = (short)Tl[abase[f] + j * p.ct];
             const bf16x8 a = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
-            for (int n = 0; n < NF; ++n) acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[n], acc[f][n], 0, 0, 0);
+            for (int n = 0; n < NF; ++n) acc[f][n] = mma16<DT>(a, b[n], acc[f][n]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWParams p, const bf
 }
 
 template <int MF, int NF>
-void launch(ThinWParams p, int groups, const void *wide, const void *thin, float *dw, hipStream_t st) {
+void launch(ThinWParams p, int groups, const void *wide, const void *thin, float *dw, hipStream_t st, int dtype) {
     constexpr int CW = 16 * NF, LDW = CW + 8;
     p.wave_lds = (SEG * LDW * 2 + (p.KH * p.trow + SEG * p.ct + 8) * 2 + 15) / 16 * 16;
     size_t smem = (size_t)4 * p.wave_lds;
@@ -199,18 +199,22 @@ void launch(ThinWParams p, int groups, const void *wide, const void *thin, float
     const int cap = (int)(24.0e6 / ((double)p.M * CW * 4.0 * groups));
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    rdfc_note_kernel("wgrad_thin_kernel<%d, %d>", MF, NF);
-    hipLaunchKernelGGL((wgrad_thin_kernel<MF, NF>), dim3(blocks, groups), dim3(256), smem, st, p, (const bf16_t *)wide,
-                       (const bf16_t *)thin, dw);
+    rdfc_note_kernel("wgrad_thin_kernel<%d, %d, %d>", MF, NF, dtype);
+    if (dtype == RDFC_F16)
+        hipLaunchKernelGGL((wgrad_thin_kernel<MF, NF, RDFC_F16>), dim3(blocks, groups), dim3(256), smem, st, p, (const bf16_t *)wide,
+                           (const bf16_t *)thin, dw);
+    else
+        hipLaunchKernelGGL((wgrad_thin_kernel<MF, NF, RDFC_BF16>), dim3(blocks, groups), dim3(256), smem, st, p, (const bf16_t *)wide,
+                           (const bf16_t *)thin, dw);
 }
 
 template <int MF>
-void launch_M(const ThinWParams &p, int nfrag, const void *wide, const void *thin, float *dw, hipStream_t st) {
+void launch_M(const ThinWParams &p, int nfrag, const void *wide, const void *thin, float *dw, hipStream_t st, int dtype) {
     // wide channels in groups of <= 64 (grid.y); each group re-reads T (tiny) and its own slice of W
-    if (nfrag % 4 == 0) launch<MF, 4>(p, nfrag / 4, wide, thin, dw, st);
-    else if (nfrag % 3 == 0) launch<MF, 3>(p, nfrag / 3, wide, thin, dw, st);
-    else if (nfrag % 2 == 0) launch<MF, 2>(p, nfrag / 2, wide, thin, dw, st);
-    else launch<MF, 1>(p, nfrag, wide, thin, dw, st);
+    if (nfrag % 4 == 0) launch<MF, 4>(p, nfrag / 4, wide, thin, dw, st, dtype);
+    else if (nfrag % 3 == 0) launch<MF, 3>(p, nfrag / 3, wide, thin, dw, st, dtype);
+    else if (nfrag % 2 == 0) launch<MF, 2>(p, nfrag / 2, wide, thin, dw, st, dtype);
+    else launch<MF, 1>(p, nfrag, wide, thin, dw, st, dtype);
 }
 
 }  // namespace
@@ -218,7 +222,7 @@ void launch_M(const ThinWParams &p, int nfrag, const void *wide, const void *thi
 // Called by rdfc_conv2d_wgrad (conv_wgrad.hip) before the MFMA tile kernels; returns 1 if it took the launch.
 int rdfc_try_wgrad_thin(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st) {
     static const bool off = getenv("RDFC_NO_WGRAD_THIN") != nullptr;
-    if (off || d->dtype != RDFC_BF16) return 0;
+    if (off || !rdfc_is16(d->dtype)) return 0;
     if (d->sh != 1 || d->sw != 1 || d->dh != 1 || d->dw != 1) return 0;
     const bool thin_x = d->Ci <= 4 && d->Co % 16 == 0 && d->ldy % 8 == 0 && d->Co <= 128;
     const bool thin_y = !thin_x && d->Co <= 4 && d->Ci % 16 == 0 && d->ldx % 8 == 0 && d->Ci <= 128;
@@ -246,9 +250,9 @@ int rdfc_try_wgrad_thin(const rdfc_conv_desc *d, const void *x, const void *dy, 
     if (p.units < 512) return 0;                            // small maps: the tile kernels' grid is fine there
     p.wave_lds = 0;
     const int nfrag = p.Ctot / 16;
-    if (p.M <= 16) launch_M<1>(p, nfrag, thin_x ? dy : x, thin_x ? x : dy, dw, st);
-    else if (p.M <= 32) launch_M<2>(p, nfrag, thin_x ? dy : x, thin_x ? x : dy, dw, st);
-    else if (p.M <= 64) launch_M<4>(p, nfrag, thin_x ? dy : x, thin_x ? x : dy, dw, st);
-    else launch_M<10>(p, nfrag, thin_x ? dy : x, thin_x ? x : dy, dw, st);
+    if (p.M <= 16) launch_M<1>(p, nfrag, thin_x ? dy : x, thin_x ? x : dy, dw, st, d->dtype);
+    else if (p.M <= 32) launch_M<2>(p, nfrag, thin_x ? dy : x, thin_x ? x : dy, dw, st, d->dtype);
+    else if (p.M <= 64) launch_M<4>(p, nfrag, thin_x ? dy : x, thin_x ? x : dy, dw, st, d->dtype);
+    else launch_M<10>(p, nfrag, thin_x ? dy : x, thin_x ? x : dy, dw, st, d->dtype);
     return 1;
 }

@@ -559,13 +559,11 @@ __global__ __launch_bounds__(NT) void normal_losses_bwd_kernel(const float *__re
     }
 }
 
-#define DISPATCH(dtype, ...)                                      \
-    if ((dtype) == RDFC_BF16) { using T = bf16_t; __VA_ARGS__; } \
-    else { using T = float; __VA_ARGS__; }
-#define CHECK_DTYPE(who, dtype) RDFC_REQUIRE((dtype) == RDFC_F32 || (dtype) == RDFC_BF16, "%s: bad dtype %d", who, dtype)
+#define DISPATCH(dtype, ...) RDFC_DISPATCH(dtype, __VA_ARGS__)
+#define CHECK_DTYPE(who, dtype) RDFC_REQUIRE(rdfc_dtype_ok(dtype), "%s: bad dtype %d", who, dtype)
 #define CHECK_VEC(who, dtype, C, ...)                                                                                     \
     {                                                                                                                     \
-        const int vec_ = (dtype) == RDFC_BF16 ? 8 : 4;                                                                    \
+        const int vec_ = rdfc_vec(dtype);                                                                                  \
         RDFC_REQUIRE((C) > 0 && (C) % vec_ == 0, "%s: C = %d must be a positive multiple of %d", who, C, vec_);            \
         for (int l_ : {__VA_ARGS__}) RDFC_REQUIRE(l_ >= (C) && l_ % vec_ == 0, "%s: bad leading dimension %d", who, l_); \
     }
@@ -579,7 +577,7 @@ extern "C" int rdfc_maxpool2d_forward(const void *x, void *y, uint8_t *idx, int 
     RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && k > 0 && k * k < 255 && s > 0 && p >= 0 && 2 * p <= k, "rdfc_maxpool2d_forward: bad geometry");
     RDFC_REQUIRE(Ho == (Hi + 2 * p - k) / s + 1 && Wo == (Wi + 2 * p - k) / s + 1, "rdfc_maxpool2d_forward: output %dx%d does not match", Ho, Wo);
     RDFC_REQUIRE(x && y && idx, "rdfc_maxpool2d_forward: null pointer");
-    const size_t total = (size_t)N * Ho * Wo * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    const size_t total = (size_t)N * Ho * Wo * (C / (rdfc_vec(dtype)));
     DISPATCH(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)x, (T *)y, idx, N,
                                        Hi, Wi, C, ldx, ldy, k, s, p, Ho, Wo));
     RDFC_LAUNCH_CHECK("rdfc_maxpool2d_forward");
@@ -592,7 +590,7 @@ extern "C" int rdfc_maxpool2d_backward(const void *dy, const uint8_t *idx, void 
     CHECK_VEC("rdfc_maxpool2d_backward", dtype, C, lddy, lddx);
     RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && k > 0 && k * k < 255 && s > 0 && p >= 0, "rdfc_maxpool2d_backward: bad geometry");
     RDFC_REQUIRE(dy && dx && idx, "rdfc_maxpool2d_backward: null pointer");
-    const size_t total = (size_t)N * Hi * Wi * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    const size_t total = (size_t)N * Hi * Wi * (C / (rdfc_vec(dtype)));
     DISPATCH(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)dy, idx, (T *)dx,
                                        N, Hi, Wi, C, lddy, lddx, k, s, p, Ho, Wo));
     RDFC_LAUNCH_CHECK("rdfc_maxpool2d_backward");
@@ -604,7 +602,7 @@ extern "C" int rdfc_adaptive_avgpool_forward(const void *x, void *y, int N, int 
     CHECK_DTYPE("rdfc_adaptive_avgpool_forward", dtype);
     CHECK_VEC("rdfc_adaptive_avgpool_forward", dtype, C, ldx, ldy);
     RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && x && y, "rdfc_adaptive_avgpool_forward: bad arguments");
-    const size_t total = (size_t)N * Ho * Wo * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    const size_t total = (size_t)N * Ho * Wo * (C / (rdfc_vec(dtype)));
     if ((Hi / Ho) * (Wi / Wo) >= 64) {         // wave per output vector
         DISPATCH(dtype, hipLaunchKernelGGL(avgpool_fwd_wave_kernel<T>, dim3(nblk(total * 64)), dim3(NT), 0, (hipStream_t)stream, (const T *)x,
                                            (T *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo));
@@ -621,7 +619,7 @@ extern "C" int rdfc_adaptive_avgpool_backward(const void *dy, void *dx, int N, i
     CHECK_DTYPE("rdfc_adaptive_avgpool_backward", dtype);
     CHECK_VEC("rdfc_adaptive_avgpool_backward", dtype, C, lddy, lddx);
     RDFC_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && dy && dx, "rdfc_adaptive_avgpool_backward: bad arguments");
-    const size_t total = (size_t)N * Hi * Wi * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    const size_t total = (size_t)N * Hi * Wi * (C / (rdfc_vec(dtype)));
     DISPATCH(dtype, hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)dy, (T *)dx, N, Hi,
                                        Wi, C, lddy, lddx, Ho, Wo));
     RDFC_LAUNCH_CHECK("rdfc_adaptive_avgpool_backward");
@@ -639,6 +637,10 @@ extern "C" int rdfc_bilinear_forward(const void *x, void *y, int N, int Hi, int 
         hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t *)x, (float *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo);
     else if (dtype == RDFC_BF16)
         hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t *)x, (bf16_t *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo);
+    else if (dtype == RDFC_F16 && out_f32)
+        hipLaunchKernelGGL((bilinear_fwd_kernel<f16_t, float>), g, b, 0, st, (const f16_t *)x, (float *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo);
+    else if (dtype == RDFC_F16)
+        hipLaunchKernelGGL((bilinear_fwd_kernel<f16_t, f16_t>), g, b, 0, st, (const f16_t *)x, (f16_t *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo);
     else
         hipLaunchKernelGGL((bilinear_fwd_kernel<float, float>), g, b, 0, st, (const float *)x, (float *)y, N, Hi, Wi, C, ldx, ldy, Ho, Wo);
     RDFC_LAUNCH_CHECK("rdfc_bilinear_forward");
@@ -652,7 +654,7 @@ extern "C" int rdfc_bilinear_backward(const void *dy, void *dx, int N, int Hi, i
     const size_t total = (size_t)N * Hi * Wi * C;
     const dim3 g(nblk(total)), b(NT);
     hipStream_t st = (hipStream_t)stream;
-    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    const int vec = rdfc_vec(dtype);
     if (!dy_f32 && C % vec == 0 && lddy % vec == 0 && lddx % vec == 0 && (Ho / Hi) * (Wo / Wi) >= 16) {      // wave per source vector
         const dim3 gw(nblk(total / vec * 64));
         DISPATCH(dtype, hipLaunchKernelGGL(bilinear_bwd_wave_kernel<T>, gw, b, 0, st, (const T *)dy, (T *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo));
@@ -663,6 +665,10 @@ extern "C" int rdfc_bilinear_backward(const void *dy, void *dx, int N, int Hi, i
         hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, float>), g, b, 0, st, (const float *)dy, (bf16_t *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo);
     else if (dtype == RDFC_BF16)
         hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t *)dy, (bf16_t *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo);
+    else if (dtype == RDFC_F16 && dy_f32)
+        hipLaunchKernelGGL((bilinear_bwd_kernel<f16_t, float>), g, b, 0, st, (const float *)dy, (f16_t *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo);
+    else if (dtype == RDFC_F16)
+        hipLaunchKernelGGL((bilinear_bwd_kernel<f16_t, f16_t>), g, b, 0, st, (const f16_t *)dy, (f16_t *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo);
     else
         hipLaunchKernelGGL((bilinear_bwd_kernel<float, float>), g, b, 0, st, (const float *)dy, (float *)dx, N, Hi, Wi, C, lddy, lddx, Ho, Wo);
     RDFC_LAUNCH_CHECK("rdfc_bilinear_backward");
@@ -673,7 +679,7 @@ extern "C" int rdfc_scale_nc(const void *x, const float *scale, void *y, int N, 
     CHECK_DTYPE("rdfc_scale_nc", dtype);
     CHECK_VEC("rdfc_scale_nc", dtype, C, ldx, ldy);
     RDFC_REQUIRE(N > 0 && HW > 0 && x && y && scale, "rdfc_scale_nc: bad arguments");
-    const size_t total = (size_t)N * HW * (C / (dtype == RDFC_BF16 ? 8 : 4));
+    const size_t total = (size_t)N * HW * (C / (rdfc_vec(dtype)));
     DISPATCH(dtype, hipLaunchKernelGGL(scale_nc_kernel<T>, dim3(nblk(total)), dim3(NT), 0, (hipStream_t)stream, (const T *)x, scale, (T *)y, N, HW,
                                        C, ldx, ldy));
     RDFC_LAUNCH_CHECK("rdfc_scale_nc");

@@ -648,8 +648,8 @@ __global__ void act_bwd_kernel(size_t total, int C, int lddy, int ldy, int lddx,
 }
 
 int check_map(const char *who, int G, int P, int C, int dtype, std::initializer_list<int> lds) {
-    RDFC_REQUIRE(dtype == RDFC_F32 || dtype == RDFC_BF16, "%s: bad dtype %d", who, dtype);
-    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    RDFC_REQUIRE(rdfc_dtype_ok(dtype), "%s: bad dtype %d", who, dtype);
+    const int vec = rdfc_vec(dtype);
     RDFC_REQUIRE(G > 0 && P > 0 && C > 0, "%s: non-positive size", who);
     RDFC_REQUIRE(C % vec == 0, "%s: C=%d must be a multiple of %d", who, C, vec);
     for (int ld : lds) RDFC_REQUIRE(ld >= C && ld % vec == 0, "%s: ld=%d must be >= C and a multiple of %d", who, ld, vec);
@@ -658,17 +658,15 @@ int check_map(const char *who, int G, int P, int C, int dtype, std::initializer_
 
 }  // namespace
 
-#define DISPATCH(dtype, ...)                          \
-    if ((dtype) == RDFC_BF16) { using T = bf16_t; __VA_ARGS__; } \
-    else { using T = float; __VA_ARGS__; }
+#define DISPATCH(dtype, ...) RDFC_DISPATCH(dtype, __VA_ARGS__)
 
 extern "C" int rdfc_norm_nchunk(int pixels_per_group, int C, int dtype) {
-    return cdiv(pixels_per_group, chunk_pixels(pixels_per_group, C, dtype == RDFC_BF16 ? 8 : 4));
+    return cdiv(pixels_per_group, chunk_pixels(pixels_per_group, C, rdfc_vec(dtype)));
 }
 
 extern "C" int rdfc_norm_stats(const void *x, float *partial, int G, int P, int C, int ld, int dtype, void *stream) {
     if (int e = check_map("rdfc_norm_stats", G, P, C, dtype, {ld})) return e;
-    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map(G, P, C, rdfc_vec(dtype));
     DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld, partial, (double *)nullptr));
     RDFC_LAUNCH_CHECK("rdfc_norm_stats");
     return 0;
@@ -678,7 +676,7 @@ extern "C" int rdfc_norm_finalize(const float *partial, float *mean, float *rstd
                                   float *run_mean, float *run_var, float momentum, void *stream) {
     RDFC_REQUIRE(G > 0 && P > 0 && C > 0, "rdfc_norm_finalize: non-positive size");
     RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_finalize: running statistics need G == 1 (batch norm)");
-    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map(G, P, C, rdfc_vec(dtype));
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(C, 32), G), dim3(FNT), 0, (hipStream_t)stream, m, cdiv(P, m.chunk),
                        partial, mean, rstd, eps, run_mean, run_var, momentum);
     RDFC_LAUNCH_CHECK("rdfc_norm_finalize");
@@ -700,7 +698,7 @@ extern "C" int rdfc_norm_finalize_seq(const float *partial, int nchunk, float *m
                                       float eps, float *run_mean, float *run_var, const float *group_momentum, void *stream) {
     RDFC_REQUIRE(G > 0 && G <= MAXSEQ && P > 0 && C > 0, "rdfc_norm_finalize_seq: 1 <= G <= %d groups", MAXSEQ);
     RDFC_REQUIRE(run_mean == nullptr || group_momentum != nullptr, "rdfc_norm_finalize_seq: running statistics need the per-group momenta");
-    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map(G, P, C, rdfc_vec(dtype));
     Moms moms{};
     for (int g = 0; g < G; ++g) moms.m[g] = group_momentum ? group_momentum[g] : 0.f;
     hipLaunchKernelGGL(stats_finalize_seq_kernel, dim3(cdiv(C, 32)), dim3(FNT), 0, (hipStream_t)stream, m,
@@ -715,7 +713,7 @@ extern "C" int rdfc_norm_apply(const void *x, const float *mean, const float *rs
     if (int e = check_map("rdfc_norm_apply", G, P, C, dtype, {ldx, ldz})) return e;
     RDFC_REQUIRE(act != RDFC_ACT_PRELU || prelu != nullptr, "rdfc_norm_apply: PReLU needs the slope pointer");
     RDFC_REQUIRE(act != RDFC_ACT_TANH && act != RDFC_ACT_SIGMOID, "rdfc_norm_apply: tanh / sigmoid never follow a norm on this path (conv epilogue only)");
-    Map m = make_map_stream(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)x, (const T *)res, (T *)z, ldx, ldr, ldz));
@@ -727,7 +725,7 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
                                     const float *beta, const void *res, float *partial, int G, int P, int C, int lddz,
                                     int ldx, int ldr, int dtype, int act, float slope, const float *prelu, void *stream) {
     if (int e = check_map("rdfc_norm_bwd_reduce", G, P, C, dtype, {lddz, ldx})) return e;
-    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr, (double *)nullptr));
@@ -739,7 +737,7 @@ extern "C" int rdfc_norm_bwd_finalize_acc(const float *partial, float *sums, int
                                           float *dgamma_acc, void *stream) {
     // (G > 1 with accumulators: BatchNorm over G stacked batches -- every group's sums are added, atomically)
     hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), G * 3), dim3(FNT), 0, (hipStream_t)stream, G, C, 3,
-                       cdiv(P, chunk_pixels(P, C, dtype == RDFC_BF16 ? 8 : 4)), partial, sums, dbeta_acc, dgamma_acc);
+                       cdiv(P, chunk_pixels(P, C, rdfc_vec(dtype))), partial, sums, dbeta_acc, dgamma_acc);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_finalize");
     return 0;
 }
@@ -752,7 +750,7 @@ extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *m
                                    int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
                                    const float *prelu, int frozen_stats, void *stream) {
     if (int e = check_map("rdfc_norm_bwd_apply", G, P, C, dtype, {lddz, ldx, lddx})) return e;
-    Map m = make_map_stream(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
@@ -799,7 +797,7 @@ extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *me
 extern "C" int rdfc_norm_stats_acc(const void *x, double *sums64, int G, int P, int C, int ld, int dtype, void *stream) {
     if (int e = check_map("rdfc_norm_stats_acc", G, P, C, dtype, {ld})) return e;
     RDFC_REQUIRE(sums64 != nullptr, "rdfc_norm_stats_acc: null accumulator");
-    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map(G, P, C, rdfc_vec(dtype));
     DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld,
                                        (float *)nullptr, sums64));
     RDFC_LAUNCH_CHECK("rdfc_norm_stats_acc");
@@ -815,7 +813,7 @@ extern "C" int rdfc_norm_apply_sums(const void *x, const double *sums64, const f
     RDFC_REQUIRE(act != RDFC_ACT_PRELU || prelu != nullptr, "rdfc_norm_apply_sums: PReLU needs the slope pointer");
     RDFC_REQUIRE(act != RDFC_ACT_TANH && act != RDFC_ACT_SIGMOID, "rdfc_norm_apply_sums: tanh / sigmoid never follow a norm on this path");
     RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_apply_sums: running statistics need G == 1 (batch norm)");
-    Map m = make_map_stream(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{nullptr, nullptr, gamma, beta, prelu, act, slope};
     a.sums64 = sums64;
     a.eps = eps;
@@ -835,7 +833,7 @@ extern "C" int rdfc_norm_bwd_reduce_acc(const void *dz, const void *x, const flo
                                         int ldx, int ldr, int dtype, int act, float slope, const float *prelu, void *stream) {
     if (int e = check_map("rdfc_norm_bwd_reduce_acc", G, P, C, dtype, {lddz, ldx})) return e;
     RDFC_REQUIRE(sums64 != nullptr, "rdfc_norm_bwd_reduce_acc: null accumulator");
-    Map m = make_map(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, (float *)nullptr, lddz, ldx, ldr, sums64));
@@ -852,7 +850,7 @@ extern "C" int rdfc_norm_bwd_apply_sums(const void *dz, const void *x, const flo
     RDFC_REQUIRE(sums64 != nullptr, "rdfc_norm_bwd_apply_sums: null sums");
     RDFC_REQUIRE(G == 1 || (dbeta_acc == nullptr && dgamma_acc == nullptr),
                  "rdfc_norm_bwd_apply_sums: in-place affine gradients need one statistics group (batch norm)");
-    Map m = make_map_stream(G, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, (const float *)nullptr, (T *)dx, (T *)dres, lddz,
@@ -865,7 +863,7 @@ extern "C" int rdfc_adain_apply(const void *x, const float *mean, const float *r
                                 int C, int ldx, int ldgb, int ldo, int dtype, void *stream) {
     if (int e = check_map("rdfc_adain_apply", N, P, C, dtype, {ldx, ldo})) return e;
     RDFC_REQUIRE(ldgb >= 2 * C, "rdfc_adain_apply: ldgb must cover 2C channels");
-    Map m = make_map_stream(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map_stream(N, P, C, rdfc_vec(dtype));
     DISPATCH(dtype, hipLaunchKernelGGL(adain_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, mean,
                                        rstd, (const T *)x, (const T *)gb, (T *)out, ldx, ldgb, ldo));
     RDFC_LAUNCH_CHECK("rdfc_adain_apply");
@@ -875,7 +873,7 @@ extern "C" int rdfc_adain_apply(const void *x, const float *mean, const float *r
 extern "C" int rdfc_adain_bwd_reduce(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb,
                                      float *partial, int N, int P, int C, int lddo, int ldx, int ldgb, int dtype, void *stream) {
     if (int e = check_map("rdfc_adain_bwd_reduce", N, P, C, dtype, {lddo, ldx})) return e;
-    Map m = make_map(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map(N, P, C, rdfc_vec(dtype));
     DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
                                        mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, partial, lddo, ldx, ldgb));
     RDFC_LAUNCH_CHECK("rdfc_adain_bwd_reduce");
@@ -886,7 +884,7 @@ extern "C" int rdfc_adain_bwd_apply(const void *dout, const void *x, const float
                                     const float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx, int ldgb,
                                     int lddx, int lddgb, int dtype, void *stream) {
     if (int e = check_map("rdfc_adain_bwd_apply", N, P, C, dtype, {lddo, ldx, lddx})) return e;
-    Map m = make_map_stream(N, P, C, dtype == RDFC_BF16 ? 8 : 4);
+    Map m = make_map_stream(N, P, C, rdfc_vec(dtype));
     DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
                                        mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, sums, (T *)dx, (T *)dgb, lddo,
                                        ldx, ldgb, lddx, lddgb));
@@ -895,9 +893,9 @@ extern "C" int rdfc_adain_bwd_apply(const void *dout, const void *x, const float
 }
 
 extern "C" int rdfc_channel_sum(const void *x, float *partial, float *out, int P, int C, int ld, int dtype, void *stream) {
-    RDFC_REQUIRE(dtype == RDFC_F32 || dtype == RDFC_BF16, "rdfc_channel_sum: bad dtype");
+    RDFC_REQUIRE(rdfc_dtype_ok(dtype), "rdfc_channel_sum: bad dtype");
     RDFC_REQUIRE(P > 0 && C > 0 && ld >= C, "rdfc_channel_sum: bad size");
-    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    const int vec = rdfc_vec(dtype);
     int nchunk;
     if (C % vec == 0 && ld % vec == 0) {
         Map m = make_map(1, P, C, vec);
@@ -916,7 +914,7 @@ extern "C" int rdfc_channel_sum(const void *x, float *partial, float *out, int P
 
 extern "C" int rdfc_act_bwd(const void *dy, const void *y, void *dx, int P, int C, int lddy, int ldy, int lddx, int dtype,
                             int y_is_f32, int act, float slope, void *stream) {
-    RDFC_REQUIRE(dtype == RDFC_F32 || dtype == RDFC_BF16, "rdfc_act_bwd: bad dtype");
+    RDFC_REQUIRE(rdfc_dtype_ok(dtype), "rdfc_act_bwd: bad dtype");
     const size_t total = (size_t)P * C;
     const int blocks = (int)min((size_t)2048, (total + 255) / 256);
     DISPATCH(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, C, lddy, ldy, lddx,

@@ -454,10 +454,8 @@ __global__ void sum_maps_scalar_kernel(SumSrc s, T *__restrict__ dst, int C, int
 
 }  // namespace
 
-#define DISPATCH(dtype, ...)                                      \
-    if ((dtype) == RDFC_BF16) { using T = bf16_t; __VA_ARGS__; } \
-    else { using T = float; __VA_ARGS__; }
-#define CHECK_DTYPE(who, dtype) RDFC_REQUIRE((dtype) == RDFC_F32 || (dtype) == RDFC_BF16, "%s: bad dtype %d", who, dtype)
+#define DISPATCH(dtype, ...) RDFC_DISPATCH(dtype, __VA_ARGS__)
+#define CHECK_DTYPE(who, dtype) RDFC_REQUIRE(rdfc_dtype_ok(dtype), "%s: bad dtype %d", who, dtype)
 
 extern "C" int rdfc_pack_weight(const float *w, void *wf, void *wb, int O, int I, int KH, int KW, int dtype, float scale, void *stream) {
     CHECK_DTYPE("rdfc_pack_weight", dtype);
@@ -507,7 +505,7 @@ extern "C" int rdfc_copy_window(const void *src, void *dst, int N, int Hs, int W
                                 int ld_src, int ld_dst, int dtype, int accumulate, void *stream) {
     CHECK_DTYPE("rdfc_copy_window", dtype);
     RDFC_REQUIRE(Hw <= Hs && Ww <= Ws && Hw <= Hd && Ww <= Wd && ld_src >= C && ld_dst >= C, "rdfc_copy_window: window / ld mismatch");
-    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    const int vec = rdfc_vec(dtype);
     const bool v = C % vec == 0 && ld_src % vec == 0 && ld_dst % vec == 0;
     const size_t total = (size_t)N * Hw * Ww * (v ? C / vec : C);
     DISPATCH(dtype, if (v) hipLaunchKernelGGL((copy_window_kernel<T, true>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
@@ -521,7 +519,7 @@ extern "C" int rdfc_copy_window(const void *src, void *dst, int N, int Hs, int W
 extern "C" int rdfc_reflect_pad(const void *src, void *dst, int N, int H, int W, int C, int pad, int dtype, void *stream) {
     CHECK_DTYPE("rdfc_reflect_pad", dtype);
     RDFC_REQUIRE(pad >= 0 && pad < H && pad < W, "rdfc_reflect_pad: pad must be smaller than the map");
-    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    const int vec = rdfc_vec(dtype);
     const bool v = C % vec == 0;
     const size_t total = (size_t)N * (H + 2 * pad) * (W + 2 * pad) * (v ? C / vec : C);
     DISPATCH(dtype, if (v) hipLaunchKernelGGL((reflect_pad_kernel<T, true>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
@@ -534,7 +532,7 @@ extern "C" int rdfc_reflect_pad(const void *src, void *dst, int N, int H, int W,
 extern "C" int rdfc_reflect_pad_adjoint(const void *dpad, void *dsrc, int N, int H, int W, int C, int pad, int dtype, void *stream) {
     CHECK_DTYPE("rdfc_reflect_pad_adjoint", dtype);
     RDFC_REQUIRE(pad >= 0 && pad < H && pad < W, "rdfc_reflect_pad_adjoint: pad must be smaller than the map");
-    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    const int vec = rdfc_vec(dtype);
     const bool v = C % vec == 0;
     const size_t total = (size_t)N * H * W * (v ? C / vec : C);
     DISPATCH(dtype, if (v) hipLaunchKernelGGL((reflect_pad_adjoint_kernel<T, true>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
@@ -660,7 +658,7 @@ extern "C" int rdfc_sum_maps(int n, const void *const *srcs, const int *lds, voi
     RDFC_REQUIRE(n >= 1 && n <= 4 && P > 0 && C > 0 && ld_dst >= C, "rdfc_sum_maps: 1..4 sources, ld_dst >= C");
     SumSrc s{};
     s.n = n;
-    const int vec = dtype == RDFC_BF16 ? 8 : 4;
+    const int vec = rdfc_vec(dtype);
     bool v = C % vec == 0 && ld_dst % vec == 0;
     for (int k = 0; k < n; ++k) {
         RDFC_REQUIRE(srcs[k] != nullptr && lds[k] >= C, "rdfc_sum_maps: bad source %d", k);

@@ -30,9 +30,11 @@ _pack_cache = {}
 
 
 def set_compute_dtype(dtype):
-    """torch.bfloat16 (fast path: bf16 MFMA) or torch.float32 (exact-f32 MFMA, parity mode)."""
+    """torch.bfloat16 (fast path: bf16 MFMA), torch.float16 (f16 MFMA; BASELINE config "fp16 activations with fp32 loss
+    accumulate" -- pair it with RDFCGAN(loss_scale=...), half precision underflows on unscaled gradients) or torch.float32
+    (exact-f32 MFMA, parity mode)."""
     global _compute_dtype
-    assert dtype in (torch.bfloat16, torch.float32)
+    assert dtype in (torch.bfloat16, torch.float16, torch.float32)
     _compute_dtype = dtype
 
 

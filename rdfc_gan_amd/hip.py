@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RDFC_HIP_LIB', os.path.join(_HERE, 'librdfc_hip.so'))   # override: A/B builds of the kernels
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 # bench.py sets this to a list: every conv launch then appends (family, algorithmic flops, start, end) with
 # HIP events recorded on the launch stream (per-kernel roofline measured inside the timed region)
 PROFILE = None
@@ -114,6 +114,8 @@ def dt(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise TypeError(f'unsupported dtype {t.dtype}')
 
 
@@ -694,6 +696,64 @@ def mdconv_backward(inp, offset, mask, weight, grad_out, stride, pad, dil, group
     _chk(lib().rdfc_mdconv_backward(C.byref(d), _p(inp), _p(offset), _p(mask), _p(weight), _p(grad_out), _p(gi), _p(go),
                                     _p(gm), _p(gw), _p(gb), _st()), 'rdfc_mdconv_backward')
     return gi, go, gm, gw, gb
+
+
+# --------------------------------------------------------------------------- NLSPN (nlspn.hip)
+AFFINITY = dict(AS=0, ASS=1, TC=2, TGASS=3)
+
+
+def nlspn_affinity(offset_aff, confidence, scale, w_conf, b_conf, affinity):
+    """offset_aff: pixel-major [B,H,W,24] (f32 | compute dtype); confidence [B,1,H,W] f32 or None -> offset [B,18,H,W],
+    aff [B,9,H,W], conf_samples [B,8,H,W] (or None)"""
+    B, H, W, Cc = offset_aff.shape
+    assert Cc == 24, 'the fused NLSPN kernels cover prop_kernel 3 (8 neighbours)'
+    dev = offset_aff.device
+    offset = torch.empty(B, 18, H, W, dtype=torch.float32, device=dev)
+    aff = torch.empty(B, 9, H, W, dtype=torch.float32, device=dev)
+    cs = torch.empty(B, 8, H, W, dtype=torch.float32, device=dev) if confidence is not None else None
+    if confidence is not None:
+        confidence = confidence.contiguous()
+        assert confidence.dtype == torch.float32 and confidence.numel() == B * H * W
+    _chk(lib().rdfc_nlspn_affinity_forward(_p(offset_aff), ld(offset_aff), dt(offset_aff), _p(confidence), _p(scale), _p(w_conf),
+                                           _p(b_conf), AFFINITY[affinity], B, H, W, _p(offset), _p(aff), _p(cs), _st()),
+         'rdfc_nlspn_affinity_forward')
+    return offset, aff, cs
+
+
+def nlspn_affinity_backward(offset_aff, conf_samples, scale, w_conf, affinity, grad_offset, grad_aff, want_conf, want_scale):
+    B, H, W, _ = offset_aff.shape
+    dev = offset_aff.device
+    g_oa = torch.empty(B, H, W, 24, dtype=offset_aff.dtype, device=dev)
+    g_conf = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev) if want_conf and conf_samples is not None else None
+    g_scale = torch.empty(1, dtype=torch.float32, device=dev) if want_scale else None
+    go = grad_offset.contiguous() if grad_offset is not None else None
+    _chk(lib().rdfc_nlspn_affinity_backward(_p(offset_aff), ld(offset_aff), dt(offset_aff), _p(conf_samples), _p(scale), _p(w_conf),
+                                            AFFINITY[affinity], B, H, W, _p(go), _p(grad_aff.contiguous()), _p(g_oa), 24, _p(g_conf),
+                                            _p(g_scale), _st()), 'rdfc_nlspn_affinity_backward')
+    return g_oa, g_conf, g_scale
+
+
+def nlspn_propagate(feat0, offset, aff, weight, bias, T):
+    """-> feats [T+1,B,1,H,W] (slot 0 = feat0, slot T = the result)"""
+    B, Cc, H, W = feat0.shape
+    assert Cc == 1 and feat0.dtype == torch.float32
+    feats = torch.empty(T + 1, B, 1, H, W, dtype=torch.float32, device=feat0.device)
+    _chk(lib().rdfc_nlspn_propagate_forward(_p(feat0.contiguous()), _p(offset), _p(aff), _p(weight), _p(bias), B, H, W, T, _p(feats),
+                                            _st()), 'rdfc_nlspn_propagate_forward')
+    return feats
+
+
+def nlspn_propagate_backward(feats, offset, aff, weight, grad_out, want_coeff):
+    """-> grad_feat0 [B,1,H,W], grad_offset, grad_aff (or None, None)"""
+    T = feats.shape[0] - 1
+    _, B, _, H, W = feats.shape
+    grads = torch.empty(T + 1, B, 1, H, W, dtype=torch.float32, device=feats.device)
+    grads[T].copy_(grad_out)
+    go = torch.empty_like(offset) if want_coeff else None
+    gm = torch.empty_like(aff) if want_coeff else None
+    _chk(lib().rdfc_nlspn_propagate_backward(_p(feats), _p(offset), _p(aff), _p(weight), B, H, W, T, _p(grads), _p(go), _p(gm), _st()),
+         'rdfc_nlspn_propagate_backward')
+    return grads[0], go, gm
 
 
 # --------------------------------------------------------------------------- label net operators (label_ops.hip)

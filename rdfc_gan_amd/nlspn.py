@@ -3,11 +3,15 @@
 ModulatedDeformConvFunction <- .../nlspn/modulated_deform_conv_func.py:15-56
 NLPSN, NLSPNRefineModule    <- .../nlspn/nlspn_model.py:6-197
 
-The 8 confidence gathers and the 18 propagation steps run on rdfc_mdconv_* (one
-fused gather + tap-sum kernel per call, no column buffer).  The affinity
-normalisation between them is still expressed with torch elementwise ops on the
-(B,8,H,W) affinity tensor (fusing it into one HIP kernel is a listed next step).
+Default (prop_kernel 3, preserve_input False -- the shipped configuration): the fused kernels of csrc/nlspn.hip.
+`_get_offset_affinity` is one launch behind the guidance conv (offset packing, tanh / TGASS scaling, the eight confidence
+gathers, normalisation, reference weight) and the propagation loop is one autograd node: T launches forward that carry
+the 1-channel map only, T launches backward for the map's cotangent, and ONE pass that produces the offset / affinity
+gradients summed over all T steps (autograd over upstream's loop writes and adds 27 gradient planes per step).
+Other configurations run upstream's structure step by step on rdfc_mdconv_* (ModulatedDeformConvFunction below).
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -52,6 +56,50 @@ class ModulatedDeformConvFunction(Function):
         return gi, go, gm, gw, gb, None, None, None, None, None, None
 
 
+class _Affinity(Function):
+    """nlspn_model.py:68-138 behind conv_offset_aff: (offset_aff pixel-major, confidence, aff_scale_const) -> offset, aff"""
+
+    @staticmethod
+    def forward(ctx, offset_aff, confidence, scale, w_conf, b_conf, affinity):
+        from . import hip
+        offset, aff, cs = hip.nlspn_affinity(offset_aff, confidence, scale, w_conf, b_conf, affinity)
+        ctx.save_for_backward(offset_aff, cs, scale, w_conf)
+        ctx.affinity = affinity
+        return offset, aff
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_offset, g_aff):
+        from . import hip
+        offset_aff, cs, scale, w_conf = ctx.saved_tensors
+        if g_aff is None:
+            g_aff = torch.zeros(offset_aff.shape[0], 9, offset_aff.shape[1], offset_aff.shape[2], dtype=torch.float32, device=offset_aff.device)
+        g_oa, g_conf, g_scale = hip.nlspn_affinity_backward(offset_aff, cs, scale, w_conf, ctx.affinity, g_offset, g_aff,
+                                                            ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return g_oa, g_conf, g_scale, None, None, None
+
+
+class _Propagate(Function):
+    """nlspn_model.py:166-173 (preserve_input False): T modulated-deformable steps as one autograd node"""
+
+    @staticmethod
+    def forward(ctx, feat, offset, aff, weight, bias, T):
+        from . import hip
+        feats = hip.nlspn_propagate(feat, offset, aff, weight, bias, T)
+        ctx.save_for_backward(feats, offset, aff, weight)
+        ctx.mark_non_differentiable(feats)            # the per-step maps upstream returns as `list_feat` (never used in a loss)
+        return feats[T].clone(), feats
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out, _g_feats):
+        from . import hip
+        feats, offset, aff, weight = ctx.saved_tensors
+        g0, go, gm = hip.nlspn_propagate_backward(feats, offset, aff, weight, g_out.contiguous(),
+                                                  ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return g0, go, gm, None, None, None
+
+
 class NLPSN(nn.Module):
     def __init__(self, channels_g, channels_f, k_g, k_f, prop_time=1, affinity=None, affinity_gamma=0.5, conf_prop=True,
                  preserve_input=False):
@@ -83,6 +131,9 @@ class NLPSN(nn.Module):
     def _get_offset_affinity(self, guidance_pm, confidence=None, rgb=None):
         """guidance_pm: pixel-major (B,H,W,channels_g) in the compute dtype; confidence NCHW f32."""
         B, H, W, _ = guidance_pm.shape
+        if self._fused():
+            oa = run_conv(guidance_pm, self.conv_offset_aff, out_f32=True)          # pixel-major [B,H,W,24] f32
+            return _Affinity.apply(oa, confidence if self.conf_prop else None, self.aff_scale_const, self.w_conf, self.b, self.affinity)
         offset_aff = Fh.to_nchw(run_conv(guidance_pm, self.conv_offset_aff, out_f32=True))
         o1, o2, aff = torch.chunk(offset_aff, 3, dim=1)
         offset = torch.cat((o1, o2), dim=1).view(B, self.num, 2, H, W)
@@ -112,6 +163,10 @@ class NLPSN(nn.Module):
         aff = torch.cat((aff[:, :self.idx_ref], aff_ref, aff[:, self.idx_ref:]), dim=1)
         return offset.contiguous(), aff.contiguous()
 
+    def _fused(self):
+        return (self.k_f == 3 and self.channels_f == 1 and not self.preserve_input and self.conv_offset_aff.weight.is_cuda
+                and os.environ.get('RDFC_NLSPN_STEPWISE') is None)
+
     def _propagate_once(self, feat, offset, aff):
         return ModulatedDeformConvFunction.apply(feat, offset, aff, self.w, self.b, self.stride, self.padding, self.dilation,
                                                  self.groups, self.deformable_groups, self.im2col_step)
@@ -125,6 +180,9 @@ class NLPSN(nn.Module):
         if self.preserve_input:
             assert feat_init.shape == feat_fix.shape
             mask_fix = (torch.sum(feat_fix > 0.0, dim=1, keepdim=True).detach() > 0.0).type_as(feat_fix)
+        if self._fused():
+            feat_result, feats = _Propagate.apply(feat_init.contiguous(), offset, aff, self.w, self.b, self.prop_time)
+            return feat_result, list(feats[1:]), offset, aff, self.aff_scale_const.data
         feat_result = feat_init
         list_feat = []
         for _ in range(self.prop_time):

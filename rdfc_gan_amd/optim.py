@@ -53,6 +53,7 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = _pview(self.flat_grad, off, p)
                 off += k
         self.steps = 0
+        self.loss_scale = 1.0         # the gradients in flat_grad are this many times too large (static loss scaling, f16 mode)
         self._pending = None          # in-flight all-reduce (work handle, event)
         self._comm_stream = None
         self._hyper = None            # device {lr, step}: set by make_capturable(); the step then launches rdfc_adam_step_dev
@@ -123,7 +124,7 @@ class FlatAdam(torch.optim.Optimizer):
         Fh.join_side_stream()
         self.wait_grads()
         g = self.param_groups[0]
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        world = (dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1) * float(self.loss_scale)
         if not self.flat.is_cuda:
             raise RuntimeError('FlatAdam.step runs the HIP kernel rdfc_adam_step: parameters must live on the GPU '
                                '(there is no CPU fallback)')

@@ -128,7 +128,7 @@ class RDFCGAN:
     def __init__(self, device, distributed, args, is_train=True, fixed_training_samples=None, fixed_testing_samples=None,
                  num_classes=14, out_height=224, out_width=304, label_wall=12, label_floor=5, label_ceiling=3,
                  normal_provider=None, exact_schedule=False, compute_dtype=None, use_label_net=False, normal_net=None,
-                 device_pepper=False, pepper_seed=0, batch_calls=None):
+                 device_pepper=False, pepper_seed=0, batch_calls=None, loss_scale=None):
         self.device, self.distributed, self.args, self.is_train = device, distributed, args, is_train
         # G_label and the label / normal-consistency terms of loss_G (rdfc_gan.py:89,187-203,238-267): off by default -- the
         # benchmarked hot path is the four-network step; on, the step computes upstream's full objective except that the
@@ -155,6 +155,12 @@ class RDFCGAN:
         self.batch_calls = batch_calls
         if compute_dtype is not None:
             Fh.set_compute_dtype(compute_dtype)
+        # Static loss scaling: every backward starts from the cotangent `loss_scale` instead of 1 and the optimizers divide
+        # it out again (folded into the Adam kernel's gradient scale).  Needed in f16 mode only -- the per-pixel loss
+        # gradients (~1e-6) sit below half precision's normal range; f32 / bf16 keep 1.  Default 1024 for f16.
+        if loss_scale is None:
+            loss_scale = 1024.0 if Fh.compute_dtype() == torch.float16 else 1.0
+        self.loss_scale = float(loss_scale)
         self.init_model()
         if self.is_train:
             self.init_optimizer()
@@ -192,13 +198,17 @@ class RDFCGAN:
         self.optimizer_G = FlatAdam(itertools.chain(self.G_A2B.parameters(), self.G_B2A.parameters()), lr=lr, betas=betas)
         self.optimizer_D = FlatAdam(itertools.chain(self.disc_A.parameters(), self.disc_B.parameters()), lr=lr, betas=betas)
         self.optimizers = dict(G=self.optimizer_G, D=self.optimizer_D)
+        for o in self.optimizers.values():
+            o.loss_scale = self.loss_scale
         if self.use_label_net:
             self.optimizer_Label = FlatAdam(self.G_label.parameters(), lr=lr, betas=betas)   # rdfc_gan.py:145-147
             self.optimizers['label'] = self.optimizer_Label
+            self.optimizer_Label.loss_scale = self.loss_scale
         if self.G_normal is not None:                                            # torch.optim.AdamW, lr / 2 (:141-144)
             self.optimizer_Normal = FlatAdam(self.G_normal.parameters(), lr=lr * 0.5, betas=betas,
                                              weight_decay=_cfg_get(a, 'weight_decay', 0.0))
             self.optimizers['Nor'] = self.optimizer_Normal
+            self.optimizer_Normal.loss_scale = self.loss_scale
 
     def init_lr_scheduler(self):
         a = self.args
@@ -412,7 +422,7 @@ class RDFCGAN:
         # lambda factors folded into one f32 product per term ((x * lambda_L1) * 5 upstream: at most one rounding apart)
         loss_G, terms = Fh.combine_losses([(gan_A2B, 1.0), (cyc_A2B, lam_A), (cyc_B2A, lam_B), (gan_B2A, 1.0),
                                            (l1_A2B, lam_1 * 5), (l1_B2A, lam_1 * 3)])
-        loss_G.backward()
+        self._backward(loss_G)
         return dict(loss_G=loss_G, loss_G_A2B=terms[0], loss_G_B2A=terms[3], loss_B2A_L1=terms[5],
                     loss_A2B_L1=terms[5],             # upstream logs B2A under this key (rdfc_gan.py:276)
                     loss_cycle_A=terms[1], loss_cycle_B=terms[2])
@@ -443,7 +453,7 @@ class RDFCGAN:
         loss_G = loss_G_A2B + loss_cycle_A2B + loss_cycle_B2A + loss_G_B2A + loss_A2B_L1 + loss_B2A_L1
         for v in list(extra_A.values()) + list(extra_B.values()):               # :252-267
             loss_G = loss_G + v
-        loss_G.backward()
+        self._backward(loss_G)
         stats = dict(loss_G=loss_G, loss_G_A2B=loss_G_A2B, loss_G_B2A=loss_G_B2A, loss_B2A_L1=loss_B2A_L1,
                      loss_A2B_L1=loss_B2A_L1,          # upstream logs B2A under this key (rdfc_gan.py:276)
                      loss_cycle_A=loss_cycle_A2B, loss_cycle_B=loss_cycle_B2A)
@@ -483,13 +493,22 @@ class RDFCGAN:
             loss_D_real = self.criterionGAN(pred_real, True)
             loss_D_fake = self.criterionGAN(pred_fake, False)
             loss_D, _ = Fh.combine_losses([(loss_D_real, 1.0), (loss_D_fake, 1.0)], post=0.5)    # (real + fake) * 0.5
-            loss_D.backward()
+            self._backward(loss_D)
             return loss_D_real, loss_D_fake, loss_D
         loss_D_real = self.criterionGAN(model_D(real), True)
         loss_D_fake = self.criterionGAN(model_D(fake.detach()), False)
         loss_D = (loss_D_real + loss_D_fake) * 0.5
-        loss_D.backward()
+        self._backward(loss_D)
         return loss_D_real, loss_D_fake, loss_D
+
+    def _backward(self, loss):
+        if self.loss_scale == 1.0:
+            loss.backward()
+        else:
+            seed = self.__dict__.get('_scale_seed')
+            if seed is None or seed.device != loss.device:
+                seed = self._scale_seed = torch.full((), self.loss_scale, dtype=torch.float32, device=loss.device)
+            loss.backward(gradient=seed)
 
     def backward_D_A2B(self):
         r, f, d = self.backward_D_basic(self.disc_A, self.real_B, self.fake_B)

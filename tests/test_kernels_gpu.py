@@ -9,7 +9,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DEV = 'cuda'
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+DT_IDS = ['f32', 'bf16', 'f16']
 
 
 def hip():
@@ -18,7 +19,9 @@ def hip():
 
 
 def tol(dtype):
-    return 2e-5 if dtype == torch.float32 else 1.5e-2
+    """relative to the largest reference value; operands are rounded identically on both sides, so what is left is the
+    rounding of the result: 2^-9 (bf16: 8 significant bits) / 2^-12 (f16: 11 bits) per element, plus summation order"""
+    return {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype]
 
 
 def rel_err(got, ref):
@@ -94,7 +97,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
 def test_conv_fwd_dgrad_wgrad(case, dtype):
     h = hip()
@@ -148,7 +151,7 @@ DILATED_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 @pytest.mark.parametrize('case', DILATED_CASES, ids=lambda c: 'x'.join(map(str, c)))
 def test_conv_dilated(case, dtype):
     h = hip()
@@ -174,7 +177,7 @@ def test_conv_dilated(case, dtype):
     assert rel_err(gw, wr.grad) < tol(dtype), 'wgrad'
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 @pytest.mark.parametrize('case', [(2, 5, 7, 512, 256), (2, 8, 10, 192, 64), (1, 15, 19, 128, 64)],
                          ids=lambda c: 'x'.join(map(str, c)))
 def test_conv_transpose_through_primitives(case, dtype):
@@ -203,7 +206,7 @@ def test_conv_transpose_through_primitives(case, dtype):
     assert rel_err(h.unpack_wgrad(dw, Cin, Cout, 3, 3), wr.grad) < tol(dtype), 'convT weight grad'
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 @pytest.mark.parametrize('mode', ['bn', 'in'])
 @pytest.mark.parametrize('act,res', [('relu', True), ('lrelu', False), ('prelu', False), ('none', False)])
 def test_norm_fwd_bwd(dtype, mode, act, res):
@@ -289,7 +292,7 @@ def test_conv_fused_statistics(case, monkeypatch):
             assert rel_err(rm2, rm1) < 2e-5 and rel_err(rv2, rv1) < 2e-5
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_norm_onestage_matches_twostage(dtype):
     """rdfc_norm_*_acc / *_sums (f64 atomics, no finalize launch) against the two-stage fixed-order path"""
     h = hip()
@@ -321,7 +324,7 @@ def test_norm_onestage_matches_twostage(dtype):
             assert rel_err(gb1, s1[0, 0]) < 1e-5 and rel_err(gg1, s1[0, 1]) < 1e-5
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_adain(dtype):
     h = hip()
     N, H, W, C = 2, 7, 9, 192
@@ -341,7 +344,7 @@ def test_adain(dtype):
     assert rel_err(from_pm(dgb), gbr.grad) < 4 * tol(dtype)
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_layout_window_pad_sum(dtype):
     h = hip()
     x = rnd(2, 24, 9, 7, seed=1).to(dtype).float()
@@ -512,7 +515,7 @@ def test_device_pepper_mask_distribution_and_determinism():
 
 
 # ---- round 2: stacked-batch BatchNorm, fan-out sums, small elementwise operators ---------------------------------------
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 @pytest.mark.parametrize('repeats', [(1, 2), (1, 1), (1, 1, 2)], ids=str)
 def test_bn_over_stacked_batches_equals_separate_calls(dtype, repeats):
     """conv + BatchNorm(train) + LeakyReLU over G stacked batches (layers.bn_groups) == G separate calls of the block:
@@ -568,7 +571,7 @@ def test_bn_over_stacked_batches_equals_separate_calls(dtype, repeats):
     Fh.set_compute_dtype(torch.bfloat16)
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_sum_maps_and_fanout(dtype):
     h = hip()
     from rdfc_gan_amd import functional as Fh
@@ -577,9 +580,9 @@ def test_sum_maps_and_fanout(dtype):
     for n in (2, 3, 4):
         got = h.sum_maps(maps[:n])
         ref = sum(m.float() for m in maps[:n])
-        assert rel_err(got.float(), ref) < (1e-6 if dtype == torch.float32 else 8e-3)
+        assert rel_err(got.float(), ref) < {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
     odd = [to_pm(rnd(N, 5, H, W, seed=s), dtype) for s in range(2)]         # channel count without a 16-byte vector
-    assert rel_err(h.sum_maps(odd).float(), odd[0].float() + odd[1].float()) < (1e-6 if dtype == torch.float32 else 8e-3)
+    assert rel_err(h.sum_maps(odd).float(), odd[0].float() + odd[1].float()) < {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
     x = maps[0].contiguous().clone().requires_grad_(True)
     a, b, c = Fh.fanout(x, 3)
     (a.float() * 2.0).sum().backward(retain_graph=True)
@@ -631,3 +634,45 @@ def test_combine_losses_and_flat_fanout():
     exp = 2 + 2 * x.detach()
     exp[:, :1] += 7
     assert torch.allclose(x.grad, exp, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('affinity', ['TGASS', 'ASS', 'AS', 'TC'])
+@pytest.mark.parametrize('off_scale', [0.6, 3.0], ids=['near', 'far'])
+def test_nlspn_fused_against_oracle(affinity, off_scale):
+    """csrc/nlspn.hip (offset/affinity kernel + the propagation loop as one autograd node) against the oracle's NLSPNProp
+    (nlspn_model.py:68-175 restated on the C restatement of upstream's deformable-conv kernels): values, and the gradients
+    of the 24-channel guidance conv output, the initial map, the confidence and aff_scale_const.  'far' offsets leave the
+    kernels' LDS windows (global-memory fallback) and the image."""
+    from oracle.nlspn import NLSPNProp
+    from rdfc_gan_amd.nlspn import _Affinity, _Propagate
+    B, H, W, T = 2, 19, 70, 4
+    oa = rnd(B, 24, H, W, seed=1)
+    oa[:, :16] *= off_scale
+    conf = torch.sigmoid(rnd(B, 1, H, W, seed=2))
+    feat = rnd(B, 1, H, W, seed=3)
+    g_out = rnd(B, 1, H, W, seed=4)
+    ref = NLSPNProp(8, 3, T, affinity, 0.5, conf_prop=True)
+    # oracle: feed the conv output directly (conv_offset_aff replaced by the identity on a 24-channel "guidance")
+    ref.conv_offset_aff = torch.nn.Identity()
+    oa_r, conf_r, feat_r = (t.clone().requires_grad_(True) for t in (oa, conf, feat))
+    off_r, aff_r = ref.offset_affinity(oa_r, conf_r)
+    y = feat_r
+    for _ in range(T):
+        y = ref.mdconv(y, off_r, aff_r, ref.w, ref.b, 1, 1, 1, 1, 1, 64)
+    y.backward(g_out)
+    # HIP
+    oa_pm = oa.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    conf_d, feat_d = conf.to(DEV).requires_grad_(True), feat.to(DEV).requires_grad_(True)
+    scale = ref.aff_scale_const.detach().clone().to(DEV).requires_grad_(True)
+    w9, b1, wc = torch.ones(1, 1, 3, 3, device=DEV), torch.zeros(1, device=DEV), torch.ones(1, 1, 1, 1, device=DEV)
+    off_d, aff_d = _Affinity.apply(oa_pm, conf_d, scale, wc, b1, affinity)
+    assert rel_err(off_d, off_r.detach()) < 1e-6 and rel_err(aff_d, aff_r.detach()) < 2e-5
+    out, feats = _Propagate.apply(feat_d, off_d, aff_d, w9, b1, T)
+    assert feats.shape == (T + 1, B, 1, H, W) and not feats.requires_grad
+    assert rel_err(out, y.detach()) < 2e-5
+    out.backward(g_out.to(DEV))
+    assert rel_err(feat_d.grad, feat_r.grad) < 5e-5
+    assert rel_err(conf_d.grad, conf_r.grad) < 5e-5
+    assert rel_err(oa_pm.grad.permute(0, 3, 1, 2), oa_r.grad) < 5e-5
+    if affinity == 'TGASS':
+        assert abs(float(scale.grad) - float(ref.aff_scale_const.grad)) < 5e-5 * max(1.0, abs(float(ref.aff_scale_const.grad)))

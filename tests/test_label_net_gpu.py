@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from cases import LABEL_CASE, gen_inputs, label_net_weights
-from test_modules_gpu import DEV, DT, IDS, check, run, setup_dtype
+from test_modules_gpu import DEV, DT, IDS, TOLS, check, run, setup_dtype
 
 pytestmark = pytest.mark.gpu
 
@@ -34,11 +34,9 @@ def build(dtype):
 
 
 # logits: std 0.5, |max| 2.8.  Gradients: upstream's own f32 input gradient is 6e-4 (relative L2) away from f64 on this case.
-TOLS = {torch.float32: dict(out_atol=2e-4, grad_l2=1e-2, buf_rtol=1e-4),
-        torch.bfloat16: dict(out_atol=0.25, grad_l2=0.8, buf_rtol=3e-2)}
 
 
-@pytest.mark.parametrize('dtype', DT, ids=IDS)
+@pytest.mark.parametrize('dtype', DT[:2], ids=IDS[:2])
 def test_label_net_against_upstream_fixture(golden, dtype):
     net = build(dtype)
     x = gen_inputs('label_net', LABEL_CASE['B'], LABEL_CASE['H'], LABEL_CASE['W'])[0].to(DEV)
@@ -46,7 +44,7 @@ def test_label_net_against_upstream_fixture(golden, dtype):
     res = run(wrapped, (x,), 'label_net_small')
     assert res['train.out'].shape == (LABEL_CASE['B'], LABEL_CASE['classes'], LABEL_CASE['H'], LABEL_CASE['W'])
     assert res['train.out'].dtype == torch.float32
-    print(check(wrapped, res, golden('label_net_small'), **TOLS[dtype]))
+    print(check(wrapped, res, golden('label_net_small'), **TOLS['label_net'][dtype]))
 
 
 def test_label_net_state_dict_keys_are_upstreams(golden):

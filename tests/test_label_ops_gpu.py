@@ -9,7 +9,7 @@ from test_kernels_gpu import DEV, DTYPES, from_pm, hip, rel_err, rnd, to_pm, tol
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES[:2], ids=['f32', 'bf16'])     # (the label net is not part of the f16 config)
 @pytest.mark.parametrize('shape', [(2, 16, 17, 21), (1, 128, 114, 152), (2, 8, 5, 4)], ids=str)
 def test_maxpool_forward_backward(shape, dtype):
     from rdfc_gan_amd import functional as Fh
@@ -27,7 +27,7 @@ def test_maxpool_forward_backward(shape, dtype):
     assert rel_err(from_pm(gx), xr.grad) < (1e-6 if dtype == torch.float32 else 8e-3)
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES[:2], ids=['f32', 'bf16'])     # (the label net is not part of the f16 config)
 @pytest.mark.parametrize('bins', [1, 2, 3, 6])
 def test_adaptive_avgpool(bins, dtype):
     from rdfc_gan_amd import functional as Fh
@@ -44,7 +44,7 @@ def test_adaptive_avgpool(bins, dtype):
     assert rel_err(from_pm(gx), xr.grad) < (2e-6 if dtype == torch.float32 else 8e-3)
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES[:2], ids=['f32', 'bf16'])     # (the label net is not part of the f16 config)
 @pytest.mark.parametrize('case', [(2, 14, 29, 38, 228, 304), (2, 16, 1, 1, 29, 38), (1, 8, 2, 2, 29, 38), (2, 8, 3, 3, 9, 11),
                                   (1, 8, 6, 6, 29, 38), (2, 5, 7, 9, 7, 9), (1, 3, 12, 10, 5, 4)], ids=str)
 def test_bilinear_align_corners(case, dtype):
@@ -77,7 +77,7 @@ def test_bilinear_into_channel_window():
     assert float(wide[..., :16].abs().max()) == 0.0 and float(wide[..., 32:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES[:2], ids=['f32', 'bf16'])     # (the label net is not part of the f16 config)
 def test_dropout2d_scale(dtype):
     from rdfc_gan_amd import functional as Fh
     x = rnd(3, 32, 7, 9, seed=8).to(dtype).float()
@@ -96,7 +96,7 @@ def test_dropout2d_scale(dtype):
     assert Fh.dropout2d(xp, 0.25, False) is xp
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES[:2], ids=['f32', 'bf16'])     # (the label net is not part of the f16 config)
 @pytest.mark.parametrize('case', [(2, 14, 19, 23, 0.0), (2, 14, 19, 23, 0.3), (1, 14, 228, 304, 0.1), (1, 3, 5, 5, 0.5)], ids=str)
 def test_cross_entropy(case, dtype):
     from rdfc_gan_amd import functional as Fh

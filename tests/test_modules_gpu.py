@@ -51,13 +51,17 @@ def err(a, b):
     return float(np.abs(a - b).max()), float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-def check(net, res, g, out_atol, grad_l2, buf_rtol):
+def check(net, res, g, out_atol, grad_in_l2, grad_l2, norm_median, norm_max, buf_rtol, stock=None):
     """collect every metric first (printed with -s / on failure), then assert.
 
     Outputs: max abs error (maps live in [-1, 1]).  Gradients: relative L2 error -- an
     elementwise bound is meaningless here: wherever a pre-activation sits within rounding of 0,
     ReLU / LeakyReLU masks legitimately differ between two fp32 summation orders (the reference
-    itself is 7e-3 max-rel / 1.4e-3 L2-rel away from an fp64 evaluation of the same net)."""
+    itself is 7e-3 max-rel / 1.4e-3 L2-rel away from an fp64 evaluation of the same net).
+    Limits per tensor class: outputs | input gradients | sampled full parameter gradients | median and max relative
+    error of the parameter-gradient norms | BatchNorm buffers.
+    stock: {key: relative L2 error of a stock-PyTorch evaluation of the oracle net in the same storage precision}: the
+    input gradients here may not be worse than 1.3x that (+ 0.02)."""
     report, bad = [], []
 
     def note(k, e, lim):
@@ -68,7 +72,10 @@ def check(net, res, g, out_atol, grad_l2, buf_rtol):
         if k.startswith(('eval.', 'train.')):
             note(k, err(res[k].detach().cpu().numpy(), g[k])[0], out_atol)
         elif k.startswith('grad_in.'):
-            note(k, err(res[k].detach().cpu().numpy(), g[k])[1], grad_l2)
+            e = err(res[k].detach().cpu().numpy(), g[k])[1]
+            note(k, e, grad_in_l2)
+            if stock is not None and k in stock:
+                note(k + '/stock', e / max(stock[k], 1e-9), 1.3 + 0.02 / max(stock[k], 1e-9))
         elif k.startswith('grad.'):
             got = dict(net.named_parameters())[k[5:]].grad.detach().cpu().numpy()
             note(k, err(got, g[k])[1], grad_l2)
@@ -85,8 +92,8 @@ def check(net, res, g, out_atol, grad_l2, buf_rtol):
             rels[n] = abs(s_ - ref[n]) / ref[n]
     rel = np.array(list(rels.values()))
     worst = sorted(rels.items(), key=lambda kv: -kv[1])[:6]
-    note('param_grad_norm.median', float(np.median(rel)), grad_l2)
-    note('param_grad_norm.max', float(rel.max()), 5 * grad_l2)
+    note('param_grad_norm.median', float(np.median(rel)), norm_median)
+    note('param_grad_norm.max', float(rel.max()), norm_max)
     report.append('worst=' + ', '.join(f'{k}:{v:.1e}' for k, v in worst))
     sd = net.state_dict()
     if len(g['buf_names']):
@@ -97,10 +104,81 @@ def check(net, res, g, out_atol, grad_l2, buf_rtol):
     return report
 
 
-TOLS = {torch.float32: dict(out_atol=2e-3, grad_l2=2e-2, buf_rtol=1e-3),
-        torch.bfloat16: dict(out_atol=0.12, grad_l2=0.8, buf_rtol=2e-2)}   # bf16: small near-cancelling grads are noise-dominated
-DT = [torch.float32, torch.bfloat16]
-IDS = ['f32', 'bf16']
+# Limits <= 2x the values measured on MI355X (round 2, `pytest -s`; measured value in the comment of each entry).
+# f32 pins the arithmetic.  bf16 / f16 store every activation and gradient map with 8 / 11 significant bits: a pre-activation
+# within that rounding of 0 flips its ReLU / LeakyReLU mask, and each flipped unit changes the gradient path through it --
+# the input gradients of these nets are 0.08 (5 layers) to 0.35 (60 layers) away from f32 in ANY bf16 evaluation, stock
+# PyTorch's included (_stock_lowp below measures it: D_A 0.082, G_B2A 0.240, G_A2B 0.346 / 0.339 against 0.076 / 0.22 / 0.31
+# here), so besides the absolute limits the bf16 / f16 cases assert "not worse than 1.3x a stock low-precision evaluation".
+TOLS = {
+    'g_a2b': {torch.float32: dict(out_atol=5e-5, grad_in_l2=8e-3, grad_l2=8e-3, norm_median=2e-4, norm_max=4e-3, buf_rtol=1e-5),
+              # f32 measured: out 1.0e-5, grad_in 4.3e-3 (full size) / 1.4e-3, sampled grads 4.7e-3, median 8.1e-5, max 1.9e-3, buffers 1.8e-7
+              torch.bfloat16: dict(out_atol=0.15, grad_in_l2=0.6, grad_l2=1.0, norm_median=2e-2, norm_max=0.2, buf_rtol=2e-3),
+              # bf16 measured: out 7.6e-2, grad_in 0.32, sampled grads 0.54 (a 40-sample BatchNorm weight), median 8.8e-3, max 0.106, buffers 8.2e-4
+              torch.float16: dict(out_atol=2e-2, grad_in_l2=0.24, grad_l2=0.6, norm_median=5e-3, norm_max=0.14, buf_rtol=3e-4)},
+              # f16 measured: out 7.6e-3, grad_in 0.116 (0.91x a stock f16 evaluation), sampled grads 0.29, median 2.3e-3, max 6.8e-2, buffers 1.1e-4
+    'g_a2b_nlspn': {torch.float32: dict(out_atol=1e-4, grad_in_l2=2e-3, grad_l2=2e-3, norm_median=2e-4, norm_max=1e-3, buf_rtol=1e-5),
+                    # f32 measured with the fused NLSPN kernels: out 4.7e-5 (18 propagation steps), grad_in 6.7e-4, grads 9.5e-4, max 3.0e-4
+                    torch.bfloat16: dict(out_atol=0.8, grad_in_l2=0.6, grad_l2=1.1, norm_median=2e-2, norm_max=1.1, buf_rtol=2e-3),
+                    # bf16: offsets come from bf16 guidance features; 18 steps of sampling at slightly different positions: out 0.41, aff_scale_const 0.53
+                    torch.float16: dict(out_atol=0.4, grad_in_l2=0.3, grad_l2=0.6, norm_median=1e-2, norm_max=0.6, buf_rtol=1e-3)},
+    'g_b2a': {torch.float32: dict(out_atol=3e-5, grad_in_l2=7e-3, grad_l2=7e-3, norm_median=4e-5, norm_max=1.1e-2, buf_rtol=1e-5),
+              # f32 measured: out 1.25e-5, grad_in 3.5e-3, grads 3.1e-3, median 1.8e-5, max 5.3e-3 (a weight in front of an InstanceNorm)
+              torch.bfloat16: dict(out_atol=0.12, grad_in_l2=0.45, grad_l2=5e-2, norm_median=3e-3, norm_max=0.3, buf_rtol=2e-3),
+              # bf16 measured: out 5.6e-2, grad_in 0.22, grads 2.1e-2, median 1.1e-3, max 0.148
+              torch.float16: dict(out_atol=6e-2, grad_in_l2=0.25, grad_l2=3e-2, norm_median=2e-3, norm_max=0.15, buf_rtol=1e-3)},
+    'patchgan': {torch.float32: dict(out_atol=1.5e-5, grad_in_l2=5e-6, grad_l2=5e-6, norm_median=1e-7, norm_max=1e-6, buf_rtol=1e-6),
+                 # f32 measured: out 5.8e-6, grad_in 1.8e-6, grads 2.3e-6, median 4.4e-8, max 3.5e-7, buffers 9.4e-8
+                 torch.bfloat16: dict(out_atol=2.6e-2, grad_in_l2=0.17, grad_l2=0.23, norm_median=4e-3, norm_max=3.5e-2, buf_rtol=2e-4),
+                 # bf16 measured: out 1.27e-2, grad_in 8.1e-2, grads 0.112 (the first conv's bias), median 1.8e-3, max 1.7e-2, buffers 9.6e-5
+                 torch.float16: dict(out_atol=1.3e-2, grad_in_l2=9e-2, grad_l2=0.12, norm_median=2e-3, norm_max=2e-2, buf_rtol=1e-4)},
+    # the two "next" networks: f32 / bf16 only (their f16 runs are not part of any BASELINE config)
+    'label_net': {torch.float32: dict(out_atol=4e-5, grad_in_l2=4e-3, grad_l2=5e-3, norm_median=6e-5, norm_max=1.1e-3, buf_rtol=1e-5),
+                  # f32 measured: out 1.7e-5, grad_in 1.9e-3, grads 2.4e-3, median 2.9e-5, max 5.3e-4, buffers 1.4e-7
+                  torch.bfloat16: dict(out_atol=0.33, grad_in_l2=0.75, grad_l2=0.85, norm_median=3e-2, norm_max=0.17, buf_rtol=6e-4)},
+                  # bf16 measured: out 0.164 (logits, |max| 2.8), grad_in 0.369, grads 0.422, median 1.45e-2, max 8.1e-2, buffers 3.0e-4
+    'normal_net': {torch.float32: dict(out_atol=5e-5, grad_in_l2=2e-3, grad_l2=2e-3, norm_median=1e-5, norm_max=1e-4, buf_rtol=1e-5),
+                   # f32 measured: out 2.1e-5, grad_in 9.0e-4, grads 7.9e-4, median 4.7e-6, max 4.1e-5, buffers 1.3e-7
+                   torch.bfloat16: dict(out_atol=0.1, grad_in_l2=0.4, grad_l2=0.4, norm_median=2e-2, norm_max=0.2, buf_rtol=6e-4)},
+                   # bf16 measured: out 5.0e-2, grad_in 0.19
+}
+_STOCK = {}
+
+
+def _stock_lowp(kind, dtype):
+    """input-gradient error (relative L2 against its own fp32 run) of a stock-PyTorch CPU evaluation of the ORACLE net with
+    weights and activations in `dtype`, on the fixture inputs: what the storage precision alone costs"""
+    key = (kind, dtype)
+    if key in _STOCK:
+        return _STOCK[key]
+    from oracle import nets as onets
+    mk, inputs, tag = {
+        'g_a2b': (lambda: onets.RDFGenerator(), lambda: gen_inputs('g_a2b', 2, 60, 76), 'g_a2b_small'),
+        'g_b2a': (lambda: onets.ResnetGenerator(1, 3, 64, 'IN2d'), lambda: (gen_inputs('g_b2a', 2, 60, 76)[1],), 'g_b2a_small'),
+        'patchgan1': (lambda: onets.PatchGANDiscriminator(1), lambda: (det_tensor(3, 'disc1', (2, 1, 60, 76)),), 'd_a_small'),
+        'patchgan3': (lambda: onets.PatchGANDiscriminator(3), lambda: (det_tensor(3, 'disc3', (2, 3, 60, 76)),), 'd_b_small'),
+    }[kind]
+    grads = {}
+    for dt in (torch.float32, dtype):
+        net = mk()
+        net.load_state_dict(det_state_dict(net.state_dict(), 0))
+        net.train()
+        net = net.to(dt)
+        ins = [t.clone().to(dt).requires_grad_(True) for t in inputs()]
+        o = net(*ins)
+        o = o if isinstance(o, dict) else {'out': o}
+        loss = 0
+        for k, v in o.items():
+            loss = loss + (v.float() * out_weights(tag, k, v.shape)).sum()
+        loss.backward()
+        grads[dt] = {i: t.grad.float() for i, t in enumerate(ins) if t.grad is not None}
+    _STOCK[key] = {f'grad_in.{i}': float((grads[dtype][i] - grads[torch.float32][i]).norm() / grads[torch.float32][i].norm())
+                   for i in grads[dtype]}
+    return _STOCK[key]
+
+
+DT = [torch.float32, torch.bfloat16, torch.float16]
+IDS = ['f32', 'bf16', 'f16']
 
 
 @pytest.mark.parametrize('dtype', DT, ids=IDS)
@@ -114,10 +192,8 @@ def test_g_a2b(golden, nlspn, name, dtype):
     rgb, depth, normal = (t.to(DEV) for t in gen_inputs('g_a2b', 2, 60, 76))
     res = run(net, (rgb, depth, normal), name)
     res.pop('grad_in.0', None)
-    tol = dict(TOLS[dtype])
-    if nlspn:            # 18 propagation steps amplify rounding (oracle vs upstream already differ by 2e-3 here)
-        tol = {k: v * 5 for k, v in tol.items()}
-    print(check(net, res, golden(name), **tol))
+    stock = _stock_lowp('g_a2b', dtype) if dtype != torch.float32 and not nlspn else None
+    print(check(net, res, golden(name), stock=stock, **TOLS['g_a2b_nlspn' if nlspn else 'g_a2b'][dtype]))
 
 
 @pytest.mark.parametrize('dtype', DT, ids=IDS)
@@ -128,7 +204,8 @@ def test_g_b2a(golden, dtype):
     net.load_state_dict(det_state_dict(net.state_dict(), 0))
     net.to(DEV)
     x = gen_inputs('g_b2a', 2, 60, 76)[1].to(DEV)
-    print(check(net, run(net, (x,), 'g_b2a_small'), golden('g_b2a_small'), **TOLS[dtype]))
+    stock = _stock_lowp('g_b2a', dtype) if dtype != torch.float32 else None
+    print(check(net, run(net, (x,), 'g_b2a_small'), golden('g_b2a_small'), stock=stock, **TOLS['g_b2a'][dtype]))
 
 
 @pytest.mark.parametrize('dtype', DT, ids=IDS)
@@ -140,7 +217,8 @@ def test_patchgan(golden, cin, name, dtype):
     net.load_state_dict(det_state_dict(net.state_dict(), 0))
     net.to(DEV)
     x = det_tensor(3, f'disc{cin}', (2, cin, 60, 76)).to(DEV)
-    print(check(net, run(net, (x,), name), golden(name), **TOLS[dtype]))
+    stock = _stock_lowp(f'patchgan{cin}', dtype) if dtype != torch.float32 else None
+    print(check(net, run(net, (x,), name), golden(name), stock=stock, **TOLS['patchgan'][dtype]))
 
 
 @pytest.mark.parametrize('dtype', DT, ids=IDS)
@@ -155,7 +233,7 @@ def test_g_a2b_full_resolution_odd_sizes(golden, dtype):
     rgb, depth, normal = (t.to(DEV) for t in gen_inputs('g_a2b', 1, 228, 304))
     res = run(net, (rgb, depth, normal), 'g_a2b_full_b1')
     res.pop('grad_in.0', None)
-    print(check(net, res, g, **TOLS[dtype]))
+    print(check(net, res, g, **TOLS['g_a2b'][dtype]))
     # north-star acceptance metric: dense-depth RMSE (metres, x5+5 de-normalised) within 1e-3 of the reference's
     gt = (torch.from_numpy(g['eval.pred_depth']) * 0.9 + 0.02) * 5 + 5      # any fixed "ground truth"
     ours = res['eval.pred_depth'].cpu() * 5 + 5
@@ -338,3 +416,76 @@ def test_eval_path_end_to_end_metrics_within_north_star_tolerance(dtype):
     assert np.abs(got[:, 0] - ref[:, 0]).max() < lim, (got[:, 0], ref[:, 0])             # RMSE, metres
     assert np.abs(got[:, 1] - ref[:, 1]).max() < lim                                     # MAE
     assert np.abs(got[:, 4:] - ref[:, 4:]).max() < (2e-4 if dtype == torch.float32 else 3e-3)   # REL, delta^1..3
+
+
+# ---- full-size step: the HIP train step in every compute dtype against the oracle's step on the same inputs ------------------
+_FULL = {}
+
+
+def _oracle_full_step():
+    """one oracle step (upstream's literal schedule, fp32, CPU) at B = 2, 228x304 -- computed once per session (~1 min)"""
+    if 'ref' in _FULL:
+        return _FULL['ref']
+    from oracle import nets as onets
+    from oracle.step import HotPathStep
+    hp = STEP_HP
+    nets = dict(G_A2B=onets.RDFGenerator(), G_B2A=onets.ResnetGenerator(1, 3, 64, 'IN2d'), disc_A=onets.PatchGANDiscriminator(1),
+                disc_B=onets.PatchGANDiscriminator(3))
+    for net in nets.values():
+        net.load_state_dict(det_state_dict(net.state_dict(), 0))
+        net.train()
+    st = HotPathStep(nets['G_A2B'], nets['G_B2A'], nets['disc_A'], nets['disc_B'], lr=hp['lr'], betas=(0.5, 0.999))
+    data, nA, nfA = step_batch(0, 2, 228, 304)
+    st.set_input(data)
+    normals = dict(real_A=nA, fake_A=nfA, fake_A_again=nfA)
+    losses = st.step(lambda tag: normals[tag], pepper_fn=None)
+    norms = {k: {n: float(v.double().norm()) for n, v in net.state_dict().items() if v.dtype.is_floating_point} for k, net in nets.items()}
+    _FULL['ref'] = (data, normals, losses, st.fake_B.clone(), st.fake_A.clone(), norms)
+    return _FULL['ref']
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['f32', 'bf16', 'f16'])
+def test_full_size_step_against_oracle(dtype, monkeypatch):
+    """B = 2 at the benchmark resolution (228x304: the odd-size crops, 57x76 / 59x78 G_B2A maps, 27x37 PatchGAN maps), one
+    optimisation step, batched schedule: every loss entry, fake_B / fake_A and the norm of every updated tensor against the
+    oracle's step (upstream's literal schedule on the CPU).  f32 pins the arithmetic; bf16 / f16 bound what storage
+    precision costs at full size (measured values in the comments; limits <= 2x measured)."""
+    from rdfc_gan_amd import rdfc_gan as rg
+    data, normals, ref_losses, ref_fB, ref_fA, ref_norms = _oracle_full_step()
+    setup_dtype(dtype)
+    monkeypatch.setattr(rg, 'draw_pepper_mask', lambda shape, snr=0.98, p=0.9: None)        # no noise on either side
+    cfg = _step_cfg(STEP_HP)
+    dn = {k: v.to(DEV) for k, v in normals.items()}
+    m = rg.RDFCGAN(torch.device(DEV), False, cfg, is_train=True, normal_provider=lambda tag, img: dn[tag], batch_calls=True)
+    for key, net in m.models.items():
+        net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    from rdfc_gan_amd import functional as Fh
+    Fh.invalidate_packed_weights()
+    m.train()
+    m.set_input(data)
+    ls = m.optimize_parameters()
+    #                    losses (rel)   fake maps (q99.9 abs, max abs)   weight norms (rel)
+    lim = {torch.float32: (2e-3, 5e-3, 5e-2, 5e-3), torch.bfloat16: (8e-2, 0.12, 0.6, 2e-2), torch.float16: (2e-2, 3e-2, 0.3, 2e-2)}[dtype]
+    report, bad = [], []
+    for k, v in ls.items():
+        ref = ref_losses[k]
+        report.append(f'{k}: {abs(v - ref) / (abs(ref) + 1e-6):.2e}')
+        if not abs(v - ref) <= lim[0] * abs(ref) + 1e-4:
+            bad.append(f'{k}: {v} vs {ref}')
+    for name, got, ref in (('fake_B', m.fake_B, ref_fB), ('fake_A', m.fake_A, ref_fA)):
+        d = (got.detach().float().cpu() - ref).abs()
+        q = float(torch.quantile(d.flatten()[::7], 0.999))
+        report.append(f'{name}: q99.9 {q:.2e} max {float(d.max()):.2e}')
+        if not (q < lim[1] and float(d.max()) < lim[2]):
+            bad.append(f'{name}: q99.9 {q} max {float(d.max())}')
+    worst = 0.0
+    for key, net in m.models.items():
+        for n, v in net.state_dict().items():
+            if v.dtype.is_floating_point and not noise_driven(key, n) and not n.endswith('num_batches_tracked'):
+                r = ref_norms[key][n]
+                worst = max(worst, abs(float(v.double().norm()) - r) / (abs(r) + 1e-4))
+    report.append(f'weight norms: worst rel {worst:.2e}')
+    print('[full-size step]', '; '.join(report))
+    if not worst < lim[3]:
+        bad.append(f'weight norms: worst rel {worst}')
+    assert not bad, '; '.join(bad)

@@ -4,15 +4,13 @@ import torch
 
 from cases import FeatureListAdapter, normal_features
 from detweights import det_state_dict
-from test_modules_gpu import DEV, DT, IDS, check, run, setup_dtype
+from test_modules_gpu import DEV, DT, IDS, TOLS, check, run, setup_dtype
 
 pytestmark = pytest.mark.gpu
 
-TOLS = {torch.float32: dict(out_atol=2e-4, grad_l2=1e-2, buf_rtol=1e-4),
-        torch.bfloat16: dict(out_atol=0.15, grad_l2=0.8, buf_rtol=3e-2)}
 
 
-@pytest.mark.parametrize('dtype', DT, ids=IDS)
+@pytest.mark.parametrize('dtype', DT[:2], ids=IDS[:2])
 def test_normal_decoder_against_upstream_fixture(golden, dtype):
     from rdfc_gan_amd.normal_net import Decoder
     setup_dtype(dtype)
@@ -21,7 +19,7 @@ def test_normal_decoder_against_upstream_fixture(golden, dtype):
     wrapped = FeatureListAdapter(net.to(DEV))
     res = run(wrapped, tuple(t.to(DEV) for t in normal_features()), 'normal_decoder_small')
     assert res['train.out'].shape == (2, 4, 32, 40) and res['train.out'].dtype == torch.float32
-    print(check(wrapped, res, golden('normal_decoder_small'), **TOLS[dtype]))
+    print(check(wrapped, res, golden('normal_decoder_small'), **TOLS['normal_net'][dtype]))
 
 
 def test_nnet_wrapper_resizes_and_requires_an_encoder():
