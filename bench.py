@@ -246,10 +246,27 @@ def main():
         torch.cuda.synchronize()
         hip.PROFILE = None
         Fh.set_multi_stream(True)
+    comm = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        # self-check of the exchange (untimed): which backend / world the collectives really run on and what one all-reduce
+        # of every gradient bucket costs alone, so that a scaling curve can be read against it
+        comm = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), buckets=[])
+        for oname, o in model.optimizers.items():
+            for bi, (lo, hi) in enumerate(o._buckets):
+                view = o.flat_grad[lo:hi]
+                dist.all_reduce(view)                                  # warm-up (RCCL sets up its rings per size class)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(view)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                comm['buckets'].append(dict(optimizer=oname, bucket=bi, mbytes=round(4e-6 * (hi - lo), 1), allreduce_ms=round(ms, 3),
+                                            bus_gb_s=round(2 * (world - 1) / world * 4e-9 * (hi - lo) / (ms * 1e-3), 1)))
     assert all(np.isfinite(v) for v in final.values()), f'non-finite losses: {final}'
 
     if rank == 0:
@@ -270,6 +287,8 @@ def main():
                    unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 3 streams (main, depth branch / D_B, weight gradients), batched calls' if not graphed else ('hip graphs (3 per step), ' + ('fork/join over the helper streams captured' if a.graph_multi_stream else 'one stream')),
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
+        if comm is not None:
+            out['comm'] = comm
         if prof:
             fam, sym = {}, {}
             for name, flops, e0, e1, _shape, kernel in prof:

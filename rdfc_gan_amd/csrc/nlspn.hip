@@ -51,9 +51,10 @@ __device__ __forceinline__ bool inside(float h, float w, int H, int W) { return 
 __device__ __forceinline__ void corners(const Smp &c, const float *__restrict__ win, int wy0, int wx0, const float *__restrict__ im,
                                         int W, float &a, float &b, float &d, float &e) {
     const int r0 = c.h0 - wy0, c0 = c.w0 - wx0;
-    if (r0 >= 0 && c0 >= 0 && r0 + 1 < WH && c0 + 1 < WW) {
+    if (__builtin_expect(r0 >= 0 && c0 >= 0 && r0 + 1 < WH && c0 + 1 < WW, 1)) {
+        // (the window holds zeros outside the image, so a corner that is out of the image reads 0 from it: no per-corner test)
         const float *wp = win + r0 * WW + c0;
-        a = c.v00 ? wp[0] : 0.f; b = c.v01 ? wp[1] : 0.f; d = c.v10 ? wp[WW] : 0.f; e = c.v11 ? wp[WW + 1] : 0.f;
+        a = wp[0]; b = wp[1]; d = wp[WW]; e = wp[WW + 1];
     } else {
         a = c.v00 ? im[(size_t)c.h0 * W + c.w0] : 0.f; b = c.v01 ? im[(size_t)c.h0 * W + c.w0 + 1] : 0.f;
         d = c.v10 ? im[(size_t)(c.h0 + 1) * W + c.w0] : 0.f; e = c.v11 ? im[(size_t)(c.h0 + 1) * W + c.w0 + 1] : 0.f;
@@ -73,8 +74,9 @@ __device__ __forceinline__ void tile_of(const Geo &g, int &b, int &y0, int &x0) 
     y0 = ty * TH;
     x0 = tx * TW;
 }
+template <int NTH = NT>
 __device__ __forceinline__ void load_window(float *win, const float *__restrict__ im, int wy0, int wx0, int H, int W) {
-    for (int e = threadIdx.x; e < WN; e += NT) {
+    for (int e = threadIdx.x; e < WN; e += NTH) {
         const int r = e / WW, c = e - r * WW, iy = wy0 + r, ix = wx0 + c;
         win[e] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? im[(size_t)iy * W + ix] : 0.f;
     }
@@ -116,54 +118,88 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(Geo g, const float *__rest
     }
 }
 
-// ---- gradient of one step w.r.t. its input map (scatter; LDS-privatised, one global atomic per touched window cell) ----
+// ---- gradient of one step w.r.t. its input map (scatter) ---------------------------------------------------------------
+// LDS-privatised: a workgroup adds its 512 pixels x 9 taps x 4 corners into a window in LDS and flushes the window with one
+// global atomic per touched cell.  The window accumulates in 64-BIT FIXED POINT: LDS float atomics run at 0.34 lane-adds
+// per clock and CU on gfx950, integer ones at 7-10 (tools/micro/lds_atomics.hip) -- with ds_add_f32 this kernel took 247 us
+// against 44 us for the forward gather of the same bytes.  The scale is a power of two chosen per workgroup from the largest
+// contribution it is going to add (2^46 / that, rounded down to a power of two): one contribution is below 2^46, a window
+// cell receives at most 512 * 9 * 4 < 2^15 of them, so the sum cannot overflow, and every add is exact to 2^-46 of the
+// largest one -- integer adds are also order-independent, so a window's sums are bit-reproducible.
 __global__ __launch_bounds__(NT) void prop_bwd_feat_kernel(Geo g, const float *__restrict__ off, const float *__restrict__ aff,
                                                            const float *__restrict__ wt, const float *__restrict__ gout,
                                                            float *__restrict__ gin /* zero-filled */) {
-    __shared__ float gacc[WN];
+    __shared__ long long gacc[WN];
+    __shared__ float wmax[NT / 64];
     int b, y0, x0;
     tile_of(g, b, y0, x0);
     const int H = g.H, W = g.W;
     const size_t HW = (size_t)H * W;
     const int wy0 = y0 - 1 - R, wx0 = x0 - 1 - R;
-    for (int e = threadIdx.x; e < WN; e += NT) gacc[e] = 0.f;
-    __syncthreads();
+    for (int e = threadIdx.x; e < WN; e += NT) gacc[e] = 0;
     float *gi = gin + (size_t)b * HW;
+    // this thread's pixels: cotangent x tap weight x affinity per tap, sampling positions
+    float tt[PPT][NTAP], hi[PPT][NTAP], wi[PPT][NTAP];
+    float big = 0.f;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
         const int pix = threadIdx.x + q * NT, h = y0 + pix / TW, w = x0 + pix % TW;
-        if (h >= H || w >= W) continue;
-        const size_t p = (size_t)h * W + w;
-        const float go = gout[(size_t)b * HW + p];
+        const bool live = h < H && w < W;
+        const size_t p = live ? (size_t)h * W + w : 0;
+        const float go = live ? gout[(size_t)b * HW + p] : 0.f;
         const float *o = off + (size_t)b * 2 * NTAP * HW + p, *m = aff + (size_t)b * NTAP * HW + p;
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
-            const float hi = h - 1 + t / 3 + o[(size_t)(2 * t) * HW], wi = w - 1 + t % 3 + o[(size_t)(2 * t + 1) * HW];
-            const float tt = wt[t] * go * m[(size_t)t * HW];
-            if (hi <= -1.f || wi <= -1.f || hi >= H || wi >= W) continue;
-            const Smp c = sample(hi, wi, H, W);
+            hi[q][t] = h - 1 + t / 3 + o[(size_t)(2 * t) * HW];
+            wi[q][t] = w - 1 + t % 3 + o[(size_t)(2 * t + 1) * HW];
+            tt[q][t] = live ? wt[t] * go * m[(size_t)t * HW] : 0.f;
+            big = fabsf(tt[q][t]) <= 3.0e38f ? fmaxf(big, fabsf(tt[q][t])) : __builtin_inff();      // NaN / inf: flagged, not dropped
+        }
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) big = fmaxf(big, __shfl_xor(big, o_, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = big;
+    __syncthreads();
+    big = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (big == 0.f) return;                             // nothing to add (uniform over the workgroup)
+    int ex = 0;
+    if (big <= 3.0e38f) frexpf(big, &ex);               // big < 2^ex
+    // fixed point needs a finite cotangent (NaN / inf go through the float atomics below and stay visible) that is not so
+    // small that 2^(46 - ex) leaves the float range (|values| < 2^-80: float path as well)
+    const bool fixed = big <= 3.0e38f && 46 - ex <= 126;
+    const float up = fixed ? ldexpf(1.f, 46 - ex) : 0.f;                   // contributions * up < 2^46 (bilinear weights <= 1)
+    const double down = fixed ? 1.0 / (double)up : 0.0;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            const float h_ = hi[q][t], w_ = wi[q][t], v = tt[q][t];
+            if (h_ <= -1.f || w_ <= -1.f || h_ >= H || w_ >= W || v == 0.f) continue;
+            const Smp c = sample(h_, w_, H, W);
             const float hh = 1.f - c.lh, hw = 1.f - c.lw;
             const int r0 = c.h0 - wy0, c0 = c.w0 - wx0;
-            if (r0 >= 0 && c0 >= 0 && r0 + 1 < WH && c0 + 1 < WW) {
-                float *ga = gacc + r0 * WW + c0;
-                if (c.v00) atomicAdd(ga, hh * hw * tt);
-                if (c.v01) atomicAdd(ga + 1, hh * c.lw * tt);
-                if (c.v10) atomicAdd(ga + WW, c.lh * hw * tt);
-                if (c.v11) atomicAdd(ga + WW + 1, c.lh * c.lw * tt);
+            if (__builtin_expect(fixed && r0 >= 0 && c0 >= 0 && r0 + 1 < WH && c0 + 1 < WW, 1)) {
+                // four unconditional LDS adds: a corner outside the image lands in a window cell that is never flushed
+                long long *ga = gacc + r0 * WW + c0;
+                const float s_ = v * up;
+                atomicAdd(reinterpret_cast<unsigned long long *>(ga), (unsigned long long)(long long)(hh * hw * s_));
+                atomicAdd(reinterpret_cast<unsigned long long *>(ga + 1), (unsigned long long)(long long)(hh * c.lw * s_));
+                atomicAdd(reinterpret_cast<unsigned long long *>(ga + WW), (unsigned long long)(long long)(c.lh * hw * s_));
+                atomicAdd(reinterpret_cast<unsigned long long *>(ga + WW + 1), (unsigned long long)(long long)(c.lh * c.lw * s_));
             } else {
-                if (c.v00) atomicAdd(gi + (size_t)c.h0 * W + c.w0, hh * hw * tt);
-                if (c.v01) atomicAdd(gi + (size_t)c.h0 * W + c.w0 + 1, hh * c.lw * tt);
-                if (c.v10) atomicAdd(gi + (size_t)(c.h0 + 1) * W + c.w0, c.lh * hw * tt);
-                if (c.v11) atomicAdd(gi + (size_t)(c.h0 + 1) * W + c.w0 + 1, c.lh * c.lw * tt);
+                if (c.v00) atomicAdd(gi + (size_t)c.h0 * W + c.w0, hh * hw * v);
+                if (c.v01) atomicAdd(gi + (size_t)c.h0 * W + c.w0 + 1, hh * c.lw * v);
+                if (c.v10) atomicAdd(gi + (size_t)(c.h0 + 1) * W + c.w0, c.lh * hw * v);
+                if (c.v11) atomicAdd(gi + (size_t)(c.h0 + 1) * W + c.w0 + 1, c.lh * c.lw * v);
             }
         }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < WN; e += NT) {
-        const float v = gacc[e];
-        if (v != 0.f) {
+        const long long a = gacc[e];
+        if (a != 0) {
             const int r = e / WW, c = e - r * WW, iy = wy0 + r, ix = wx0 + c;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) atomicAdd(gi + (size_t)iy * W + ix, v);
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) atomicAdd(gi + (size_t)iy * W + ix, (float)((double)a * down));
         }
     }
 }
@@ -171,7 +207,9 @@ __global__ __launch_bounds__(NT) void prop_bwd_feat_kernel(Geo g, const float *_
 // ---- gradients of offsets / affinities, summed over the T steps --------------------------------------------------------
 // feats[i] = input map of step i + 1 (i = 0 .. T-1), gouts[i] = cotangent of that step's output; both [T][B][H][W]
 // (feats may have a larger stride between steps: the buffer also holds the final map).
-__global__ __launch_bounds__(NT) void prop_bwd_coeff_kernel(Geo g, int T, const float *__restrict__ feats, size_t feat_stride,
+// (512 threads, one pixel each: 54 live values per pixel -- two pixels per thread needed 498 registers, one wave per SIMD)
+constexpr int CNT = TH * TW;
+__global__ __launch_bounds__(CNT) void prop_bwd_coeff_kernel(Geo g, int T, const float *__restrict__ feats, size_t feat_stride,
                                                             const float *__restrict__ gouts, size_t gout_stride,
                                                             const float *__restrict__ off, const float *__restrict__ aff,
                                                             const float *__restrict__ wt, float *__restrict__ goff,
@@ -183,12 +221,12 @@ __global__ __launch_bounds__(NT) void prop_bwd_coeff_kernel(Geo g, int T, const 
     const size_t HW = (size_t)H * W;
     const int wy0 = y0 - 1 - R, wx0 = x0 - 1 - R;
     // per pixel: the sampling geometry is the same for every step -- keep it, and the 27 sums, in registers
-    float hi[PPT][NTAP], wi[PPT][NTAP], am[PPT][NTAP], s_h[PPT][NTAP], s_w[PPT][NTAP], s_m[PPT][NTAP];
-    bool live[PPT];
-    size_t pp[PPT];
+    float hi[1][NTAP], wi[1][NTAP], am[1][NTAP], s_h[1][NTAP], s_w[1][NTAP], s_m[1][NTAP];
+    bool live[1];
+    size_t pp[1];
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-        const int pix = threadIdx.x + q * NT, h = y0 + pix / TW, w = x0 + pix % TW;
+    for (int q = 0; q < 1; ++q) {
+        const int pix = threadIdx.x + q * CNT, h = y0 + pix / TW, w = x0 + pix % TW;
         live[q] = h < H && w < W;
         pp[q] = live[q] ? (size_t)h * W + w : 0;
         const float *o = off + (size_t)b * 2 * NTAP * HW + pp[q], *m = aff + (size_t)b * NTAP * HW + pp[q];
@@ -203,10 +241,10 @@ __global__ __launch_bounds__(NT) void prop_bwd_coeff_kernel(Geo g, int T, const 
     for (int i = 0; i < T; ++i) {
         const float *im = feats + (size_t)i * feat_stride + (size_t)b * HW;
         __syncthreads();                                  // the previous step's reads of the window are done
-        load_window(win, im, wy0, wx0, H, W);
+        load_window<CNT>(win, im, wy0, wx0, H, W);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
+        for (int q = 0; q < 1; ++q) {
             if (!live[q]) continue;
             const float go = gouts[(size_t)i * gout_stride + (size_t)b * HW + pp[q]];
 #pragma unroll
@@ -224,7 +262,7 @@ __global__ __launch_bounds__(NT) void prop_bwd_coeff_kernel(Geo g, int T, const 
         }
     }
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) {
+    for (int q = 0; q < 1; ++q) {
         if (!live[q]) continue;
         float *go_ = goff + (size_t)b * 2 * NTAP * HW + pp[q], *gm_ = gaff + (size_t)b * NTAP * HW + pp[q];
 #pragma unroll
@@ -491,7 +529,7 @@ extern "C" int rdfc_nlspn_propagate_backward(const float *feats, const float *of
         hipLaunchKernelGGL(prop_bwd_feat_kernel, grid, dim3(NT), 0, st, g, offset, aff, weight, grads + (size_t)i * n, grads + (size_t)(i - 1) * n);
     if (grad_offset != nullptr || grad_aff != nullptr) {
         RDFC_REQUIRE(grad_offset != nullptr && grad_aff != nullptr, "rdfc_nlspn_propagate_backward: offset and affinity gradients come together");
-        hipLaunchKernelGGL(prop_bwd_coeff_kernel, grid, dim3(NT), 0, st, g, T, feats, n, grads + n, n, offset, aff, weight, grad_offset, grad_aff);
+        hipLaunchKernelGGL(prop_bwd_coeff_kernel, grid, dim3(CNT), 0, st, g, T, feats, n, grads + n, n, offset, aff, weight, grad_offset, grad_aff);
     }
     RDFC_LAUNCH_CHECK("rdfc_nlspn_propagate_backward");
     return 0;

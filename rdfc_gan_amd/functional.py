@@ -124,6 +124,19 @@ def net_stream(device):
     return s
 
 
+def helper_streams(device):
+    """the helper streams that exist on `device` (weight-gradient, branch, net): what a consumer of the gradients on yet
+    another stream has to wait for"""
+    out = []
+    side = _side.get(device)
+    if side is not None:
+        out.append(side[0])
+    for tab in (_branch, _net):
+        if tab.get(device) is not None:
+            out.append(tab[device])
+    return out
+
+
 def join_side_stream():
     """make the current stream wait for everything launched on the helper streams (weight gradients on the side stream,
     the branch / net streams they may have been forked from); release the tensors kept alive for them"""
@@ -462,6 +475,25 @@ class _FanOutFlat(torch.autograd.Function):
         while len(live) > 1:
             live = [hip.sum_flat(live[:4])] + live[4:]
         return live[0], None
+
+
+class _BackwardMarker(torch.autograd.Function):
+    """identity whose backward calls `fn()` first: placed on a network's input, it fires when that network's whole backward
+    has been enqueued (data-parallel bucket exchange, rdfc_gan.py)"""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fn()
+        return g, None
+
+
+def backward_marker(x, fn):
+    return _BackwardMarker.apply(x, fn) if x.requires_grad else x
 
 
 def fanout_flat(x, n):

@@ -54,7 +54,9 @@ class FlatAdam(torch.optim.Optimizer):
                 off += k
         self.steps = 0
         self.loss_scale = 1.0         # the gradients in flat_grad are this many times too large (static loss scaling, f16 mode)
-        self._pending = None          # in-flight all-reduce (work handle, event)
+        self._pending = []            # events of the in-flight bucket all-reduces
+        self._buckets = [(0, n)]
+        self._started = set()
         self._comm_stream = None
         self._hyper = None            # device {lr, step}: set by make_capturable(); the step then launches rdfc_adam_step_dev
         self._hyper_lr = None
@@ -79,6 +81,7 @@ class FlatAdam(torch.optim.Optimizer):
         # (no join of the helper streams here: step() / the all-reduce joined them before they read the gradients, and the
         # other optimizer's weight gradients may keep running under this one's backward)
         self.wait_grads()
+        self._started = set()
         if self.flat_grad.is_cuda:
             hip.zero_(self.flat_grad)       # hipMemsetAsync
         else:
@@ -95,29 +98,69 @@ class FlatAdam(torch.optim.Optimizer):
             p.grad = _pview(self.flat_grad, off, p)
             off += p.numel()
 
-    # ---- data parallel: one bucket, side stream -------------------------------------------------
-    def all_reduce_grads_async(self):
-        """start sum-all-reduce of the flat gradient on a side stream (RCCL over xGMI); the
-        1/world_size is folded into the Adam kernel.  No-op when not distributed."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    # ---- data parallel: buckets of the flat gradient, side stream ---------------------------------------------------
+    # The flat gradient is cut into buckets (element ranges) in the order in which they become final during backward;
+    # the train step starts a bucket's sum-all-reduce (RCCL over xGMI, on a communication stream of its own) as soon as
+    # the backward of the network that owns it has been enqueued, so that the exchange runs under the rest of the
+    # backward / the next phase of the step.  1/world_size is folded into the Adam kernel.  Default: one bucket.
+    def set_buckets(self, ranges):
+        """ranges: [(start, end), ...] element ranges of the flat buffers, disjoint, covering everything"""
+        ranges = [(int(a), int(b)) for a, b in ranges if b > a]
+        assert sorted(ranges)[0][0] == 0 and sorted(ranges)[-1][1] == self.flat.numel()
+        assert all(x[1] == y[0] for x, y in zip(sorted(ranges), sorted(ranges)[1:])), 'buckets must tile the flat buffer'
+        self._buckets = ranges
+        self._started = set()
+
+    def param_range(self, params):
+        """element range of a run of consecutive parameters (as passed to the constructor) in the flat buffers"""
+        ids = {id(p) for p in params}
+        off, lo, hi = 0, None, None
+        for p in self._params:
+            if id(p) in ids:
+                lo = off if lo is None else lo
+                hi = off + p.numel()
+            off += p.numel()
+        return lo, hi
+
+    @staticmethod
+    def _distributed():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def all_reduce_bucket_async(self, i):
+        """start the all-reduce of bucket i (idempotent within a step).  The communication stream waits for the current
+        stream and for every helper stream (weight gradients are launched on one of their own), not the other way round:
+        nothing on the compute streams waits here."""
+        if not self._distributed() or i in self._started:
             return
-        Fh.join_side_stream()             # weight gradients still in flight on the side stream
+        self._started.add(i)
+        a, b = self._buckets[i]
+        view = self.flat_grad[a:b]
         if self.flat_grad.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
-            self._comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._comm_stream):
-                dist.all_reduce(self.flat_grad)
+            cs = self._comm_stream
+            cs.wait_stream(torch.cuda.current_stream())
+            for s_ in Fh.helper_streams(self.flat_grad.device):
+                cs.wait_stream(s_)
+            with torch.cuda.stream(cs):
+                dist.all_reduce(view)
             ev = torch.cuda.Event()
-            ev.record(self._comm_stream)
-            self._pending = ev
+            ev.record(cs)
+            self._pending.append(ev)
         else:
-            dist.all_reduce(self.flat_grad)   # gloo / CPU tests
+            dist.all_reduce(view)             # gloo / CPU tests
+
+    def all_reduce_grads_async(self):
+        """start the all-reduce of every bucket that has not been started in this step.  No-op when not distributed."""
+        if not self._distributed():
+            return
+        for i in range(len(self._buckets)):
+            self.all_reduce_bucket_async(i)
 
     def wait_grads(self):
-        if self._pending is not None:
-            torch.cuda.current_stream().wait_event(self._pending)
-            self._pending = None
+        for ev in self._pending:
+            torch.cuda.current_stream().wait_event(ev)
+        self._pending = []
 
     @torch.no_grad()
     def step(self, closure=None):

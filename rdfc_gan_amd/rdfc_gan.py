@@ -200,6 +200,21 @@ class RDFCGAN:
         self.optimizers = dict(G=self.optimizer_G, D=self.optimizer_D)
         for o in self.optimizers.values():
             o.loss_scale = self.loss_scale
+        # Data-parallel exchange in buckets, in the order in which the gradients become final (upstream: DDP's 25 MB
+        # reverse-order buckets, rdfc_gan.py:102-119).  G: G_B2A's backward completes first (bucket 0, started by a marker on
+        # its input while G_A2B's backward still runs), then G_A2B in three chunks when the backward ends; D: one bucket per
+        # discriminator, each started when its own backward has been enqueued.
+        oG, oD = self.optimizer_G, self.optimizer_D
+        a0, a1 = oG.param_range(list(self.G_A2B.parameters()))
+        b0, b1 = oG.param_range(list(self.G_B2A.parameters()))
+        cuts, off, third = [a0], a0, (a1 - a0 + 2) // 3
+        for p in self.G_A2B.parameters():       # chunk boundaries on parameter boundaries
+            off += p.numel()
+            if off - cuts[-1] >= third and off < a1:
+                cuts.append(off)
+        cuts.append(a1)
+        oG.set_buckets([(b0, b1)] + list(zip(cuts[:-1], cuts[1:])))
+        oD.set_buckets([oD.param_range(list(self.disc_A.parameters())), oD.param_range(list(self.disc_B.parameters()))])
         if self.use_label_net:
             self.optimizer_Label = FlatAdam(self.G_label.parameters(), lr=lr, betas=betas)   # rdfc_gan.py:145-147
             self.optimizers['label'] = self.optimizer_Label
@@ -333,9 +348,14 @@ class RDFCGAN:
         # fake_B feeds G_B2A, D_A and the L1 term; fake_A feeds D_B and its L1 term: their cotangents are summed by one HIP pass
         fB_cyc, self._fB_D, self._fB_L1 = Fh.fanout_flat(self.fake_B, 3)
         # G_B2A is InstanceNorm only: nothing in it couples the samples of a batch
-        out = self.G_B2A(_stack2(self.real_B, fB_cyc))
+        # (the marker's backward runs when G_B2A's backward has been enqueued: its gradient bucket starts its all-reduce then)
+        out = self.G_B2A(Fh.backward_marker(_stack2(self.real_B, fB_cyc), self._start_G_B2A_bucket))
         self.fake_A, self.rec_A = _SplitBatch.apply(out, B)
         self._fA_D, self._fA_L1 = Fh.fanout_flat(self.fake_A, 2)
+
+    def _start_G_B2A_bucket(self):
+        if self.is_train and not getattr(self, '_graph_mode', False):
+            self.optimizer_G.all_reduce_bucket_async(0)
 
     def _pepper(self, fake_B):
         if getattr(self, '_graph_mode', False):
@@ -680,10 +700,11 @@ class RDFCGAN:
         self.optimizer_D.zero_grad()
         with self._net_stream_ctx():                  # the two discriminators are independent: D_B's step on the second stream
             stats_DB = self.backward_D_B2A()
+            self.optimizer_D.all_reduce_bucket_async(1)       # D_B's bucket: under D_A's backward
         loss_stats.update(self.backward_D_A2B())
         self._join_net_stream(tuple(stats_DB.values()))
         loss_stats.update(stats_DB)
-        self.optimizer_D.all_reduce_grads_async()
+        self.optimizer_D.all_reduce_grads_async()             # D_A's bucket: under G's Adam update
         self.optimizer_G.step()
         if self.G_normal is not None:
             self.optimizer_Normal.step()

@@ -37,6 +37,18 @@ def _worker(rank, world, port, q):
         opt.all_reduce_grads_async()                        # gloo: synchronous sum into the flat bucket
         opt.wait_grads()
         assert torch.all(opt.flat_grad == 3.0), 'flat gradient bucket is not the sum over ranks'
+        # buckets: element ranges reduced separately, in any order, each exactly once per step
+        opt.zero_grad()
+        lo, hi = opt.param_range(list(net[2].parameters()))
+        assert hi == opt.flat.numel() and 0 < lo < hi
+        opt.set_buckets([(lo, hi), (0, lo)])
+        opt.flat_grad.fill_(float(rank + 1))
+        opt.all_reduce_bucket_async(0)
+        assert torch.all(opt.flat_grad[lo:] == 3.0) and torch.all(opt.flat_grad[:lo] == float(rank + 1))
+        opt.all_reduce_grads_async()                        # the rest; bucket 0 is not reduced a second time
+        opt.wait_grads()
+        assert torch.all(opt.flat_grad == 3.0), 'a bucket was skipped or reduced twice'
+        opt.set_buckets([(0, opt.flat.numel())])
         # autograd accumulates into the persistent views (no re-allocation of .grad)
         opt.zero_grad()
         x = torch.randn(2, 3, 6, 6)

@@ -676,3 +676,23 @@ def test_nlspn_fused_against_oracle(affinity, off_scale):
     assert rel_err(oa_pm.grad.permute(0, 3, 1, 2), oa_r.grad) < 5e-5
     if affinity == 'TGASS':
         assert abs(float(scale.grad) - float(ref.aff_scale_const.grad)) < 5e-5 * max(1.0, abs(float(ref.aff_scale_const.grad)))
+
+
+def test_nlspn_scatter_keeps_nonfinite_and_tiny_cotangents():
+    """prop_bwd_feat accumulates in 64-bit fixed point scaled per workgroup; a NaN cotangent must stay a NaN in the result
+    and cotangents far below the float range of the fixed-point scale (1e-30) must not be flushed to zero"""
+    from rdfc_gan_amd.nlspn import _Propagate
+    B, H, W, T = 1, 12, 70, 2
+    feat = rnd(B, 1, H, W, seed=1).to(DEV).requires_grad_(True)
+    off = (rnd(B, 18, H, W, seed=2) * 0.4).to(DEV)
+    aff = torch.softmax(rnd(B, 9, H, W, seed=3), 1).to(DEV)
+    w9, b1 = torch.ones(1, 1, 3, 3, device=DEV), torch.zeros(1, device=DEV)
+    out, _ = _Propagate.apply(feat, off, aff, w9, b1, T)
+    g = rnd(B, 1, H, W, seed=4).to(DEV)
+    (gx,) = torch.autograd.grad(out, feat, g, retain_graph=True)
+    (gt,) = torch.autograd.grad(out, feat, g * 1e-30, retain_graph=True)
+    assert rel_err(gt * 1e30, gx) < 1e-5                                      # linear in the cotangent down to 1e-30
+    gn = g.clone()
+    gn[0, 0, 5, 33] = float('nan')
+    (gb,) = torch.autograd.grad(out, feat, gn)
+    assert torch.isnan(gb).any() and not torch.isnan(gb[0, 0, :, :8]).any()

@@ -115,23 +115,26 @@ TOLS = {
               # f32 measured: out 1.0e-5, grad_in 4.3e-3 (full size) / 1.4e-3, sampled grads 4.7e-3, median 8.1e-5, max 1.9e-3, buffers 1.8e-7
               torch.bfloat16: dict(out_atol=0.15, grad_in_l2=0.6, grad_l2=1.0, norm_median=2e-2, norm_max=0.2, buf_rtol=2e-3),
               # bf16 measured: out 7.6e-2, grad_in 0.32, sampled grads 0.54 (a 40-sample BatchNorm weight), median 8.8e-3, max 0.106, buffers 8.2e-4
-              torch.float16: dict(out_atol=2e-2, grad_in_l2=0.24, grad_l2=0.6, norm_median=5e-3, norm_max=0.14, buf_rtol=3e-4)},
-              # f16 measured: out 7.6e-3, grad_in 0.116 (0.91x a stock f16 evaluation), sampled grads 0.29, median 2.3e-3, max 6.8e-2, buffers 1.1e-4
+              torch.float16: dict(out_atol=2e-2, grad_in_l2=0.24, grad_l2=0.6, norm_median=5.5e-3, norm_max=0.14, buf_rtol=3e-4)},
+              # f16 measured: out 9.5e-3, grad_in 0.116 (0.91x a stock f16 evaluation), sampled grads 0.29, median 2.3e-3, max 6.8e-2, buffers 1.1e-4
     'g_a2b_nlspn': {torch.float32: dict(out_atol=1e-4, grad_in_l2=2e-3, grad_l2=2e-3, norm_median=2e-4, norm_max=1e-3, buf_rtol=1e-5),
                     # f32 measured with the fused NLSPN kernels: out 4.7e-5 (18 propagation steps), grad_in 6.7e-4, grads 9.5e-4, max 3.0e-4
                     torch.bfloat16: dict(out_atol=0.8, grad_in_l2=0.6, grad_l2=1.1, norm_median=2e-2, norm_max=1.1, buf_rtol=2e-3),
                     # bf16: offsets come from bf16 guidance features; 18 steps of sampling at slightly different positions: out 0.41, aff_scale_const 0.53
-                    torch.float16: dict(out_atol=0.4, grad_in_l2=0.3, grad_l2=0.6, norm_median=1e-2, norm_max=0.6, buf_rtol=1e-3)},
+                    torch.float16: dict(out_atol=7e-2, grad_in_l2=0.2, grad_l2=0.7, norm_median=6e-3, norm_max=8e-2, buf_rtol=3e-4)},
+                    # f16 measured: out 3.2e-2, grad_in 9.5e-2, sampled grads 0.33, median 2.7e-3, max 3.7e-2, buffers 1.1e-4
     'g_b2a': {torch.float32: dict(out_atol=3e-5, grad_in_l2=7e-3, grad_l2=7e-3, norm_median=4e-5, norm_max=1.1e-2, buf_rtol=1e-5),
               # f32 measured: out 1.25e-5, grad_in 3.5e-3, grads 3.1e-3, median 1.8e-5, max 5.3e-3 (a weight in front of an InstanceNorm)
               torch.bfloat16: dict(out_atol=0.12, grad_in_l2=0.45, grad_l2=5e-2, norm_median=3e-3, norm_max=0.3, buf_rtol=2e-3),
               # bf16 measured: out 5.6e-2, grad_in 0.22, grads 2.1e-2, median 1.1e-3, max 0.148
-              torch.float16: dict(out_atol=6e-2, grad_in_l2=0.25, grad_l2=3e-2, norm_median=2e-3, norm_max=0.15, buf_rtol=1e-3)},
+              torch.float16: dict(out_atol=2e-2, grad_in_l2=0.16, grad_l2=0.22, norm_median=1.2e-3, norm_max=0.22, buf_rtol=1e-3)},
+              # f16 measured: out 9.4e-3, grad_in 8.0e-2 (0.92x stock f16), grads 0.109, median 5.8e-4, max 0.109
     'patchgan': {torch.float32: dict(out_atol=1.5e-5, grad_in_l2=5e-6, grad_l2=5e-6, norm_median=1e-7, norm_max=1e-6, buf_rtol=1e-6),
                  # f32 measured: out 5.8e-6, grad_in 1.8e-6, grads 2.3e-6, median 4.4e-8, max 3.5e-7, buffers 9.4e-8
                  torch.bfloat16: dict(out_atol=2.6e-2, grad_in_l2=0.17, grad_l2=0.23, norm_median=4e-3, norm_max=3.5e-2, buf_rtol=2e-4),
                  # bf16 measured: out 1.27e-2, grad_in 8.1e-2, grads 0.112 (the first conv's bias), median 1.8e-3, max 1.7e-2, buffers 9.6e-5
-                 torch.float16: dict(out_atol=1.3e-2, grad_in_l2=9e-2, grad_l2=0.12, norm_median=2e-3, norm_max=2e-2, buf_rtol=1e-4)},
+                 torch.float16: dict(out_atol=4e-3, grad_in_l2=6e-2, grad_l2=6.5e-2, norm_median=7e-4, norm_max=1.3e-2, buf_rtol=3e-5)},
+                 # f16 measured: out 1.8e-3, grad_in 2.8e-2 (0.96 - 1.20x stock f16), grads 3.2e-2, median 3.5e-4, max 6.5e-3, buffers 1.1e-5
     # the two "next" networks: f32 / bf16 only (their f16 runs are not part of any BASELINE config)
     'label_net': {torch.float32: dict(out_atol=4e-5, grad_in_l2=4e-3, grad_l2=5e-3, norm_median=6e-5, norm_max=1.1e-3, buf_rtol=1e-5),
                   # f32 measured: out 1.7e-5, grad_in 1.9e-3, grads 2.4e-3, median 2.9e-5, max 5.3e-4, buffers 1.4e-7
@@ -139,8 +142,8 @@ TOLS = {
                   # bf16 measured: out 0.164 (logits, |max| 2.8), grad_in 0.369, grads 0.422, median 1.45e-2, max 8.1e-2, buffers 3.0e-4
     'normal_net': {torch.float32: dict(out_atol=5e-5, grad_in_l2=2e-3, grad_l2=2e-3, norm_median=1e-5, norm_max=1e-4, buf_rtol=1e-5),
                    # f32 measured: out 2.1e-5, grad_in 9.0e-4, grads 7.9e-4, median 4.7e-6, max 4.1e-5, buffers 1.3e-7
-                   torch.bfloat16: dict(out_atol=0.1, grad_in_l2=0.4, grad_l2=0.4, norm_median=2e-2, norm_max=0.2, buf_rtol=6e-4)},
-                   # bf16 measured: out 5.0e-2, grad_in 0.19
+                   torch.bfloat16: dict(out_atol=0.1, grad_in_l2=0.4, grad_l2=0.4, norm_median=5e-3, norm_max=4e-2, buf_rtol=4e-4)},
+                   # bf16 measured: out 5.0e-2, grad_in 0.193, grads 0.204, median 2.4e-3, max 1.9e-2, buffers 1.8e-4
 }
 _STOCK = {}
 
@@ -465,7 +468,9 @@ def test_full_size_step_against_oracle(dtype, monkeypatch):
     m.set_input(data)
     ls = m.optimize_parameters()
     #                    losses (rel)   fake maps (q99.9 abs, max abs)   weight norms (rel)
-    lim = {torch.float32: (2e-3, 5e-3, 5e-2, 5e-3), torch.bfloat16: (8e-2, 0.12, 0.6, 2e-2), torch.float16: (2e-2, 3e-2, 0.3, 2e-2)}[dtype]
+    # measured (f32 | bf16 | f16): losses 2.8e-7 | 3.0e-3 | 1.7e-4; fake maps q99.9 7.2e-6 | 9.0e-2 | 1.1e-2, max 1.3e-5 | 0.147 | 1.7e-2;
+    # weight norms 5.4e-4 | 5.4e-3 | 3.2e-3 (one Adam step moves a weight by lr whatever its gradient's size: sign flips of near-zero gradients)
+    lim = {torch.float32: (1e-5, 5e-5, 1e-4, 1.1e-3), torch.bfloat16: (6e-3, 0.18, 0.3, 1.1e-2), torch.float16: (4e-4, 2.3e-2, 3.5e-2, 6.5e-3)}[dtype]
     report, bad = [], []
     for k, v in ls.items():
         ref = ref_losses[k]
