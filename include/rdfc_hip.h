@@ -369,6 +369,32 @@ int rdfc_nlspn_propagate_backward(const float *feats, const float *offset, const
                                   int T, float *grads, float *grad_offset, float *grad_aff, void *stream);
 
 /* ------------------------------------------------------------------------------
+ * Training-batch preparation (lib/datasets/nyuv2/nyuv2_dataset_training.py:75-134 -> get_train_data's sample dict),
+ * whole batch, on the device; bit-identical to the PIL / torchvision chain upstream runs per sample on the host:
+ * CutOffBlackBorder (preprocessing.py:312-327) -> TF.rotate(angle, NEAREST) -> T.Resize(height) (bilinear; labels nearest)
+ * -> T.CenterCrop -> ToTensor -> masks (:119-120,130) -> T.Normalize (:126-133).
+ * ------------------------------------------------------------------------------ */
+typedef struct rdfc_prep_desc {
+    int32_t B, Hraw, Wraw;      /* decoded images: [B][Hraw][Wraw]([3])                                */
+    int32_t top, left, Hc, Wc;  /* the window CutOffBlackBorder keeps                                   */
+    int32_t Hr, Wr;             /* size after T.Resize                                                  */
+    int32_t cy0, cx0, Ho, Wo;   /* T.CenterCrop: origin in the resized image, output size               */
+    int32_t ks;                 /* taps per row of the coefficient tables (Resample.c ksize)            */
+} rdfc_prep_desc;
+/* rgb / normal: uint8 RGB interleaved; raw_mm / gt_mm: uint16 millimetres; labels uint8.  affine: [B][6] int32, the
+ * 16.16 fixed-point matrix of Geometry.c affine_fixed for each sample's rotation (host-computed from the angle).
+ * h_* / v_*: Resample.c precompute_coeffs tables for the two axes: bounds [n][2] (first tap, count), k8 [n][ks] (22-bit
+ * integer coefficients, 8-bit images), kd [n][ks] (double, 'F' images); x_nearest / y_nearest: ImagingScaleAffine's source
+ * index per resized coordinate (labels).  mean_std: device f32 {rgb mean[3], rgb std[3], depth mean, depth std}.
+ * Outputs: f32 [B][3][Ho][Wo] x2, f32 [B][1][Ho][Wo] x2, u8 (bool) masks [B][1][Ho][Wo] / [B][Ho][Wo], i64 labels. */
+int rdfc_nyu_prepare_batch(const rdfc_prep_desc *d, const uint8_t *rgb, const uint8_t *normal, const uint16_t *raw_mm,
+                           const uint16_t *gt_mm, const uint8_t *labels, const int32_t *affine, const int32_t *h_bounds,
+                           const int32_t *h_k8, const double *h_kd, const int32_t *v_bounds, const int32_t *v_k8,
+                           const double *v_kd, const int32_t *x_nearest, const int32_t *y_nearest, const float *mean_std,
+                           float *out_rgb, float *out_normal, float *out_raw, float *out_gt, uint8_t *out_depth_mask,
+                           uint8_t *out_normal_mask, int64_t *out_labels, void *stream);
+
+/* ------------------------------------------------------------------------------
  * Small elementwise operators that keep stock-framework arithmetic off the path.
  * ------------------------------------------------------------------------------ */
 /* hipMemsetAsync(p, 0, bytes) on `stream`. */
