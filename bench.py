@@ -233,6 +233,15 @@ def main():
         enq1 = time.perf_counter() - t1
         torch.cuda.synchronize()
         unsynced = (time.perf_counter() - t1, enq1)
+    # host cost of enqueueing ONE step into an idle queue (no back-pressure from earlier steps): median of three
+    host_one = []
+    for i in range(3):
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        one_step(i, sync=False)
+        host_one.append(time.perf_counter() - t2)
+    torch.cuda.synchronize()
+    host_one = sorted(host_one)[1]
     ev_steps = max(1, ev_steps)                                   # timed steps that carried per-kernel events
     # Untimed extra step on ONE stream with the same events: in the timed steps a kernel shares the chip with the other
     # streams' kernels, so its duration there (what rocprofv3 of this command shows too) understates what it does alone.
@@ -283,7 +292,7 @@ def main():
                                dead_forwards='executed' if a.exact_schedule else 'elided (result-identical, see DESIGN.md)',
                                step_gflop_per_pair=round(gflop_pair, 1)),
                    loss_readback='every step (reference API)' if not a.no_sync_losses else 'none in the timed region',
-                   host_enqueue_ms_per_step=round(1e3 * (unsynced[1] if unsynced else enqueue) / a.steps, 3),
+                   host_enqueue_ms_per_step=round(1e3 * host_one, 3),
                    unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 3 streams (main, depth branch / D_B, weight gradients), batched calls' if not graphed else ('hip graphs (3 per step), ' + ('fork/join over the helper streams captured' if a.graph_multi_stream else 'one stream')),
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
@@ -310,15 +319,23 @@ def main():
                                    event_steps=ev_steps)
             # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from the
             # committed rocprofv3 passes over this same command (tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
-            # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and only apply to the default workload
-            tfile = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), apply to the default workload only and
+            # are refused when they were taken from other kernel sources than the ones this library was built from
+            tfile = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
             default_wl = (a.batch, a.height, a.width, a.dtype, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, 'bf16', False, False, False)   # (--full-objective sets label_net)
             if default_wl and os.path.exists(tfile):
-                for k, v in json.load(open(tfile)).items():
-                    if top + '(' in k:
-                        out['roofline']['traffic'] = round(v['fetch_bytes'] + v['write_bytes'])
-                        out['roofline']['traffic_note'] = (f"bytes per launch (read {v['fetch_bytes'] / 1e6:.1f} MB + write {v['write_bytes'] / 1e6:.1f} MB), "
-                                                           'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_bench.sh (profiles/r01_pmc_traffic.json)')
+                from rdfc_gan_amd.build import source_hash
+                tab = json.load(open(tfile))
+                meta = tab.pop('_meta', {})
+                if meta.get('csrc_sha16') != source_hash():
+                    out['roofline']['traffic_note'] = (f"profiles/r02_pmc_traffic.json was measured on kernel sources {meta.get('csrc_sha16')}, this build is "
+                                                       f'{source_hash()}: stale counters refused (re-run tools/pmc_bench.sh)')
+                else:
+                    for k, v in tab.items():
+                        if top + '(' in k:
+                            out['roofline']['traffic'] = round(v['fetch_bytes'] + v['write_bytes'])
+                            out['roofline']['traffic_note'] = (f"bytes per launch (read {v['fetch_bytes'] / 1e6:.1f} MB + write {v['write_bytes'] / 1e6:.1f} MB), "
+                                                               f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_bench.sh over this command, kernel sources {meta.get('csrc_sha16')}")
             if iso:
                 ifl = sum(r[1] for r in iso if r[5] == top)
                 isec = sum(r[2].elapsed_time(r[3]) * 1e-3 for r in iso if r[5] == top)
@@ -326,9 +343,10 @@ def main():
                 if inum:
                     out['roofline']['isolated'] = dict(achieved=round(ifl / isec / 1e12, 2), frac=round(ifl / isec / 1e12 / peak, 4),
                                                        avg_launch_us=round(1e6 * isec / inum, 2), launches=inum,
-                                                       note='same kernel on one extra untimed single-stream step.  Under rocprofv3 the run is host-bound '
-                                                            '(~59 ms per step) and the streams overlap little, so the profiler average of this kernel sits '
-                                                            'near this figure; the in-step one is what the un-profiled, overlapped step measures')
+                                                       note='same kernel on one extra untimed single-stream step (nothing else on the chip): what the kernel '
+                                                            'does alone.  In the timed steps it shares the chip with the HBM-bound normalisation kernels and the '
+                                                            'weight gradients of two other streams, which is what `achieved` above and the rocprofv3 summary of '
+                                                            'this command (profiles/) measure')
             out['kernels'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), avg_launch_us=round(1e6 * v[1] / v[2], 2),
                                       launches=v[2], share_of_step=round(v[1] / (elapsed * ev_steps / a.steps), 4))
                               for k, v in sorted(sym.items(), key=lambda kv: -kv[1][1])[:8]}

@@ -19,6 +19,19 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', 
          '-Wno-pass-failed']
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources: stamps measurement artefacts (profiles/*_pmc_traffic.json) with
+    the code they were taken from, so that bench.py can refuse counters of another build"""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    files.append(os.path.join(os.path.dirname(HERE), 'include', 'rdfc_hip.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
 

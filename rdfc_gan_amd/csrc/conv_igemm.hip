@@ -365,6 +365,7 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
 int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G);
 int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                         hipStream_t st);                 // conv_igemm_glds.hip
+int rdfc_try_head_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const float *bias, void *dx, hipStream_t st);   // conv_head_dgrad.hip
 int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st);               // conv_thin_in.hip
 static bool patch_enabled() {
@@ -420,7 +421,8 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
     IgemmParams p{d->N, d->Ho, d->Wo, d->Co, d->Hi, d->Wi, d->Ci, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
                   d->ldy, d->ldx, 1, d->act, d->slope, d->out_f32, d->KH * d->KW * d->Co};
     hipStream_t st = (hipStream_t)stream;
-    if (rdfc_try_conv_thin(d, 1, dy, w_bwd, bias, dx, st)) {
+    if (rdfc_try_head_dgrad(d, dy, w_bwd, bias, dx, st)) {
+    } else if (rdfc_try_conv_thin(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_conv_thin_in(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_conv3x3_glds(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_igemm_glds(d, 1, dy, w_bwd, bias, dx, st)) {

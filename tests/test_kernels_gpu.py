@@ -92,6 +92,7 @@ CONV_CASES = [
     (4, 130, 140, 1, 16, 3, 1, 1),
     (4, 130, 140, 3, 48, 3, 1, 1),
     (4, 130, 140, 96, 1, 3, 1, 1),
+    (2, 190, 180, 128, 1, 3, 1, 1),         # >= 65536 pixels: the streaming head input-gradient kernel (conv_head_dgrad.hip)
     (4, 134, 146, 1, 64, 7, 1, 0),
     (4, 134, 146, 64, 3, 7, 1, 0),
 ]
