@@ -26,7 +26,7 @@ struct WGParams {
     int tiles_ci;
 };
 
-constexpr int SEG = 32, XPX = SEG + 2, NT = 256;
+constexpr int SEG = 32, XPX = SEG + 2;
 
 __device__ inline void glds16(const void *gsrc, unsigned lds_base) {
     unsigned keep;
@@ -62,20 +62,24 @@ template <int ROWB> __device__ inline bf16x8 tr_frag(const unsigned char *img, i
 #endif
 constexpr int WG_RING = RDFC_WGRAD_GLDS_RING;
 
-template <int TCO, int NKY, int DT = RDFC_BF16>   // NKY = 1: one kernel row (3 taps) per workgroup; NKY = 3: all nine taps (64 x 64 tiles only)
-__global__ __launch_bounds__(NT, 2) void wgrad_glds_kernel(WGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
+// TCI = 128 (8 waves, 128 co x 128 ci): per k-step the workgroup stages 8 KB of dY + 8.7 KB of X for 192 MFMAs instead of 8 + 4.4 KB
+// for 96 -- the LDS-DMA issue rate of a CU (one 1-KB piece per ~55 cycles, shared by its waves) is what bounds the 64-ci tile:
+// 4 pieces per wave and k-step against 24 MFMAs (384 matrix-pipe cycles) at 8 waves per CU = 1 760 DMA cycles per 768 MFMA cycles.
+template <int TCO, int NKY, int DT = RDFC_BF16, int TCI = 64>   // NKY = 1: one kernel row (3 taps) per workgroup; NKY = 3: all nine taps (64 x 64 tiles only)
+__global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                            float *__restrict__ dw, const bf16_t *__restrict__ zero) {
-    constexpr int TCI = 64;
+    constexpr int NT = 256 * (TCI / 64);
     constexpr int YROW = TCO * 2, XROW = TCI * 2;               // bytes per pixel row of the two images
     constexpr int YB = SEG * YROW;                              // 8 KB / 4 KB
     constexpr int NY = YB / (NT * 16);                          // dY DMAs per thread and k-step (2 / 1)
     constexpr int NX = (NKY * XPX * (TCI / 8) + NT - 1) / NT;   // X DMAs per thread and k-step: 272 (816) pieces -> 2 (4) rounds
     constexpr int XB = NX * NT * 16;                            // 8 KB (16 KB) region, 4352 B (13056 B) used
     constexpr int SLOT = YB + XB;
-    constexpr int WCO = NKY == 3 ? 2 : TCO / 64, WCI = 4 / WCO; // waves along co / ci
+    constexpr int WCO = NKY == 3 ? 2 : TCO / 64, WCI = (NT / 64) / WCO; // waves along co / ci
     constexpr int WTCO = TCO / WCO, WTCI = TCI / WCI;           // wave tile: 64 co x (32 | 16) ci, or 32 x 32 with nine taps
     constexpr int MT = WTCO / 16, NTF = WTCI / 16, NTAP = 3 * NKY;
     static_assert(NKY == 1 || TCO == 64, "the nine-tap variant keeps 9 x 2 x 2 accumulators per wave");
+    static_assert(TCI == 64 || (TCO == 128 && NKY == 1), "the 128-ci tile is the 8-wave 128 x 128 variant");
     constexpr int PER_STEP = NY + NX;                           // DMAs per wave and k-step
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -207,15 +211,16 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO, int NKY, int DT = RDFC_BF16>
+template <int TCO, int NKY, int DT = RDFC_BF16, int TCI = 64>
 int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
-    constexpr int SMEM = WG_RING * (SEG * TCO * 2 + ((NKY * XPX * 8 + NT - 1) / NT) * NT * 16);
+    constexpr int NT = 256 * (TCI / 64);
+    constexpr int SMEM = WG_RING * (SEG * TCO * 2 + ((NKY * XPX * (TCI / 8) + NT - 1) / NT) * NT * 16);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wgrad_glds_kernel<TCO, NKY, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)wgrad_glds_kernel<TCO, NKY, DT, TCI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
-    p.tiles_ci = cdiv(p.Ci, 64);
+    p.tiles_ci = cdiv(p.Ci, TCI);
     const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * (3 / NKY);
     // Split-K factor: fill the chip's workgroup slots in ONE round -- 528 workgroups measured 1.3x slower
     // than 480 -- within an atomic budget of 48 MB per launch (sweep on one device, 256->256 @ 57x76: 24 MB / 240
@@ -224,7 +229,7 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     // workgroups the chip holds at once: the 64-co kernel (48 KB of LDS, 104 registers) fits three per CU, the 128-co one two.
     // Sizing the 64-co launches for 768 instead of 512: 64->64 @ 228x304 87 -> 80 us, 256->128 @ 114x152 154 -> 132, 128->64 @ 228x304 158 -> 141
     static const int slots_env = getenv("RDFC_WGRAD_SLOTS") ? atoi(getenv("RDFC_WGRAD_SLOTS")) : 0;
-    const int slots = slots_env ? slots_env : (TCO == 64 && NKY == 1 ? 768 : 512);
+    const int slots = slots_env ? slots_env : (TCI == 128 ? 256 : (TCO == 64 && NKY == 1 ? 768 : 512));     // 128 x 128: one 8-wave workgroup per CU
     int slices = slots / tiles;
     const int atomic_cap = (int)(cap_mb * 1.0e6 / (4.0 * p.Co * p.Ci * 9));
     if (slices > atomic_cap) slices = atomic_cap;
@@ -232,7 +237,7 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     if (slices < 1) slices = 1;
     p.segs_per_slice = cdiv(p.total_segs, slices);
     slices = cdiv(p.total_segs, p.segs_per_slice);
-    rdfc_note_kernel("wgrad_glds_kernel<%d, %d, %d>", TCO, NKY, DT);
+    rdfc_note_kernel("wgrad_glds_kernel<%d, %d, %d, %d>", TCO, NKY, DT, TCI);
     static const bool xcd_group = !(getenv("RDFC_WGRAD_XCD") && atoi(getenv("RDFC_WGRAD_XCD")) == 0);
     p.tiles = tiles;
     // measured (tools/wgrad_xcd_ab.sh): 64->64 @ 228x304 (3 tiles) 95 -> 89 us; with 12-24 tiles per slice the slice count
@@ -240,7 +245,7 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     // shows the re-reads (3x on the 64-channel layers) either way; the Infinity Cache serves them at full rate.
     p.xcd_group = xcd_group && tiles <= 3 && slices >= 8;
     const dim3 grid = p.xcd_group ? dim3(cdiv(slices, 8) * 8 * tiles, 1) : dim3(slices, tiles);
-    hipLaunchKernelGGL((wgrad_glds_kernel<TCO, NKY, DT>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw, zero);
+    hipLaunchKernelGGL((wgrad_glds_kernel<TCO, NKY, DT, TCI>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, dw, zero);
     return 1;
 }
 
@@ -258,8 +263,11 @@ int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, 
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
     WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0};
+    // 128 x 128 tiles (8 waves) where both channel counts allow: RDFC_WGRAD_GLDS=4 forces it off (A/B)
+    if (mode != 4 && d->Co % 128 == 0 && d->Ci % 128 == 0)
+        return d->dtype == RDFC_F16 ? launch<128, 1, RDFC_F16, 128>(p, x, dy, dw, zero, st) : launch<128, 1, RDFC_BF16, 128>(p, x, dy, dw, zero, st);
     // 128-co tiles from 256 output channels up; below that the 64-co tile's larger grid wins (128->128: 82 vs 92 us)
-    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return d->dtype == RDFC_F16 ? launch<128, 1, RDFC_F16>(p, x, dy, dw, zero, st) : launch<128, 1>(p, x, dy, dw, zero, st);
+    if (d->Co % 128 == 0 && (mode == 3 || ((mode == 1 || mode == 4) && d->Co >= 256))) return d->dtype == RDFC_F16 ? launch<128, 1, RDFC_F16>(p, x, dy, dw, zero, st) : launch<128, 1>(p, x, dy, dw, zero, st);
     // all nine taps per workgroup (dY and X staged once instead of once per kernel row): measured SLOWER on the
     // full-resolution 64-channel layers (120 vs 97 us: 36 MFMAs against 40 transposing reads per k-step, 244 VGPRs), so
     // L2 traffic is not what bounds them; kept behind RDFC_WGRAD_GLDS_NINE=1 for A/B runs

@@ -92,7 +92,11 @@ CONV_CASES = [
     (4, 130, 140, 1, 16, 3, 1, 1),
     (4, 130, 140, 3, 48, 3, 1, 1),
     (4, 130, 140, 96, 1, 3, 1, 1),
-    (2, 190, 180, 128, 1, 3, 1, 1),         # >= 65536 pixels: the streaming head input-gradient kernel (conv_head_dgrad.hip)
+    (2, 190, 180, 128, 1, 3, 1, 1),
+    # 128 x 128 eight-wave weight-gradient tile (conv_wgrad_glds.hip, TCI = 128)
+    (2, 20, 38, 128, 128, 3, 1, 1),
+    (1, 29, 38, 256, 256, 3, 1, 1),
+    (2, 12, 70, 128, 256, 3, 1, 0),         # >= 65536 pixels: the streaming head input-gradient kernel (conv_head_dgrad.hip)
     (4, 134, 146, 1, 64, 7, 1, 0),
     (4, 134, 146, 64, 3, 7, 1, 0),
 ]
