@@ -62,9 +62,8 @@ template <int ROWB> __device__ inline bf16x8 tr_frag(const unsigned char *img, i
 #endif
 constexpr int WG_RING = RDFC_WGRAD_GLDS_RING;
 
-// TCI = 128 (8 waves, 128 co x 128 ci): per k-step the workgroup stages 8 KB of dY + 8.7 KB of X for 192 MFMAs instead of 8 + 4.4 KB
-// for 96 -- the LDS-DMA issue rate of a CU (one 1-KB piece per ~55 cycles, shared by its waves) is what bounds the 64-ci tile:
-// 4 pieces per wave and k-step against 24 MFMAs (384 matrix-pipe cycles) at 8 waves per CU = 1 760 DMA cycles per 768 MFMA cycles.
+// TCI = 128 (8 waves, 128 co x 128 ci; experiment, see rdfc_try_wgrad_glds): per k-step the workgroup stages 8 KB of dY + 8.7 KB of X
+// for 192 MFMAs instead of 8 + 4.4 KB for 96.
 template <int TCO, int NKY, int DT = RDFC_BF16, int TCI = 64>   // NKY = 1: one kernel row (3 taps) per workgroup; NKY = 3: all nine taps (64 x 64 tiles only)
 __global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                            float *__restrict__ dw, const bf16_t *__restrict__ zero) {
@@ -263,11 +262,13 @@ int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, 
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
     WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0};
-    // 128 x 128 tiles (8 waves) where both channel counts allow: RDFC_WGRAD_GLDS=4 forces it off (A/B)
-    if (mode != 4 && d->Co % 128 == 0 && d->Ci % 128 == 0)
+    // 128 x 128 tiles (8 waves, one workgroup per CU): A/B switch RDFC_WGRAD_GLDS=5 -- measured SLOWER at the batched step's sizes
+    // (N = 16; 128 x 128 against the default): 256->256 @ 57x76 150-154 vs 146-148 us, 128->128 @ 114x152 189 vs 137 us, 512->512 @
+    // 29x38 187 vs 181 us: halving the DMA'd bytes per MFMA does not pay for going from two 4-wave workgroups per CU to one
+    if (mode == 5 && d->Co % 128 == 0 && d->Ci % 128 == 0)
         return d->dtype == RDFC_F16 ? launch<128, 1, RDFC_F16, 128>(p, x, dy, dw, zero, st) : launch<128, 1, RDFC_BF16, 128>(p, x, dy, dw, zero, st);
     // 128-co tiles from 256 output channels up; below that the 64-co tile's larger grid wins (128->128: 82 vs 92 us)
-    if (d->Co % 128 == 0 && (mode == 3 || ((mode == 1 || mode == 4) && d->Co >= 256))) return d->dtype == RDFC_F16 ? launch<128, 1, RDFC_F16>(p, x, dy, dw, zero, st) : launch<128, 1>(p, x, dy, dw, zero, st);
+    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return d->dtype == RDFC_F16 ? launch<128, 1, RDFC_F16>(p, x, dy, dw, zero, st) : launch<128, 1>(p, x, dy, dw, zero, st);
     // all nine taps per workgroup (dY and X staged once instead of once per kernel row): measured SLOWER on the
     // full-resolution 64-channel layers (120 vs 97 us: 36 MFMAs against 40 transposing reads per k-step, 244 VGPRs), so
     // L2 traffic is not what bounds them; kept behind RDFC_WGRAD_GLDS_NINE=1 for A/B runs

@@ -93,7 +93,7 @@ CONV_CASES = [
     (4, 130, 140, 3, 48, 3, 1, 1),
     (4, 130, 140, 96, 1, 3, 1, 1),
     (2, 190, 180, 128, 1, 3, 1, 1),
-    # 128 x 128 eight-wave weight-gradient tile (conv_wgrad_glds.hip, TCI = 128)
+    # 128- and 256-channel 3x3 layers (the LDS-DMA weight-gradient tiles; RDFC_WGRAD_GLDS=5 runs them on the 128 x 128 variant)
     (2, 20, 38, 128, 128, 3, 1, 1),
     (1, 29, 38, 256, 256, 3, 1, 1),
     (2, 12, 70, 128, 256, 3, 1, 0),         # >= 65536 pixels: the streaming head input-gradient kernel (conv_head_dgrad.hip)
