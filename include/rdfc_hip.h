@@ -95,6 +95,11 @@ int rdfc_conv2d_forward_stats(const rdfc_conv_desc *d, const void *x, const void
  * Also the forward of ConvTranspose2d (then bias/act apply to the result). */
 int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const float *bias,
                       void *dx, void *stream);
+/* dx = rdfc_conv2d_dgrad(dy) + addend (same dtype and layout as dx, pixel stride ld_add): the gradient of an activation that
+ * feeds this convolution and a second consumer -- torchvision BasicBlock's `out += identity` (common.py:11-17), the
+ * downsample path -- without a separate summation pass. */
+int rdfc_conv2d_dgrad_add(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const void *addend, int ld_add,
+                          void *dx, void *stream);
 /* dw_packed f32 [Co][KH*KW][Ci] += sum_pixels dy (x) x   (caller zeroes dw_packed first). */
 int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream);
 
@@ -112,6 +117,9 @@ int rdfc_copy_window(const void *src, void *dst, int N, int Hs, int Ws, int Hd, 
 /* nn.ReflectionPad2d(pad) forward, and its adjoint (fold the border back). resnet_generator.py:19,50,68,84 */
 int rdfc_reflect_pad(const void *src, void *dst, int N, int H, int W, int C, int pad, int dtype, void *stream);
 int rdfc_reflect_pad_adjoint(const void *dpad, void *dsrc, int N, int H, int W, int C, int pad, int dtype, void *stream);
+/* same, + addend (the un-padded map's cotangent from a second consumer: ResnetBlock's `x + conv_block(x)`, resnet_generator.py:97-99) */
+int rdfc_reflect_pad_adjoint_add(const void *dpad, const void *addend, int ld_add, void *dsrc, int N, int H, int W, int C, int pad,
+                                 int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------
  * Normalisation (+ residual + activation).  Stands in for nn.BatchNorm2d (train and

@@ -33,6 +33,8 @@ struct GParams {
     int out_f32;
     int tiles_x, tiles_y;
     int stats_groups;            // fused statistics: 0 = off, 1 = one group (batch norm), N = one group per image (instance norm)
+    const void *addend;          // optional map (2-byte elements, pixel stride ld_add) added to the result before the store: the
+    int ld_add;                  // input gradient of a residual junction in one pass (rdfc_conv2d_dgrad_add)
 };
 
 constexpr int BK = 32, TC = 16, PW = TC + 2;
@@ -491,6 +493,15 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = actf(acc[i][j][r] + bv[i][r]);
                 const size_t off = po * p.ld_out + co;
+                if (p.addend != nullptr) {
+                    const bf16_t *ad = reinterpret_cast<const bf16_t *>(p.addend) + po * p.ld_add + co;
+                    if ((p.ld_add & 3) == 0 && co + 3 < p.Cout) {
+                        const bf16x4 t = *reinterpret_cast<const bf16x4 *>(ad);
+                        for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t[r]);
+                    } else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) v[r] += f32of<DT>(ad[r]);
+                }
                 if (p.out_f32) {
                     float *y = reinterpret_cast<float *>(yout) + off;
                     if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
@@ -574,7 +585,7 @@ int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G) {
 // Called by conv_igemm.hip's entry points before the register-staged 3x3 kernels. Returns 1 if it took the launch.
 // stats != nullptr (forward only): also write the per-tile normalisation statistics, G groups.
 int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
-                          hipStream_t st, float *stats = nullptr, int G = 0) {
+                          hipStream_t st, float *stats = nullptr, int G = 0, const void *addend = nullptr, int ld_add = 0) {
     static const int mode = getenv("RDFC_GLDS") ? atoi(getenv("RDFC_GLDS")) : 1;
     if (!glds_shape_ok(d, transposed)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
@@ -584,7 +595,7 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     const int pad = d->ph;
     GParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo,
               Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
-              d->act, d->slope, d->out_f32, 0, 0, stats != nullptr ? G : 0};
+              d->act, d->slope, d->out_f32, 0, 0, stats != nullptr ? G : 0, addend, ld_add};
     p.tiles_x = cdiv(p.W, TC);
     if (d->dtype == RDFC_F16) {                      // f16: the default variants only (the A/B variants below are bf16 experiments)
         p.tiles_y = cdiv(p.H, Cout > 64 ? 8 : 16);

@@ -361,10 +361,10 @@ int rdfc_try_conv3x3_patch(const rdfc_conv_desc *d, int transposed, const void *
 int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                        hipStream_t st);                  // conv_thin.hip
 int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
-                          hipStream_t st, float *stats = nullptr, int G = 0);               // conv_glds.hip
+                          hipStream_t st, float *stats = nullptr, int G = 0, const void *addend = nullptr, int ld_add = 0);   // conv_glds.hip
 int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G);
 int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
-                        hipStream_t st);                 // conv_igemm_glds.hip
+                        hipStream_t st, const void *addend = nullptr, int ld_add = 0);       // conv_igemm_glds.hip
 int rdfc_try_head_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const float *bias, void *dx, hipStream_t st);   // conv_head_dgrad.hip
 int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st);               // conv_thin_in.hip
@@ -432,4 +432,25 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
     else launch_T<float>(p, dy, w_bwd, bias, dx, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_dgrad");
     return 0;
+}
+
+// dx = input gradient + addend: the gradient of an activation that feeds this conv AND a second consumer (a residual junction:
+// torchvision BasicBlock `out += identity`, ResNet-18 downsample path) in one pass.  The LDS-DMA kernels add in their epilogue;
+// every other shape runs the plain input gradient followed by one in-place sum pass.
+extern "C" int rdfc_sum_maps(int n, const void *const *srcs, const int *lds, void *dst, int P, int C, int ld_dst, int dtype, void *stream);
+extern "C" int rdfc_conv2d_dgrad_add(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const void *addend, int ld_add,
+                                     void *dx, void *stream) {
+    if (int e = check_desc(d, "rdfc_conv2d_dgrad_add")) return e;
+    RDFC_REQUIRE(addend != nullptr && ld_add >= d->Ci, "rdfc_conv2d_dgrad_add: addend missing or ld_add < Ci");
+    RDFC_REQUIRE(d->act == RDFC_ACT_NONE && !d->out_f32, "rdfc_conv2d_dgrad_add: plain input gradient only");
+    hipStream_t st = (hipStream_t)stream;
+    if (rdfc_is16(d->dtype) && (rdfc_try_conv3x3_glds(d, 1, dy, w_bwd, nullptr, dx, st, nullptr, 0, addend, ld_add) ||
+                                rdfc_try_igemm_glds(d, 1, dy, w_bwd, nullptr, dx, st, addend, ld_add))) {
+        RDFC_LAUNCH_CHECK("rdfc_conv2d_dgrad_add");
+        return 0;
+    }
+    if (int e = rdfc_conv2d_dgrad(d, dy, w_bwd, nullptr, dx, stream)) return e;
+    const void *srcs[2] = {dx, addend};
+    const int lds[2] = {d->ldx, ld_add};
+    return rdfc_sum_maps(2, srcs, lds, dx, d->N * d->Hi * d->Wi, d->Ci, d->ldx, d->dtype, stream);
 }

@@ -24,6 +24,8 @@ struct IGParams {
     int act;
     float slope;
     int out_f32;
+    const void *addend;          // optional map added to the result before the store (rdfc_conv2d_dgrad_add)
+    int ld_add;
 };
 
 __device__ inline void glds16(const void *gsrc, unsigned lds_base) {
@@ -221,6 +223,15 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = actf(acc[i][j][r] + bv[i][r]);
                 const size_t off = (size_t)po * p.ld_out + co;
+                if (p.addend != nullptr) {
+                    const bf16_t *ad = reinterpret_cast<const bf16_t *>(p.addend) + (size_t)po * p.ld_add + co;
+                    if ((p.ld_add & 3) == 0 && co + 3 < p.Cout) {
+                        const bf16x4 t = *reinterpret_cast<const bf16x4 *>(ad);
+                        for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t[r]);
+                    } else
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.Cout) v[r] += f32of<DT>(ad[r]);
+                }
                 if (p.out_f32) {
                     float *y = reinterpret_cast<float *>(yout) + off;
                     if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
@@ -285,7 +296,7 @@ int launch(const IGParams &p, const void *x, const void *w, const float *bias, v
 
 // Called by conv_igemm.hip's entry points after the 3x3 / stride-1 kernels. Returns 1 if it took the launch.
 int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
-                        hipStream_t st) {
+                        hipStream_t st, const void *addend = nullptr, int ld_add = 0) {
     static const int mode = getenv("RDFC_IGEMM_GLDS") ? atoi(getenv("RDFC_IGEMM_GLDS")) : 1;
     if (!mode || !rdfc_is16(d->dtype)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
@@ -301,7 +312,7 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
     if (zero == nullptr) return 0;
     IGParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, Cin, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo, Cout,
                d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw, ld_in, transposed ? d->ldx : d->ldy, transposed,
-               d->act, d->slope, d->out_f32};
+               d->act, d->slope, d->out_f32, addend, ld_add};
     if (d->dtype == RDFC_F16)
         return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, st);
     if (Cout > 64 || mode == 3) return launch<128>(p, in, w, bias, out, zero, st);

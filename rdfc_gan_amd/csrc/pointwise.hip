@@ -151,7 +151,8 @@ __global__ void reflect_pad_kernel(const T *__restrict__ s, T *__restrict__ d, i
 
 // adjoint as a gather: every source pixel sums the padded positions that read it
 template <typename T, bool VECP>
-__global__ void reflect_pad_adjoint_kernel(const T *__restrict__ dp, T *__restrict__ ds, int N, int H, int W, int C, int pad) {
+__global__ void reflect_pad_adjoint_kernel(const T *__restrict__ dp, T *__restrict__ ds, int N, int H, int W, int C, int pad,
+                                           const T *__restrict__ addend, int ld_add) {
     constexpr int V = VECP ? Elem<T>::VEC : 1;
     const int CV = C / V, Hp = H + 2 * pad, Wp = W + 2 * pad;
     const size_t total = (size_t)N * H * W * CV;
@@ -168,6 +169,15 @@ __global__ void reflect_pad_adjoint_kernel(const T *__restrict__ dp, T *__restri
         if (xx <= W - 2 && xx >= W - 1 - pad) xs[nx++] = 2 * (W - 1) - xx + pad;
         float acc[V];
         for (int v = 0; v < V; ++v) acc[v] = 0.f;
+        if (addend != nullptr) {                       // the cotangent of a second consumer of the un-padded map (ResnetBlock's skip)
+            if constexpr (VECP) {
+                Vec16<T> t;
+                t.load(addend + ps * ld_add + cv * V);
+                for (int v = 0; v < V; ++v) acc[v] = t.get(v);
+            } else {
+                acc[0] = Elem<T>::ld(addend + ps * ld_add + cv);
+            }
+        }
         for (int a = 0; a < ny; ++a)
             for (int b = 0; b < nx; ++b) {
                 const size_t pp = ((size_t)n * Hp + ys[a]) * Wp + xs[b];
@@ -529,16 +539,23 @@ extern "C" int rdfc_reflect_pad(const void *src, void *dst, int N, int H, int W,
     RDFC_LAUNCH_CHECK("rdfc_reflect_pad");
     return 0;
 }
+extern "C" int rdfc_reflect_pad_adjoint_add(const void *dpad, const void *addend, int ld_add, void *dsrc, int N, int H, int W, int C, int pad,
+                                            int dtype, void *stream);
 extern "C" int rdfc_reflect_pad_adjoint(const void *dpad, void *dsrc, int N, int H, int W, int C, int pad, int dtype, void *stream) {
+    return rdfc_reflect_pad_adjoint_add(dpad, nullptr, 0, dsrc, N, H, W, C, pad, dtype, stream);
+}
+extern "C" int rdfc_reflect_pad_adjoint_add(const void *dpad, const void *addend, int ld_add, void *dsrc, int N, int H, int W, int C, int pad,
+                                            int dtype, void *stream) {
     CHECK_DTYPE("rdfc_reflect_pad_adjoint", dtype);
     RDFC_REQUIRE(pad >= 0 && pad < H && pad < W, "rdfc_reflect_pad_adjoint: pad must be smaller than the map");
     const int vec = rdfc_vec(dtype);
-    const bool v = C % vec == 0;
+    RDFC_REQUIRE(addend == nullptr || ld_add >= C, "rdfc_reflect_pad_adjoint_add: ld_add < C");
+    const bool v = C % vec == 0 && (addend == nullptr || ld_add % vec == 0);
     const size_t total = (size_t)N * H * W * (v ? C / vec : C);
     DISPATCH(dtype, if (v) hipLaunchKernelGGL((reflect_pad_adjoint_kernel<T, true>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
-                                              (const T *)dpad, (T *)dsrc, N, H, W, C, pad);
+                                              (const T *)dpad, (T *)dsrc, N, H, W, C, pad, (const T *)addend, ld_add);
              else hipLaunchKernelGGL((reflect_pad_adjoint_kernel<T, false>), dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream,
-                                     (const T *)dpad, (T *)dsrc, N, H, W, C, pad));
+                                     (const T *)dpad, (T *)dsrc, N, H, W, C, pad, (const T *)addend, ld_add));
     RDFC_LAUNCH_CHECK("rdfc_reflect_pad_adjoint");
     return 0;
 }

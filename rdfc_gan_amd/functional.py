@@ -182,13 +182,16 @@ def _wgrad(d, a, b, weight, O, I, k, scale):
 class ConvSpec:
     """static description of one conv block (shared by forward and backward)"""
     __slots__ = ('k', 'stride', 'pad', 'transposed', 'out_pad', 'norm', 'act', 'slope', 'eps', 'momentum',
-                 'out_f32', 'wscale', 'dil', 'group_momenta')
+                 'out_f32', 'wscale', 'dil', 'group_momenta', 'passthrough')
 
     def __init__(self, k, stride=1, pad=0, transposed=False, out_pad=0, norm='none', act='none', slope=0.0,
-                 eps=1e-5, momentum=0.1, out_f32=False, wscale=1.0, dil=1, group_momenta=None):
+                 eps=1e-5, momentum=0.1, out_f32=False, wscale=1.0, dil=1, group_momenta=None, passthrough=False):
         """group_momenta (BatchNorm only): the batch is G = len(group_momenta) stacked batches of as many separate calls of
         this layer -- statistics per group, running statistics advanced once per group with its momentum"""
         assert dil == 1 or not transposed
+        # passthrough: the block also returns an alias of its input for a second consumer (a residual junction); the alias'
+        # cotangent is added to the input gradient inside the input-gradient kernel (rdfc_conv2d_dgrad_add)
+        self.passthrough = bool(passthrough) and not transposed
         self.group_momenta = tuple(group_momenta) if group_momenta is not None and len(group_momenta) > 1 else None
         self.k, self.stride, self.pad, self.transposed, self.out_pad, self.dil = k, stride, pad, transposed, out_pad, dil
         self.norm, self.act, self.slope, self.eps, self.momentum = norm, act, slope, eps, momentum
@@ -244,7 +247,7 @@ class _ConvBlock(torch.autograd.Function):
         ctx.has_bias = bias is not None
         if not has_norm:
             ctx.save_for_backward(x, weight, y if spec.act != 'none' else None)
-            return y
+            return (y, x.view(x.shape)) if spec.passthrough else y
         G = N if spec.norm == 'in' else (len(gm) if gm is not None else 1)
         if spec.norm == 'bn' and not training:
             mean = run_mean.view(1, -1).float()
@@ -264,10 +267,10 @@ class _ConvBlock(torch.autograd.Function):
                 mean, rstd = hip.norm_forward_onestage(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
                                                        run_mean if upd else None, run_var if upd else None, spec.momentum)
         ctx.save_for_backward(x, weight, y, mean, rstd, gamma, beta, res, prelu)
-        return z
+        return (z, x.view(x.shape)) if spec.passthrough else z
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, d_alias=None):
         spec = ctx.spec
         Cout, Ho, Wo = ctx.shapes
         has_norm = spec.norm != 'none'
@@ -305,7 +308,11 @@ class _ConvBlock(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=Cin, ldy=hip.ld(dy), dtype=hip.dt(x))
                 g_x = torch.empty(N, H, W, Cin, dtype=x.dtype, device=x.device)
-                hip.conv_dgrad(d, dy, wb, None, g_x)
+                if d_alias is not None and d_alias.dtype != x.dtype:
+                    d_alias = d_alias.to(x.dtype)
+                hip.conv_dgrad(d, dy, wb, None, g_x, addend=d_alias)
+            elif d_alias is not None:
+                g_x = d_alias
             if ctx.needs_input_grad[1]:
                 d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=hip.ld(x), ldy=hip.ld(dy), dtype=hip.dt(x))
                 g_w = _wgrad(d, x, dy, weight, Cout, Cin, spec.k, spec.wscale)
@@ -535,17 +542,21 @@ def combine_losses(terms, post=1.0):
 
 class _ReflectPad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pad):
+    def forward(ctx, x, pad, passthrough):
         ctx.pad = pad
-        return hip.reflect_pad(x.contiguous(), pad)
+        out = hip.reflect_pad(x.contiguous(), pad)
+        return (out, x.view(x.shape)) if passthrough else out
 
     @staticmethod
-    def backward(ctx, dy):
-        return hip.reflect_pad_adjoint(dy.contiguous(), ctx.pad), None
+    def backward(ctx, dy, d_alias=None):
+        if d_alias is not None and d_alias.dtype != dy.dtype:
+            d_alias = d_alias.to(dy.dtype)
+        return hip.reflect_pad_adjoint(dy.contiguous(), ctx.pad, addend=d_alias), None, None
 
 
-def reflect_pad(x, pad):
-    return _ReflectPad.apply(x, pad)
+def reflect_pad(x, pad, passthrough=False):
+    """passthrough: -> (padded, alias of x) for a second consumer of x; the alias' cotangent is added inside the adjoint kernel"""
+    return _ReflectPad.apply(x, pad, passthrough)
 
 
 class _ToPM(torch.autograd.Function):

@@ -228,8 +228,8 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x):
         cb = self.conv_block
-        x, xr = Fh.fanout(x, 2)
-        y = run_conv(Fh.reflect_pad(x, 1), cb[1], cb[2], cb[3])
+        xp, xr = Fh.reflect_pad(x, 1, passthrough=True)     # the skip's cotangent is added inside the pad's adjoint kernel
+        y = run_conv(xp, cb[1], cb[2], cb[3])
         return run_conv(Fh.reflect_pad(y, 1), cb[5], cb[6], None, res=xr)     # out = x + conv_block(x)
 
 

@@ -253,9 +253,14 @@ def conv_forward_stats(d, x, w_fwd, bias, y, G, eps, run_mean=None, run_var=None
     return mean, rstd
 
 
-def conv_dgrad(d, dy, w_bwd, bias, dx):
+def conv_dgrad(d, dy, w_bwd, bias, dx, addend=None):
+    """addend: a map like dx (may be a channel slice) added to the input gradient in the same pass (rdfc_conv2d_dgrad_add)"""
     with _Timed('igemm_kernel (conv fwd / dgrad)', d):
-        _chk(lib().rdfc_conv2d_dgrad(C.byref(d), _p(dy), _p(w_bwd), _p(bias), _p(dx), _st()), 'rdfc_conv2d_dgrad')
+        if addend is None:
+            _chk(lib().rdfc_conv2d_dgrad(C.byref(d), _p(dy), _p(w_bwd), _p(bias), _p(dx), _st()), 'rdfc_conv2d_dgrad')
+        else:
+            assert bias is None and addend.dtype == dx.dtype and addend.shape == dx.shape
+            _chk(lib().rdfc_conv2d_dgrad_add(C.byref(d), _p(dy), _p(w_bwd), _p(addend), ld(addend), _p(dx), _st()), 'rdfc_conv2d_dgrad_add')
     return dx
 
 
@@ -315,12 +320,17 @@ def reflect_pad(src, pad):
     return out
 
 
-def reflect_pad_adjoint(dpad, pad):
+def reflect_pad_adjoint(dpad, pad, addend=None):
     N, Hp, Wp, Cc = dpad.shape
     assert dpad.is_contiguous()
     H, W = Hp - 2 * pad, Wp - 2 * pad
     out = torch.empty(N, H, W, Cc, dtype=dpad.dtype, device=dpad.device)
-    _chk(lib().rdfc_reflect_pad_adjoint(_p(dpad), _p(out), N, H, W, Cc, pad, dt(dpad), _st()), 'rdfc_reflect_pad_adjoint')
+    if addend is None:
+        _chk(lib().rdfc_reflect_pad_adjoint(_p(dpad), _p(out), N, H, W, Cc, pad, dt(dpad), _st()), 'rdfc_reflect_pad_adjoint')
+    else:
+        assert addend.dtype == dpad.dtype and tuple(addend.shape) == (N, H, W, Cc)
+        _chk(lib().rdfc_reflect_pad_adjoint_add(_p(dpad), _p(addend), ld(addend), _p(out), N, H, W, Cc, pad, dt(dpad), _st()),
+             'rdfc_reflect_pad_adjoint_add')
     return out
 
 

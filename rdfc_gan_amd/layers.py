@@ -67,11 +67,11 @@ def _count_batch(norm, k):
 _spec_cache = {}
 
 
-def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
+def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False, passthrough=False):
     """conv (nn.Conv2d | nn.ConvTranspose2d) [+ norm (BatchNorm2d | InstanceNorm2d)] [+ res] [+ act module]"""
     # the static description of the block is the same on every call of the same modules: cache it (a train step runs
     # ~180 blocks, each used to rebuild its ConvSpec from a dozen attribute lookups)
-    key = (id(conv), id(norm), id(act), out_f32, BN_STAT_REPEAT, getattr(act, 'negative_slope', None), BN_GROUP_REPEATS)
+    key = (id(conv), id(norm), id(act), out_f32, BN_STAT_REPEAT, getattr(act, 'negative_slope', None), BN_GROUP_REPEATS, passthrough)
     hit = _spec_cache.get(key)
     if hit is not None and hit[0] is conv and hit[1] is norm and hit[2] is act:
         _c, _n, _a, spec, nname, prelu = hit
@@ -107,7 +107,8 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False):
     elif BN_STAT_REPEAT != 1:
         momentum = 1.0 - (1.0 - momentum) ** BN_STAT_REPEAT
     spec = ConvSpec(k, s, p, transposed, conv.output_padding[0] if transposed else 0, nname, aname, slope,
-                    eps=getattr(norm, 'eps', 1e-5), momentum=momentum, out_f32=out_f32, dil=conv.dilation[0], group_momenta=gmom)
+                    eps=getattr(norm, 'eps', 1e-5), momentum=momentum, out_f32=out_f32, dil=conv.dilation[0], group_momenta=gmom,
+                    passthrough=passthrough)
     gamma = beta = rm = rv = None
     training = True
     if nname == 'bn':
@@ -172,8 +173,9 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        x, xr = Fh.fanout(x, 2)                     # conv1 and the identity / downsample path
-        y = run_conv(x, self.conv1, self.bn1, self.relu)
+        # conv1 and the identity / downsample path share x: conv1's block hands out an alias whose cotangent its input-gradient
+        # kernel adds in its epilogue (no separate summation pass)
+        y, xr = run_conv(x, self.conv1, self.bn1, self.relu, passthrough=True)
         idt = xr if self.downsample is None else run_conv(xr, self.downsample[0], self.downsample[1], None)
         return run_conv(y, self.conv2, self.bn2, self.relu, res=idt)
 

@@ -701,3 +701,27 @@ def test_nlspn_scatter_keeps_nonfinite_and_tiny_cotangents():
     gn[0, 0, 5, 33] = float('nan')
     (gb,) = torch.autograd.grad(out, feat, gn)
     assert torch.isnan(gb).any() and not torch.isnan(gb[0, 0, :, :8]).any()
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize('case', [(3, 29, 38, 64, 64, 3, 1, 1), (2, 30, 76, 64, 128, 3, 2, 1), (2, 20, 128, 64, 128, 1, 2, 0),
+                                  (2, 16, 18, 64, 128, 4, 2, 1), (2, 12, 14, 24, 40, 3, 1, 1)], ids=lambda c: 'x'.join(map(str, c)))
+def test_dgrad_with_addend_and_reflect_adjoint_with_addend(case, dtype):
+    """rdfc_conv2d_dgrad_add == input gradient + addend (the LDS-DMA kernels add in their epilogue, other shapes run a sum pass);
+    the addend may be a channel slice of a wider map.  Same for the reflection pad's adjoint."""
+    h = hip()
+    N, H, W, Ci, Co, k, s, p = case
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    w = rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5)
+    _, wb = h.pack_weight(w.to(DEV), dtype)
+    gy = to_pm(rnd(N, Co, Ho, Wo, seed=4), dtype)
+    add = to_pm(rnd(N, Ci, H, W, seed=5), dtype, ld_extra=8)
+    d = h.conv_desc((N, H, W, Ci), Co, k, s, p, ldx=Ci, ldy=Co, dtype=h.dt(gy))
+    plain = h.conv_dgrad(d, gy, wb, None, torch.empty(N, H, W, Ci, dtype=dtype, device=DEV))
+    fused = h.conv_dgrad(d, gy, wb, None, torch.empty(N, H, W, Ci, dtype=dtype, device=DEV), addend=add)
+    ref = plain.float() + add.float()
+    assert rel_err(fused.float(), ref) < {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+    g = to_pm(rnd(N, Ci, H + 4, W + 4, seed=6), dtype)
+    a = h.reflect_pad_adjoint(g, 2)
+    b = h.reflect_pad_adjoint(g, 2, addend=add)
+    assert rel_err(b.float(), a.float() + add.float()) < {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
