@@ -233,10 +233,10 @@ class _ConvBlock(torch.autograd.Function):
             d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
                               act=epi_act, slope=spec.slope, out_f32=out_f32)
             G_ = N if spec.norm == 'in' else 1
-            if live_stats and gm is None and _DETERMINISTIC and hip.conv_stats_nchunk(d, G_) > 0:
+            if live_stats and _DETERMINISTIC and hip.conv_stats_nchunk(d, G_) > 0:
                 upd = spec.norm == 'bn' and run_mean is not None
                 fused = hip.conv_forward_stats(d, x, wf, bias, y, G_, spec.eps, run_mean if upd else None,
-                                               run_var if upd else None, spec.momentum)
+                                               run_var if upd else None, spec.momentum, group_momenta=gm)
             else:
                 hip.conv_forward(d, x, wf, bias, y)
         else:   # equivalent conv maps the (larger) output map onto x

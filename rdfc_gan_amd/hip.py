@@ -236,15 +236,24 @@ def conv_stats_nchunk(d, G):
     return lib().rdfc_conv_stats_nchunk(C.byref(d), int(G))
 
 
-def conv_forward_stats(d, x, w_fwd, bias, y, G, eps, run_mean=None, run_var=None, momentum=0.1):
+def conv_forward_stats(d, x, w_fwd, bias, y, G, eps, run_mean=None, run_var=None, momentum=0.1, group_momenta=None):
     """conv forward with the normalisation statistics fused into its epilogue (conv_stats_nchunk(d, G) must be > 0).
-    -> mean[G,Co], rstd[G,Co]"""
+    -> mean[G,Co], rstd[G,Co].  group_momenta (BatchNorm over len(group_momenta) stacked batches; call with G = 1): the
+    per-tile rows are ordered by image, so the stacked batches are contiguous row ranges of the one-group layout."""
     n = conv_stats_nchunk(d, G)
     assert n > 0
     partial = torch.empty(G * n * 2 * d.Co, dtype=torch.float32, device=x.device)
     with _Timed('igemm_kernel (conv fwd / dgrad)', d):
         _chk(lib().rdfc_conv2d_forward_stats(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial), int(G), _st()),
              'rdfc_conv2d_forward_stats')
+    if group_momenta is not None:
+        Gs = len(group_momenta)
+        assert G == 1 and n % Gs == 0 and d.N % Gs == 0
+        mean = torch.empty(Gs, d.Co, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(Gs, d.Co, dtype=torch.float32, device=x.device)
+        _chk(lib().rdfc_norm_finalize_seq(_p(partial), n // Gs, _p(mean), _p(rstd), Gs, d.N * d.Ho * d.Wo // Gs, d.Co, dt(x), _f(eps),
+                                          _p(run_mean), _p(run_var), _momenta(group_momenta), _st()), 'rdfc_norm_finalize_seq')
+        return mean, rstd
     mean = torch.empty(G, d.Co, dtype=torch.float32, device=x.device)
     rstd = torch.empty(G, d.Co, dtype=torch.float32, device=x.device)
     P = d.N * d.Ho * d.Wo // G

@@ -521,8 +521,9 @@ def test_device_pepper_mask_distribution_and_determinism():
 
 # ---- round 2: stacked-batch BatchNorm, fan-out sums, small elementwise operators ---------------------------------------
 @pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize('chan', [(16, 32), (64, 64)], ids=['16to32', '64to64'])       # 64 -> 64: the LDS-DMA kernel (fused statistics under RDFC_FUSED_STATS=1)
 @pytest.mark.parametrize('repeats', [(1, 2), (1, 1), (1, 1, 2)], ids=str)
-def test_bn_over_stacked_batches_equals_separate_calls(dtype, repeats):
+def test_bn_over_stacked_batches_equals_separate_calls(dtype, repeats, chan):
     """conv + BatchNorm(train) + LeakyReLU over G stacked batches (layers.bn_groups) == G separate calls of the block:
     outputs, running statistics (advanced once per group, in order, group g standing for repeats[g] identical forwards),
     num_batches_tracked, input / weight / affine gradients."""
@@ -530,7 +531,7 @@ def test_bn_over_stacked_batches_equals_separate_calls(dtype, repeats):
     from rdfc_gan_amd import functional as Fh, layers
     Fh.set_compute_dtype(dtype)
     torch.manual_seed(0)
-    G, n, Ci, Co, H, W = len(repeats), 2, 16, 32, 11, 13
+    G, n, (Ci, Co), H, W = len(repeats), 2, chan, 11, 13
 
     def make():
         torch.manual_seed(1)

@@ -16,7 +16,8 @@ VARIANTS = [
     ('RDFC_GLDS', '3', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and bf16'),   # 8-wave 128 co x 256 px workgroups
     ('RDFC_GLDS', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and bf16'),   # register-staged predecessors
     ('RDFC_WGRAD_GLDS_NINE', '1', 'test_conv_fwd_dgrad_wgrad and bf16'),            # all nine taps per workgroup
-    ('RDFC_FUSED_STATS', '1', 'fused_statistics'),                                  # conv-epilogue statistics
+    ('RDFC_FUSED_STATS', '1', 'fused_statistics or stacked_batches'),               # conv-epilogue statistics (also under stacked-batch BatchNorm)
+    ('RDFC_WGRAD_GLDS', '5', 'test_conv_fwd_dgrad_wgrad and bf16'),                 # 128 x 128 eight-wave weight-gradient tile
     ('RDFC_NORM_ONESTAGE', '1', 'test_norm_fwd_bwd or onestage'),                   # f64-atomic reductions
 ]
 
