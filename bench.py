@@ -135,6 +135,8 @@ def main():
     ap.add_argument('--full-objective', action='store_true', help="--label-net plus G_normal (decoder on HIP behind the tests' stock-PyTorch "
                     'stand-in encoder): every term of upstream loss_G, six networks, four optimizers (not the headline workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rccl-self-test', action='store_true', help='N = 1 only: initialise a one-rank RCCL process group and send the step '
+                    'through every collective of the data-parallel path (bucketed all-reduces, loss all-reduces); adds the comm block')
     ap.add_argument('--no-sync-losses', action='store_true', help='do not read the losses back every step (the host then runs ahead '
                     'of the GPU; NOT the reference API behaviour -- the default run reports this variant as an extra key)')
     ap.add_argument('--no-kernel-events', action='store_true')
@@ -155,8 +157,16 @@ def main():
         local = int(os.environ['RDFC_BENCH_DEVICE'])
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    from rdfc_gan_amd import functional as Fh
+    if os.environ.get('RDFC_RESERVE_STREAMS', '1') != '0':
+        Fh.reserve_streams(dev)             # the compute streams take their hardware queues before RCCL's streams exist
+    if world > 1 or a.rccl_self_test:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if a.rccl_self_test:          # one rank, every collective of the step through RCCL all the same (rdfc_gan_amd/optim.py dp_active)
+            assert world == 1
+            os.environ['RDFC_DP_FORCE'] = '1'
+            for k, v in (('MASTER_PORT', '29533'), ('RANK', '0'), ('WORLD_SIZE', '1')):
+                os.environ.setdefault(k, v)
         backend = os.environ.get('RDFC_BENCH_BACKEND', 'nccl')
         dist.init_process_group(backend, **(dict(device_id=dev) if backend == 'nccl' else {}))
     assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
@@ -174,7 +184,7 @@ def main():
         from rdfc_gan_amd.normal_net import NNET
         a.label_net = True
         kw = dict(normal_net=NNET(a.height, a.width, encoder=StandInEncoder()), out_height=a.height, out_width=a.width)
-    model = RDFCGAN(dev, world > 1, model_cfg(a.nlspn), is_train=True, exact_schedule=a.exact_schedule, use_label_net=a.label_net, **kw)
+    model = RDFCGAN(dev, world > 1 or a.rccl_self_test, model_cfg(a.nlspn), is_train=True, exact_schedule=a.exact_schedule, use_label_net=a.label_net, **kw)
     model.train()
     batches = [synth_batch(a.batch, a.height, a.width, 1234 + rank * 100 + i, dev) for i in range(2)]
 
@@ -258,7 +268,7 @@ def main():
         hip.PROFILE = None
         Fh.set_multi_stream(True)
     comm = None
-    if world > 1:
+    if world > 1 or a.rccl_self_test:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)

@@ -124,6 +124,29 @@ def net_stream(device):
     return s
 
 
+def wgrad_stream(device):
+    """the weight-gradient stream of `device` when weight gradients are launched on one (None otherwise)"""
+    if not (_WGRAD_STREAM and _multi_stream) or torch.device(device).type != 'cuda':
+        return None
+    return _side_stream(torch.device(device))[0]
+
+
+def reserve_streams(device):
+    """create the step's HIP streams NOW and put one launch on each.  The HIP runtime binds a stream to one of its
+    GPU_MAX_HW_QUEUES (4) hardware queues at the stream's first use, round-robin; the step uses four (default, weight
+    gradients, depth branch, B->A half).  Called before torch.distributed.init_process_group -- whose RCCL communicator brings
+    streams of its own -- it gives the four compute streams a queue each; called after, two of them can end up sharing one."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    for s in (torch.cuda.default_stream(device), _side_stream(device)[0], branch_stream(device), net_stream(device)):
+        with torch.cuda.stream(s):
+            torch.zeros(64, device=device)
+    torch.cuda.synchronize(device)
+
+
 def helper_streams(device):
     """the helper streams that exist on `device` (weight-gradient, branch, net): what a consumer of the gradients on yet
     another stream has to wait for"""

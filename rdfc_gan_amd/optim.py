@@ -9,6 +9,8 @@ Parameters keep their nn.Parameter identity and state_dict keys: their storage i
 re-pointed into the flat buffer, and `.grad` is a persistent view of the flat gradient
 buffer (autograd accumulates into it in place).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -124,31 +126,49 @@ class FlatAdam(torch.optim.Optimizer):
 
     @staticmethod
     def _distributed():
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return dp_active()
 
     def all_reduce_bucket_async(self, i):
-        """start the all-reduce of bucket i (idempotent within a step).  The communication stream waits for the current
-        stream and for every helper stream (weight gradients are launched on one of their own), not the other way round:
-        nothing on the compute streams waits here."""
+        """start the all-reduce of bucket i (idempotent within a step).  Nothing on the compute streams waits here: the
+        collective is issued (async_op) from the weight-gradient stream after that stream has been made to wait for the
+        current one and the other helper streams -- its later launches wait for the current stream anyway -- so the process
+        group's own stream picks the dependencies up and no further HIP stream is needed.  (The runtime multiplexes streams
+        onto GPU_MAX_HW_QUEUES = 4 hardware queues and the step already uses four: every further stream shares a queue with
+        a compute stream and its waits stall that stream.  One-rank RCCL runs of bench.py: 38.7 ms per step without a process
+        group, 41.3 with one and a communication stream per optimizer, 40.3-40.9 once the compute streams are bound to their
+        queues first -- functional.reserve_streams -- with either scheme)
+        RDFC_DP_COMM=stream keeps the round-1 scheme (a communication stream per optimizer) for A/B runs."""
         if not self._distributed() or i in self._started:
             return
         self._started.add(i)
         a, b = self._buckets[i]
         view = self.flat_grad[a:b]
-        if self.flat_grad.is_cuda:
+        if not self.flat_grad.is_cuda:
+            dist.all_reduce(view)             # gloo / CPU tests
+            return
+        dev = self.flat_grad.device
+        cur = torch.cuda.current_stream(dev)
+        if _DP_COMM == 'stream':
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
             cs = self._comm_stream
-            cs.wait_stream(torch.cuda.current_stream())
-            for s_ in Fh.helper_streams(self.flat_grad.device):
+            cs.wait_stream(cur)
+            for s_ in Fh.helper_streams(dev):
                 cs.wait_stream(s_)
             with torch.cuda.stream(cs):
                 dist.all_reduce(view)
             ev = torch.cuda.Event()
             ev.record(cs)
             self._pending.append(ev)
-        else:
-            dist.all_reduce(view)             # gloo / CPU tests
+            return
+        issue = Fh.wgrad_stream(dev) or cur
+        if issue != cur:
+            issue.wait_stream(cur)
+        for s_ in Fh.helper_streams(dev):
+            if s_ != issue and s_ != cur:
+                issue.wait_stream(s_)
+        with torch.cuda.stream(issue):
+            self._pending.append(dist.all_reduce(view, async_op=True))
 
     def all_reduce_grads_async(self):
         """start the all-reduce of every bucket that has not been started in this step.  No-op when not distributed."""
@@ -158,8 +178,12 @@ class FlatAdam(torch.optim.Optimizer):
             self.all_reduce_bucket_async(i)
 
     def wait_grads(self):
-        for ev in self._pending:
-            torch.cuda.current_stream().wait_event(ev)
+        """the current stream waits for the bucket all-reduces started so far"""
+        for w in self._pending:
+            if isinstance(w, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(w)
+            else:
+                w.wait()
         self._pending = []
 
     @torch.no_grad()
@@ -222,6 +246,18 @@ class FlatAdam(torch.optim.Optimizer):
                                      '(coupled L2 decay is not implemented by rdfc_adam_step)')
             if k_ != 'params':
                 self.param_groups[0][k_] = v
+
+
+_DP_COMM = os.environ.get('RDFC_DP_COMM', 'side')
+
+
+def dp_active():
+    """whether the step exchanges gradients / losses: a process group with more than one rank -- or any initialised group
+    under RDFC_DP_FORCE=1, which sends a one-rank job through the very same collectives (how the RCCL path is exercised on a
+    one-GPU box: tests/test_dp_gpu.py, bench.py --rccl-self-test)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('RDFC_DP_FORCE') == '1'
 
 
 def broadcast_module_state(modules, src=0):

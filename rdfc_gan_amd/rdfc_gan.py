@@ -16,7 +16,9 @@ Differences from upstream that do not change results:
     second time with the very same batch statistics, which is reproduced exactly by one
     update with momentum 1-(1-m)^2 (`exact_schedule=True` runs upstream's literal schedule).
   * the 23 per-key `all_reduce` + `.item()` calls of Base.reduce_loss (base.py:121-132)
-    are one packed all-reduce and one device->host copy.
+    are one packed all-reduce and one device->host copy per loss group (G, D_A, D_B), posted as soon as the group's
+    forward has produced the values (`_LossReadback`): the host gets this step's floats while the GPU still runs the
+    discriminators' backward passes and the Adam updates, and starts enqueueing the next step under them.
   * per-step `dist.barrier()` (rdfc_gan.py:337-338) is dropped (the all-reduces order ranks).
 """
 import contextlib
@@ -34,7 +36,7 @@ from .discriminator import build_discriminator
 from .gan_loss import GANLoss, L1_loss
 from .generator import build_generator
 from .init_weights import init_weights
-from .optim import FlatAdam, broadcast_module_state
+from .optim import FlatAdam, broadcast_module_state, dp_active
 
 
 def norm_normalize(norm_out):
@@ -44,6 +46,59 @@ def norm_normalize(norm_out):
 
 
 _NET_STREAMS = os.environ.get('RDFC_NET_STREAMS', '1') != '0'
+
+
+class _LossReadback:
+    """base.py:121-132 (mean over ranks, python floats) without draining the queue: every post() packs one group of 0-d
+    losses on the stream that produced them, copies it into pinned host memory and records an event; collect() waits for
+    those events only.  Data parallel: the groups are packed as they come, but averaged by ONE all-reduce at the end of the
+    step -- a collective issued on a compute stream in mid-step would queue behind the gradient buckets on the process
+    group's stream and hold the compute stream until every weight gradient before it has finished."""
+    SLOTS = 64
+
+    def __init__(self, device):
+        self.device = device
+        self.host = torch.empty(self.SLOTS, dtype=torch.float32).pin_memory() if device.type == 'cuda' else None
+        self.posts, self.used = [], 0
+
+    def begin(self):
+        self.posts, self.used = [], 0
+
+    def post(self, stats):
+        keys = list(stats)
+        packed = torch.stack([stats[k].detach().float().reshape(()) for k in keys])
+        if self.host is None or dp_active():
+            ev = None
+            if packed.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+            self.posts.append((keys, packed, ev))
+            return
+        assert self.used + len(keys) <= self.SLOTS
+        dst = self.host[self.used:self.used + len(keys)]
+        dst.copy_(packed, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.posts.append((keys, dst, ev))
+        self.used += len(keys)
+
+    def collect(self, order):
+        got = {}
+        if dp_active():
+            for _, _, ev in self.posts:
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)          # a group packed on another stream
+            keys = [k for ks, _, _ in self.posts for k in ks]
+            packed = torch.cat([v for _, v, _ in self.posts]) / dist.get_world_size()
+            dist.all_reduce(packed)
+            got = dict(zip(keys, packed.tolist()))
+        else:
+            for keys, vals, ev in self.posts:
+                if ev is not None:
+                    ev.synchronize()
+                got.update(zip(keys, vals.tolist()))
+        self.posts = []
+        return {k: got[k] for k in order}
 
 
 def draw_pepper_mask(shape, snr=0.98, p=0.9):
@@ -442,10 +497,12 @@ class RDFCGAN:
         # lambda factors folded into one f32 product per term ((x * lambda_L1) * 5 upstream: at most one rounding apart)
         loss_G, terms = Fh.combine_losses([(gan_A2B, 1.0), (cyc_A2B, lam_A), (cyc_B2A, lam_B), (gan_B2A, 1.0),
                                            (l1_A2B, lam_1 * 5), (l1_B2A, lam_1 * 3)])
+        stats = dict(loss_G=loss_G, loss_G_A2B=terms[0], loss_G_B2A=terms[3], loss_B2A_L1=terms[5],
+                     loss_A2B_L1=terms[5],             # upstream logs B2A under this key (rdfc_gan.py:276)
+                     loss_cycle_A=terms[1], loss_cycle_B=terms[2])
+        self._post_losses(stats)
         self._backward(loss_G)
-        return dict(loss_G=loss_G, loss_G_A2B=terms[0], loss_G_B2A=terms[3], loss_B2A_L1=terms[5],
-                    loss_A2B_L1=terms[5],             # upstream logs B2A under this key (rdfc_gan.py:276)
-                    loss_cycle_A=terms[1], loss_cycle_B=terms[2])
+        return stats
 
     def backward_G(self):
         if self._batched():
@@ -473,12 +530,13 @@ class RDFCGAN:
         loss_G = loss_G_A2B + loss_cycle_A2B + loss_cycle_B2A + loss_G_B2A + loss_A2B_L1 + loss_B2A_L1
         for v in list(extra_A.values()) + list(extra_B.values()):               # :252-267
             loss_G = loss_G + v
-        self._backward(loss_G)
         stats = dict(loss_G=loss_G, loss_G_A2B=loss_G_A2B, loss_G_B2A=loss_G_B2A, loss_B2A_L1=loss_B2A_L1,
                      loss_A2B_L1=loss_B2A_L1,          # upstream logs B2A under this key (rdfc_gan.py:276)
                      loss_cycle_A=loss_cycle_A2B, loss_cycle_B=loss_cycle_B2A)
         stats.update(extra_A)
         stats.update(extra_B)
+        self._post_losses(stats)
+        self._backward(loss_G)
         return stats
 
     def _label_and_normal_terms(self, tag, label_list, normal, lam_1):
@@ -503,7 +561,16 @@ class RDFCGAN:
             out.update({f'floor_loss_{tag}': v[1] * lam_1, f'wall_loss_{tag}': v[2] * lam_1, f'ceiling_loss_{tag}': v[3] * lam_1})
         return out
 
-    def backward_D_basic(self, model_D, real, fake):
+    def _post_losses(self, stats):
+        """hand a finished group of loss values to the step's read-back (no-op outside optimize_parameters(sync_losses=True))"""
+        rb = self.__dict__.get('_rb_active')
+        if rb is not None:
+            rb.post(stats)
+
+    def backward_D_basic(self, model_D, real, fake, names=None):
+        """names: the three logging keys (loss, real, fake) under which the values go to the step's loss read-back before the
+        backward pass is enqueued"""
+        post = (lambda d, r, f: self._post_losses({names[0]: d, names[1]: r, names[2]: f})) if names else (lambda *a: None)
         if self._batched():
             # D(real) then D(fake.detach()) as one pass over [real | fake]: BatchNorm statistics (and running-statistics
             # updates, in upstream's order) per half
@@ -513,11 +580,13 @@ class RDFCGAN:
             loss_D_real = self.criterionGAN(pred_real, True)
             loss_D_fake = self.criterionGAN(pred_fake, False)
             loss_D, _ = Fh.combine_losses([(loss_D_real, 1.0), (loss_D_fake, 1.0)], post=0.5)    # (real + fake) * 0.5
+            post(loss_D, loss_D_real, loss_D_fake)
             self._backward(loss_D)
             return loss_D_real, loss_D_fake, loss_D
         loss_D_real = self.criterionGAN(model_D(real), True)
         loss_D_fake = self.criterionGAN(model_D(fake.detach()), False)
         loss_D = (loss_D_real + loss_D_fake) * 0.5
+        post(loss_D, loss_D_real, loss_D_fake)
         self._backward(loss_D)
         return loss_D_real, loss_D_fake, loss_D
 
@@ -531,11 +600,11 @@ class RDFCGAN:
             loss.backward(gradient=seed)
 
     def backward_D_A2B(self):
-        r, f, d = self.backward_D_basic(self.disc_A, self.real_B, self.fake_B)
+        r, f, d = self.backward_D_basic(self.disc_A, self.real_B, self.fake_B, names=('loss_D_A', 'loss_D_A_real', 'loss_D_A_fake'))
         return dict(loss_D_A=d, loss_D_A_real=r, loss_D_A_fake=f)
 
     def backward_D_B2A(self):
-        r, f, d = self.backward_D_basic(self.disc_B, self.real_A, self.fake_A)
+        r, f, d = self.backward_D_basic(self.disc_B, self.real_A, self.fake_A, names=('loss_D_B', 'loss_D_B_real', 'loss_D_B_fake'))
         return dict(loss_D_B=d, loss_D_B_real=r, loss_D_B_fake=f)
 
     # ---- HIP-graph mode: the step is captured once as three graphs (G step | D step | Adam) and replayed; the
@@ -682,6 +751,20 @@ class RDFCGAN:
         if getattr(self, '_graph_mode', False):
             return self._optimize_graphed(sync_losses)
         loss_stats = {}
+        rb = None
+        if sync_losses:
+            rb = self.__dict__.get('_rb')
+            if rb is None or rb.device != self.device:
+                rb = self._rb = _LossReadback(self.device)
+            rb.begin()
+        self._rb_active = rb
+        try:
+            self._enqueue_step(loss_stats)
+        finally:
+            self._rb_active = None
+        return rb.collect(list(loss_stats)) if sync_losses else loss_stats
+
+    def _enqueue_step(self, loss_stats):
         self.forward()
         self.set_requires_grad([self.disc_A, self.disc_B], False)
         self.optimizer_G.zero_grad()
@@ -711,13 +794,12 @@ class RDFCGAN:
         if self.use_label_net:
             self.optimizer_Label.step()
         self.optimizer_D.step()
-        return self.reduce_loss(loss_stats) if sync_losses else loss_stats
 
     def reduce_loss(self, loss):
         """base.py:121-132 semantics (mean over ranks, python floats) with one collective and one D2H copy"""
         keys = list(loss)
         packed = torch.stack([loss[k].detach().float().reshape(()) for k in keys])
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dp_active():
             packed = packed / dist.get_world_size()
             dist.all_reduce(packed)
         return dict(zip(keys, packed.tolist()))

@@ -24,6 +24,19 @@ def test_two_ranks_stay_identical(full):
         assert "optimizers ['D', 'G', 'Nor', 'label']" in out, out[-3000:]
 
 
+def test_rccl_one_rank_step_equals_plain_step():
+    """every collective of the step through RCCL itself (one rank on the one GPU, RDFC_DP_FORCE): broadcast, the bucketed
+    all-reduces on the communication stream, the packed loss all-reduces; results must match the step without a process group
+    (tools/dp_smoke.py: first-step losses bit for bit, parameters after two steps within the run-to-run bound of the float atomics)"""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29521', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0', DP_SMOKE_BACKEND='nccl', DP_SMOKE_FULL='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'dp_smoke.py')], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert 'step-1 loss difference to the step without a process group = 0.000e+00' in out, out[-3000:]
+
+
 def test_bench_multi_rank_control_flow():
     """bench.py's N > 1 path (barriers, max over ranks, the extra isolated step on every rank, one JSON line from rank 0) with two
     ranks on the one test GPU over gloo (RDFC_BENCH_DEVICE / RDFC_BENCH_BACKEND hooks; the driver's runs use RCCL, one GPU per rank)"""

@@ -1,6 +1,10 @@
 """Two data-parallel ranks on ONE GPU over gloo (RCCL needs a GPU per rank): exercises the step's collectives, the side
 streams and FlatAdam's bucket exchange end to end; after two steps the replicas must hold identical parameters.
-Launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 tools/dp_smoke.py"""
+Launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 tools/dp_smoke.py
+
+DP_SMOKE_BACKEND=nccl with ONE rank (RDFC_DP_FORCE=1 is set here): the same step with every collective going through RCCL on the
+real device (broadcast, bucketed all-reduces on the communication stream, packed loss all-reduces); its parameters after two steps
+must equal those of the same step run without a process group, bit for bit."""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,9 +16,15 @@ from rdfc_gan_amd import functional as Fh
 from rdfc_gan_amd.rdfc_gan import RDFCGAN
 
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-dist.init_process_group('gloo')
+backend = os.environ.get('DP_SMOKE_BACKEND', 'gloo')
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
+if backend == 'nccl':
+    assert world == 1, 'RCCL wants one GPU per rank; this box has one'
+    os.environ['RDFC_DP_FORCE'] = '1'
+    dist.init_process_group('nccl', device_id=dev)
+else:
+    dist.init_process_group('gloo')
 Fh.set_compute_dtype(torch.bfloat16)
 torch.manual_seed(100 + rank)           # different initial weights per rank: the broadcast must equalise them
 random.seed(rank); np.random.seed(rank)
@@ -25,14 +35,45 @@ if full:
     from cases import StandInEncoder
     from rdfc_gan_amd.normal_net import NNET
     kw = dict(use_label_net=True, normal_net=NNET(64, 80, encoder=StandInEncoder()), out_height=64, out_width=80)
-m = RDFCGAN(dev, True, bench.model_cfg(False), is_train=True, **kw)
-m.train()
-for it in range(2):
-    m.set_input(bench.synth_batch(2, 64, 80, 50 + 10 * rank + it, dev))
-    losses = m.optimize_parameters()
-    assert all(np.isfinite(v) for v in losses.values()), losses
-torch.cuda.synchronize()
+
+
+def two_steps(distributed):
+    torch.manual_seed(100 + rank)
+    random.seed(rank); np.random.seed(rank)
+    m = RDFCGAN(dev, distributed, bench.model_cfg(False), is_train=True, **kw)
+    m.train()
+    trace = []
+    for it in range(2):
+        m.set_input(bench.synth_batch(2, 64, 80, 50 + 10 * rank + it, dev))
+        losses = m.optimize_parameters()
+        assert all(np.isfinite(v) for v in losses.values()), losses
+        trace.append(losses)
+    torch.cuda.synchronize()
+    return m, trace
+
+
+m, trace = two_steps(True)
+losses = trace[-1]
 flat = torch.cat([o.flat for o in m.optimizers.values()]).float()
+if backend == 'nccl':
+    from rdfc_gan_amd.optim import dp_active
+    assert dp_active() and dist.get_backend() == 'nccl'
+    started = {n: sorted(o._started) for n, o in m.optimizers.items()}
+    assert all(started[n] == list(range(len(o._buckets))) for n, o in m.optimizers.items()), started     # every bucket went out
+    os.environ['RDFC_DP_FORCE'] = '0'
+    m2, trace2 = two_steps(False)
+    flat2 = torch.cat([o.flat for o in m2.optimizers.values()]).float()
+    # Step 1's losses depend on the initial weights only (the one-rank broadcast must leave them alone): equal bit for bit.
+    # After the updates the two runs differ by what the weight gradients' split-K float atomics differ between ANY two runs
+    # (an Adam update of a noise-level gradient can flip: 2 lr per step), so the parameters are compared against that bound.
+    d, mean = (flat - flat2).abs().max().item(), (flat - flat2).abs().mean().item()
+    first = max(abs(trace[0][k] - trace2[0][k]) for k in trace[0])
+    last = max(abs(trace[1][k] - trace2[1][k]) / max(1.0, abs(trace2[1][k])) for k in trace[1])
+    print(f'dp_smoke: RCCL one-rank step, buckets {started}; step-1 loss difference to the step without a process group = {first:.3e}; '
+          f'parameters after 2 steps: max difference {d:.3e}, mean {mean:.3e}; step-2 losses relative {last:.3e}')
+    assert first == 0.0 and d <= 1e-2 and mean <= 1e-3 and last <= 2e-2, (first, d, mean, last)
+    dist.destroy_process_group()
+    sys.exit(0)
 mine = flat.cpu()
 other = [torch.empty_like(mine) for _ in range(world)]
 dist.all_gather(other, mine)
