@@ -77,6 +77,19 @@ int rdfc_pack_weight(const float *w_oihw, void *w_fwd, void *w_bwd, int O, int I
  * the weight gradient accumulates straight into the parameter's .grad and needs no unpack). */
 int rdfc_pack_weight_ohwi(const float *w_ohwi, void *w_fwd, void *w_bwd, int O, int I, int KH, int KW,
                           int dtype, float scale, void *stream);
+/* Every weight of a network in ONE launch (after the optimizer step: lib/models/rdfc_gan.py:324-334 runs optimizer.step(), the
+ * next forward then needs every operand again).  jobs: DEVICE array of njobs descriptors sorted by block0; job j owns the
+ * workgroups [block0_j, block0_{j+1}): one per (tap, 64-row tile of O, 64-column tile of I), nblocks in all.  Source element
+ * (o, t, i) sits at w[o * so + t * st + i * si] (OIHW: so = I T, si = T, st = 1; [O][T][I]: so = T I, st = I, si = 1). */
+typedef struct rdfc_pack_job {
+    const float *w;             /* f32 master weight                                   */
+    void *w_fwd, *w_bwd;        /* as in rdfc_pack_weight (either may be NULL)           */
+    int32_t O, I, T;            /* T = KH * KW                                          */
+    int32_t so, st, si;         /* source strides (elements)                            */
+    float   scale;
+    int32_t block0;             /* first workgroup of this job                          */
+} rdfc_pack_job;
+int rdfc_pack_weights_batch(const rdfc_pack_job *jobs, int njobs, int nblocks, int dtype, void *stream);
 /* dw_packed f32 [O][KH*KW][I] -> grad_oihw f32 [O][I][KH][KW] = scale * dw_packed (overwrite) */
 int rdfc_unpack_wgrad(const float *dw_packed, float *grad_oihw, int O, int I, int KH, int KW,
                       float scale, void *stream);

@@ -59,6 +59,50 @@ __global__ void pack_weight_ohwi_kernel(const float *__restrict__ w, T *__restri
     }
 }
 
+// all weights of a network in one launch: workgroup -> (job, tap, 64 x 64 tile of the [O][I] matrix of that tap); the tile goes
+// through LDS so that the source rows, the w_fwd rows (along I) and the w_bwd rows (along O) are all read / written as lines
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const rdfc_pack_job *__restrict__ jobs, int njobs) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = njobs - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                                // last job whose block0 <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const rdfc_pack_job j = jobs[lo];
+    const int tiles_i = (j.I + 63) >> 6, tiles_o = (j.O + 63) >> 6;
+    int local = b - j.block0;
+    const int ti = local % tiles_i;
+    local /= tiles_i;
+    const int to = local % tiles_o, t = local / tiles_o;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    T *wf = (T *)j.w_fwd, *wb = (T *)j.w_bwd;
+    {
+        const int i = ti * 64 + tx;
+#pragma unroll 4
+        for (int r = ty; r < 64; r += 4) {
+            const int o = to * 64 + r;
+            float v = 0.f;
+            if (o < j.O && i < j.I) {
+                v = j.w[(size_t)o * j.so + (size_t)t * j.st + (size_t)i * j.si] * j.scale;
+                if (wf) Elem<T>::st(wf + ((size_t)o * j.T + t) * j.I + i, v);
+            }
+            tile[r][tx] = v;
+        }
+    }
+    __syncthreads();
+    if (wb) {
+        const int o = to * 64 + tx;
+#pragma unroll 4
+        for (int r = ty; r < 64; r += 4) {
+            const int i = ti * 64 + r;
+            if (o < j.O && i < j.I) Elem<T>::st(wb + ((size_t)i * j.T + t) * j.O + o, tile[tx][r]);
+        }
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float *__restrict__ dw, float *__restrict__ g, int O, int I, int Tn, float scale) {
     const size_t total = (size_t)O * I * Tn;
     GRID_STRIDE(i, total) {   // i indexes the OIHW destination
@@ -484,6 +528,14 @@ extern "C" int rdfc_pack_weight_ohwi(const float *w, void *wf, void *wb, int O, 
     DISPATCH(dtype, hipLaunchKernelGGL(pack_weight_ohwi_kernel<T>, dim3(nblocks(total)), dim3(NT), 0, (hipStream_t)stream, w, (T *)wf,
                                        (T *)wb, O, I, KH * KW, scale));
     RDFC_LAUNCH_CHECK("rdfc_pack_weight_ohwi");
+    return 0;
+}
+
+extern "C" int rdfc_pack_weights_batch(const rdfc_pack_job *jobs, int njobs, int nblocks, int dtype, void *stream) {
+    CHECK_DTYPE("rdfc_pack_weights_batch", dtype);
+    RDFC_REQUIRE(jobs != nullptr && njobs > 0 && nblocks >= njobs, "rdfc_pack_weights_batch: bad job table");
+    DISPATCH(dtype, hipLaunchKernelGGL(pack_batch_kernel<T>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, jobs, njobs));
+    RDFC_LAUNCH_CHECK("rdfc_pack_weights_batch");
     return 0;
 }
 

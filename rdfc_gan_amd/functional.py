@@ -13,6 +13,7 @@ Blocks
 """
 import math
 import os
+import weakref
 
 import torch
 
@@ -26,7 +27,6 @@ from . import hip
 _DETERMINISTIC = os.environ.get('RDFC_NORM_ONESTAGE', '0') != '1'
 _compute_dtype = torch.bfloat16
 _weights_epoch = 0
-_pack_cache = {}
 
 
 def set_compute_dtype(dtype):
@@ -43,23 +43,76 @@ def compute_dtype():
 
 
 def invalidate_packed_weights():
-    """call after parameters were changed behind autograd's back (fused optimizer step, load_state_dict)."""
+    """call after parameters were changed behind autograd's back (load_state_dict, an optimizer that is not FlatAdam): every
+    packed operand is stale and is rebuilt at its next use."""
     global _weights_epoch
     _weights_epoch += 1
-    _pack_cache.clear()
+    for k in [k for k, e in _pack_reg.items() if e.ref() is None]:
+        del _pack_reg[k]
+    _pack_tables.clear()
+
+
+class _Pack:
+    """the packed operands (w_fwd, w_bwd) of one weight tensor, kept across steps"""
+    __slots__ = ('ref', 'ptr', 'wf', 'wb', 'epoch', 'version', 'scale', 'shape', 'dtype', 'strides')
+
+
+_pack_reg = {}          # (data_ptr, dtype, scale) -> _Pack
+_pack_tables = {}       # (lo, hi, dtype) -> (registry generation, device job table, njobs, nblocks, entries)
+_pack_generation = 0    # bumped whenever an entry is added or replaced
+pack_misses = 0         # single-weight pack launches so far (diagnostic: a steady-state step has none)
+_BATCH_PACK = os.environ.get('RDFC_BATCH_PACK', '1') != '0'
 
 
 def _packed(weight, dtype, scale):
-    key = (weight.data_ptr(), weight._version, _weights_epoch, dtype, scale, tuple(weight.shape))
-    hit = _pack_cache.get(key)
-    if hit is None:
-        w = weight.detach()
-        if hip.is_ohwi(w) and not w.is_contiguous():    # channels-last master weights (FlatAdam): no OIHW copy
-            hit = hip.pack_weight_ohwi(w, dtype, scale)
-        else:
-            hit = hip.pack_weight(w.contiguous(), dtype, scale)
-        _pack_cache[key] = hit
-    return hit
+    global _pack_generation
+    key = (weight.data_ptr(), dtype, scale)
+    e = _pack_reg.get(key)
+    # identity of the memory behind the key: the tensor the weight is a view of (W-AdaIN views its linear weight as a 1x1 conv
+    # weight afresh in every call) or the weight itself; a dead or different owner means the address has been recycled
+    owner = weight._base if weight._base is not None else weight
+    if e is not None and e.ref() is owner and e.epoch == _weights_epoch and e.version == weight._version \
+            and e.shape == weight.shape:
+        return e.wf, e.wb
+    global pack_misses
+    pack_misses += 1
+    w = weight.detach()
+    e = _Pack()
+    if hip.is_ohwi(w) and not w.is_contiguous():    # channels-last master weights (FlatAdam): no OIHW copy
+        e.wf, e.wb = hip.pack_weight_ohwi(w, dtype, scale)
+    else:
+        w = w.contiguous()
+        e.wf, e.wb = hip.pack_weight(w, dtype, scale)
+    e.ref, e.ptr, e.epoch, e.version = weakref.ref(owner), weight.data_ptr(), _weights_epoch, weight._version
+    e.scale, e.shape, e.dtype = scale, weight.shape, dtype
+    e.strides = tuple(weight.stride()) if w.data_ptr() == weight.data_ptr() else None     # None: packed from a copy
+    _pack_reg[key] = e
+    _pack_generation += 1
+    return e.wf, e.wb
+
+
+def weights_updated(flat):
+    """FlatAdam.step() changed the weights stored in `flat` (behind autograd's back, on the current stream, every helper stream
+    joined): rebuild the packed operands the step has been using, all in one launch (rdfc_pack_weights_batch) into the buffers
+    they already have -- instead of ~80 small launches at their next first uses.  Operands outside `flat` stay as they are."""
+    if not (_BATCH_PACK and flat.is_cuda) or torch.cuda.is_current_stream_capturing():
+        invalidate_packed_weights()
+        return
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+    for dtype in {e.dtype for e in _pack_reg.values() if lo <= e.ptr < hi}:
+        tab = _pack_tables.get((lo, hi, dtype))
+        if tab is None or tab[0] != _pack_generation:
+            ents = [e for e in _pack_reg.values() if lo <= e.ptr < hi and e.dtype == dtype and e.strides is not None
+                    and e.epoch == _weights_epoch and e.ref() is not None and e.version == e.ref()._version]
+            tab = (_pack_generation,) + hip.pack_job_table(ents, flat.device) + (ents,)
+            _pack_tables[(lo, hi, dtype)] = tab
+        _, jobs, njobs, nblocks, ents = tab
+        if njobs:
+            hip.pack_weights_batch(jobs, njobs, nblocks, dtype)
+    # whatever of this buffer is not in a table (packed from a copy, stale already) is rebuilt at its next use
+    for e in _pack_reg.values():
+        if lo <= e.ptr < hi and e.strides is None:
+            e.epoch = -1
 
 
 def _accumulable(g):

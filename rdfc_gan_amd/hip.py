@@ -11,6 +11,8 @@ dimension is contiguous and whose pixel stride ``ld = t.stride(2)`` may exceed C
 import ctypes as C
 import os
 
+import numpy as np
+
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -194,6 +196,33 @@ def pack_weight_ohwi(w, dtype, scale=1.0, fwd=True, bwd=True):
     _chk(lib().rdfc_pack_weight_ohwi(_p(w), _p(wf), _p(wb), O, I, KH, KW, dt(wf if fwd else wb), _f(scale), _st()),
          'rdfc_pack_weight_ohwi')
     return wf, wb
+
+
+_PACK_JOB = np.dtype([('w', '<u8'), ('wf', '<u8'), ('wb', '<u8'), ('O', '<i4'), ('I', '<i4'), ('T', '<i4'), ('so', '<i4'), ('st', '<i4'),
+                      ('si', '<i4'), ('scale', '<f4'), ('block0', '<i4')], align=True)       # rdfc_pack_job (include/rdfc_hip.h)
+assert _PACK_JOB.itemsize == 56
+
+
+def pack_job_table(entries, device):
+    """device copy of the rdfc_pack_job array for `entries` (objects with ptr, shape, strides of the f32 weight, wf, wb, scale)
+    -> (table, njobs, nblocks)"""
+    tab = np.zeros(len(entries), dtype=_PACK_JOB)
+    b = 0
+    for k, e in enumerate(entries):
+        O, I, KH, KW = e.shape
+        so, si, sh, sw = e.strides
+        assert KH == 1 or sh == KW * sw, 'taps must be evenly strided'
+        tab[k] = (e.ptr, e.wf.data_ptr() if e.wf is not None else 0, e.wb.data_ptr() if e.wb is not None else 0, O, I, KH * KW,
+                  so, sw, si, e.scale, b)
+        b += KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
+    if not len(entries):
+        return None, 0, 0
+    return torch.from_numpy(tab.view(np.uint8)).to(device), len(entries), b
+
+
+def pack_weights_batch(jobs, njobs, nblocks, dtype):
+    _chk(lib().rdfc_pack_weights_batch(_p(jobs), njobs, nblocks, {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[dtype],
+                                       _st()), 'rdfc_pack_weights_batch')
 
 
 def unpack_wgrad(dw_packed, O, I, KH, KW, scale=1.0):

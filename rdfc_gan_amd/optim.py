@@ -211,7 +211,7 @@ class FlatAdam(torch.optim.Optimizer):
             self.steps += 1
             hip.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
                           g['eps'], self.steps, 1.0 / world)
-        Fh.invalidate_packed_weights()
+        Fh.weights_updated(self.flat)
 
     # ---- checkpoint format of torch.optim.Adam (lib/utils/checkpoint.py:21-58 stores optimizer.state_dict()) ----
     def state_dict(self):

@@ -726,3 +726,43 @@ def test_dgrad_with_addend_and_reflect_adjoint_with_addend(case, dtype):
     a = h.reflect_pad_adjoint(g, 2)
     b = h.reflect_pad_adjoint(g, 2, addend=add)
     assert rel_err(b.float(), a.float() + add.float()) < {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
+def test_batched_weight_pack_equals_single_packs(dtype):
+    """rdfc_pack_weights_batch (all weights of a network in one launch, after the optimizer step) writes exactly what
+    rdfc_pack_weight / rdfc_pack_weight_ohwi write one weight at a time: ragged tiles, both master layouts, scales, and the
+    registry that drives it (functional._packed / weights_updated) picks up in-place updates of a flat buffer."""
+    h = hip()
+    from rdfc_gan_amd import functional as Fh
+    shapes = [(1, 3, 7, 7), (64, 64, 3, 3), (70, 130, 3, 3), (512, 1, 4, 4), (3, 200, 1, 1), (129, 65, 2, 2)]
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat = (torch.arange(n, dtype=torch.float32) * 0.37).sin().to(DEV)
+    ws, off = [], 0
+    for k, s in enumerate(shapes):
+        v = flat[off:off + int(np.prod(s))]
+        off += int(np.prod(s))
+        if k % 2 == 0:          # channels-last storage, logical OIHW (how FlatAdam keeps conv weights)
+            O, I, KH, KW = s
+            ws.append(v.view(O, KH, KW, I).permute(0, 3, 1, 2))
+        else:
+            ws.append(v.view(s))
+    Fh.invalidate_packed_weights()
+    scales = [1.0, 0.5, 1.0, 2.0, 1.0, 0.25]
+    first = [Fh._packed(w, dtype, sc) for w, sc in zip(ws, scales)]
+    ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in first]
+    flat.data.mul_(-1.5).add_(0.25)                # "the optimizer step": the weights change behind the registry's back (no version bump)
+    Fh.weights_updated(flat)
+    again = [Fh._packed(w, dtype, sc) for w, sc in zip(ws, scales)]
+    assert [(a.data_ptr(), b.data_ptr()) for a, b in again] == ptrs          # same buffers, refreshed by the batch launch
+    for w, sc, (wf, wb) in zip(ws, scales, again):
+        if h.is_ohwi(w) and not w.is_contiguous():
+            rf, rb = h.pack_weight_ohwi(w, dtype, sc)
+        else:
+            rf, rb = h.pack_weight(w.contiguous(), dtype, sc)
+        assert torch.equal(wf, rf) and torch.equal(wb, rb), tuple(w.shape)
+        O, I, KH, KW = w.shape
+        ref = (w.float() * sc).to(dtype)
+        assert torch.equal(wf.view(O, KH, KW, I).permute(0, 3, 1, 2), ref)
+        assert torch.equal(wb.view(I, KH, KW, O).permute(3, 0, 1, 2), ref)
+    Fh.invalidate_packed_weights()
