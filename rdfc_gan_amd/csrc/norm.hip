@@ -196,7 +196,10 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
 
 // fixed-order sum over the chunk partials of one (group, k, channel): 32 channels x FL lanes per workgroup,
 // lane l adds chunks l, l+FL, ... in f64, then the FL lane sums are added in lane order (deterministic)
-constexpr int FL = 32, FNT = 32 * FL;
+#ifndef RDFC_NORM_FL
+#define RDFC_NORM_FL 32
+#endif
+constexpr int FL = RDFC_NORM_FL, FNT = 32 * FL;
 __device__ inline double chunk_sum(const float *__restrict__ partial, int g, int K, int k, int C, int c, int nchunk,
                                    double *red /* [FL][32] */) {
     const int lane = threadIdx.x >> 5, cl = threadIdx.x & 31;

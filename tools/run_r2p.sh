@@ -1,7 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-python tools/pack_misses.py 2>&1 | grep -v amdgpu.ids
-python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "batched_weight_pack" 2>&1 | tail -3
+python -m pytest tests/test_modules_gpu.py -x -q -m gpu -k "g_a2b or trace or full_size" 2>&1 | tail -4
 run() { tag=$1; shift; "$@" > gpurun_out/r2p_$tag.json 2> gpurun_out/r2p_$tag.err; python - $tag <<'PY'
 import json,sys
 try:
@@ -12,7 +11,7 @@ except Exception as e:
 PY
 }
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline"
-run batchpack $B
-RDFC_BATCH_PACK=0 run nobatchpack $B
-run batchpack2 $B
-RDFC_BATCH_PACK=0 run nobatchpack2 $B
+run interleaved $B
+run interleaved2 $B
+run nlspn $B --nlspn
+bash tools/timeline.sh 2>&1 | grep -v "^columns" | head -75
