@@ -128,7 +128,7 @@ class FlatAdam(torch.optim.Optimizer):
     def _distributed():
         return dp_active()
 
-    def all_reduce_bucket_async(self, i):
+    def all_reduce_bucket_async(self, i, helpers=True):
         """start the all-reduce of bucket i (idempotent within a step).  Nothing on the compute streams waits here: the
         collective is issued (async_op) from the weight-gradient stream after that stream has been made to wait for the
         current one and the other helper streams -- its later launches wait for the current stream anyway -- so the process
@@ -137,7 +137,9 @@ class FlatAdam(torch.optim.Optimizer):
         a compute stream and its waits stall that stream.  One-rank RCCL runs of bench.py: 38.7 ms per step without a process
         group, 41.3 with one and a communication stream per optimizer, 40.3-40.9 once the compute streams are bound to their
         queues first -- functional.reserve_streams -- with either scheme)
-        RDFC_DP_COMM=stream keeps the round-1 scheme (a communication stream per optimizer) for A/B runs."""
+        RDFC_DP_COMM=stream keeps the round-1 scheme (a communication stream per optimizer) for A/B runs.
+        helpers=False: the bucket's gradients come from the current stream and the weight-gradient stream only (the
+        discriminators' step beside G's backward): do not wait for what the other helper streams are still running."""
         if not self._distributed() or i in self._started:
             return
         self._started.add(i)
@@ -153,8 +155,9 @@ class FlatAdam(torch.optim.Optimizer):
                 self._comm_stream = torch.cuda.Stream()
             cs = self._comm_stream
             cs.wait_stream(cur)
-            for s_ in Fh.helper_streams(dev):
-                cs.wait_stream(s_)
+            for s_ in (Fh.helper_streams(dev) if helpers else [Fh.wgrad_stream(dev)]):
+                if s_ is not None:
+                    cs.wait_stream(s_)
             with torch.cuda.stream(cs):
                 dist.all_reduce(view)
             ev = torch.cuda.Event()
@@ -164,7 +167,7 @@ class FlatAdam(torch.optim.Optimizer):
         issue = Fh.wgrad_stream(dev) or cur
         if issue != cur:
             issue.wait_stream(cur)
-        for s_ in Fh.helper_streams(dev):
+        for s_ in (Fh.helper_streams(dev) if helpers else []):
             if s_ != issue and s_ != cur:
                 issue.wait_stream(s_)
         with torch.cuda.stream(issue):

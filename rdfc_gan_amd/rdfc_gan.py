@@ -46,6 +46,10 @@ def norm_normalize(norm_out):
 
 
 _NET_STREAMS = os.environ.get('RDFC_NET_STREAMS', '1') != '0'
+# where the discriminators' own step is enqueued (bench.py, bf16, batch 8 at 228x304, three interleaved runs each): '0' behind G's
+# backward on the main / B->A streams as upstream orders it: 37.5-37.6 ms per step; '1' behind it on the host but forked before it
+# on the B->A stream: 37.0-37.2; 'first' (default) enqueued before it on the depth-branch stream: 36.1-36.4
+_D_UNDER_G = {'0': False, '1': True}.get(os.environ.get('RDFC_D_UNDER_G', 'first'), os.environ.get('RDFC_D_UNDER_G', 'first'))
 
 
 class _LossReadback:
@@ -501,10 +505,18 @@ class RDFCGAN:
                      loss_A2B_L1=terms[5],             # upstream logs B2A under this key (rdfc_gan.py:276)
                      loss_cycle_A=terms[1], loss_cycle_B=terms[2])
         self._post_losses(stats)
+        # the discriminators' own step needs nothing of G's backward: it forks HERE (see _enqueue_step)
+        self._fork_D = None
+        if self._net_streams_on() and _D_UNDER_G:
+            self._fork_D = torch.cuda.Event()
+            self._fork_D.record(torch.cuda.current_stream(self.device))
+            if _D_UNDER_G == 'first' and self.__dict__.get('_D_hook') is not None:
+                self._D_hook()                       # enqueue the discriminators' step before G's backward
         self._backward(loss_G)
         return stats
 
     def backward_G(self):
+        self._fork_D = None
         if self._batched():
             return self._backward_G_batched()
         a = self.args
@@ -764,7 +776,35 @@ class RDFCGAN:
             self._rb_active = None
         return rb.collect(list(loss_stats)) if sync_losses else loss_stats
 
+    def _enqueue_D_steps(self, loss_stats):
+        """Both discriminator steps on a helper stream, forked BEFORE G's backward: they depend on the forward only (fake_A /
+        fake_B detached; the G-loss passes through D_A / D_B were built with the discriminators frozen, so G's backward writes
+        none of their gradients), and their small kernels (27x37 maps) fill a quarter of the chip when they run alone behind
+        G's backward -- here they run beside it.  FlatAdam.step() joins the streams."""
+        self.set_requires_grad([self.disc_A, self.disc_B], True)
+        main = torch.cuda.current_stream(self.device)
+        first = _D_UNDER_G == 'first'
+        # enqueued before G's backward they take the depth-branch stream (idle until G_A2B's backward reaches that branch);
+        # behind it the B->A stream (G's backward has used it for D_B's input gradient by then)
+        stream = Fh.branch_stream(self.device) if first else Fh.net_stream(self.device)
+        stream.wait_event(self._fork_D)
+        with torch.cuda.stream(stream):
+            self.optimizer_D.zero_grad()
+            stats_DB = self.backward_D_B2A()
+            stats_DA = self.backward_D_A2B()
+            self.optimizer_D.all_reduce_bucket_async(1, helpers=False)
+            self.optimizer_D.all_reduce_bucket_async(0, helpers=False)
+        for t in list(stats_DB.values()) + list(stats_DA.values()):
+            t.record_stream(main)
+        self._D_stats = dict(stats_DA)
+        self._D_stats.update(stats_DB)
+        self._D_done = True
+        if first:
+            self.set_requires_grad([self.disc_A, self.disc_B], False)        # (host-side flag only; G's graph is built already)
+
     def _enqueue_step(self, loss_stats):
+        self._D_done, self._D_stats = False, None
+        self._D_hook = (lambda: self._enqueue_D_steps(loss_stats)) if self._batched() else None
         self.forward()
         self.set_requires_grad([self.disc_A, self.disc_B], False)
         self.optimizer_G.zero_grad()
@@ -780,14 +820,20 @@ class RDFCGAN:
         if self.use_label_net:
             self.optimizer_Label.all_reduce_grads_async()
         self.set_requires_grad([self.disc_A, self.disc_B], True)
-        self.optimizer_D.zero_grad()
-        with self._net_stream_ctx():                  # the two discriminators are independent: D_B's step on the second stream
-            stats_DB = self.backward_D_B2A()
-            self.optimizer_D.all_reduce_bucket_async(1)       # D_B's bucket: under D_A's backward
-        loss_stats.update(self.backward_D_A2B())
-        self._join_net_stream(tuple(stats_DB.values()))
-        loss_stats.update(stats_DB)
-        self.optimizer_D.all_reduce_grads_async()             # D_A's bucket: under G's Adam update
+        fork = self.__dict__.get('_fork_D')
+        if fork is not None:
+            if not self.__dict__.get('_D_done'):
+                self._enqueue_D_steps(loss_stats)
+            loss_stats.update(self._D_stats)
+        else:
+            self.optimizer_D.zero_grad()
+            with self._net_stream_ctx():              # the two discriminators are independent: D_B's step on the second stream
+                stats_DB = self.backward_D_B2A()
+                self.optimizer_D.all_reduce_bucket_async(1)       # D_B's bucket: under D_A's backward
+            loss_stats.update(self.backward_D_A2B())
+            self._join_net_stream(tuple(stats_DB.values()))
+            loss_stats.update(stats_DB)
+            self.optimizer_D.all_reduce_grads_async()             # D_A's bucket: under G's Adam update
         self.optimizer_G.step()
         if self.G_normal is not None:
             self.optimizer_Normal.step()

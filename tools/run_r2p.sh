@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-python -m pytest tests/test_modules_gpu.py -x -q -m gpu -k "g_a2b or trace or full_size" 2>&1 | tail -4
+RDFC_D_UNDER_G=first python -m pytest tests/test_modules_gpu.py -x -q -m gpu -k "trace or full_size" 2>&1 | tail -3
 run() { tag=$1; shift; "$@" > gpurun_out/r2p_$tag.json 2> gpurun_out/r2p_$tag.err; python - $tag <<'PY'
 import json,sys
 try:
@@ -11,7 +11,8 @@ except Exception as e:
 PY
 }
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline"
-run interleaved $B
-run interleaved2 $B
-run nlspn $B --nlspn
-bash tools/timeline.sh 2>&1 | grep -v "^columns" | head -75
+for rep in 1 2 3; do
+RDFC_D_UNDER_G=first run d_first $B
+RDFC_D_UNDER_G=1 run d_under_g $B
+RDFC_D_UNDER_G=0 run d_after_g $B
+done
