@@ -159,7 +159,8 @@ def main():
     dev = torch.device('cuda', local)
     from rdfc_gan_amd import functional as Fh
     if os.environ.get('RDFC_RESERVE_STREAMS', '1') != '0':
-        Fh.reserve_streams(dev)             # the compute streams take their hardware queues before RCCL's streams exist
+        # the compute streams take their hardware queues before RCCL's stream exists (three under data parallelism, four without)
+        Fh.reserve_streams(dev, with_net=not (world > 1 or a.rccl_self_test))
     if world > 1 or a.rccl_self_test:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if a.rccl_self_test:          # one rank, every collective of the step through RCCL all the same (rdfc_gan_amd/optim.py dp_active)
@@ -201,7 +202,12 @@ def main():
     for i in range(a.warmup):
         if graphed and i == 1:
             model.enable_graph(True, multi_stream=a.graph_multi_stream)
+        # the last warm-up step carries kernel events like every --event-every-th timed step: the runtime grows its event /
+        # signal pools on first use, which would otherwise land in the first timed step (seen as rare 40 ms outliers)
+        warm_ev = not graphed and not a.no_kernel_events and i == a.warmup - 1
+        hip.PROFILE = [] if warm_ev else None
         one_step(i)
+        hip.PROFILE = None
     if graphed and a.warmup < 2:
         model.enable_graph(True, multi_stream=a.graph_multi_stream)
         one_step(a.warmup)                 # capture + first replay (untimed)

@@ -184,17 +184,19 @@ def wgrad_stream(device):
     return _side_stream(torch.device(device))[0]
 
 
-def reserve_streams(device):
+def reserve_streams(device, with_net=False):
     """create the step's HIP streams NOW and put one launch on each.  The HIP runtime binds a stream to one of its
-    GPU_MAX_HW_QUEUES (4) hardware queues at the stream's first use, round-robin; the step uses four (default, weight
-    gradients, depth branch, B->A half).  Called before torch.distributed.init_process_group -- whose RCCL communicator brings
-    streams of its own -- it gives the four compute streams a queue each; called after, two of them can end up sharing one."""
+    GPU_MAX_HW_QUEUES (4) hardware queues at the stream's first use, round-robin; the batched step uses three (default, weight
+    gradients, depth branch / discriminator step).  Called before torch.distributed.init_process_group -- whose RCCL communicator
+    brings a stream of its own -- it gives the three compute streams a queue each and leaves the fourth to RCCL; called after,
+    two compute streams can end up sharing one (a wait queued on one then stalls the other).  with_net: also the B->A stream,
+    which the step uses for D_B's G-loss pass when no process group exists (worth 0.4 ms per step)."""
     device = torch.device(device)
     if device.type != 'cuda':
         return
     if device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
-    for s in (torch.cuda.default_stream(device), _side_stream(device)[0], branch_stream(device), net_stream(device)):
+    for s in (torch.cuda.default_stream(device), _side_stream(device)[0], branch_stream(device)) + ((net_stream(device),) if with_net else ()):
         with torch.cuda.stream(s):
             torch.zeros(64, device=device)
     torch.cuda.synchronize(device)

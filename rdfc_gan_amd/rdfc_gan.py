@@ -46,6 +46,7 @@ def norm_normalize(norm_out):
 
 
 _NET_STREAMS = os.environ.get('RDFC_NET_STREAMS', '1') != '0'
+_GLOSS_NET = os.environ.get('RDFC_GLOSS_NET')            # A/B override: '0' | '1' (default: on unless a process group exists)
 # where the discriminators' own step is enqueued (bench.py, bf16, batch 8 at 228x304, three interleaved runs each): '0' behind G's
 # backward on the main / B->A streams as upstream orders it: 37.5-37.6 ms per step; '1' behind it on the host but forked before it
 # on the B->A stream: 37.0-37.2; 'first' (default) enqueued before it on the depth-branch stream: 36.1-36.4
@@ -489,14 +490,23 @@ class RDFCGAN:
     def _backward_G_batched(self):
         a = self.args
         lam_A, lam_B, lam_1 = _cfg_get(a, 'lambda_A', 100.0), _cfg_get(a, 'lambda_B', 100.0), _cfg_get(a, 'lambda_L1', 100.0)
-        with self._net_stream_ctx():                  # the two discriminators are independent: D_B on the second stream
+        # D_B's G-loss pass on the B->A stream -- unless a process group exists: the runtime has four hardware queues, RCCL's
+        # stream needs one, and a compute stream that shares a queue with it stalls behind the collectives' waits
+        # (bench.py: 36.45 vs 36.85 ms per step with / without the fourth compute stream; one-rank RCCL 38.6 vs 37.3)
+        gloss_net = (_GLOSS_NET == '1') if _GLOSS_NET is not None else not (dist.is_available() and dist.is_initialized())
+        gloss_net = gloss_net and self._net_streams_on()
+        if gloss_net:
+            with self._net_stream_ctx():
+                gan_B2A = self.criterionGAN(self.disc_B(self._fA_D), True)
+        else:
             gan_B2A = self.criterionGAN(self.disc_B(self._fA_D), True)
         gan_A2B = self.criterionGAN(self.disc_A(self._fB_D), True)
         l1_B2A = self.criterionL1(self._fA_L1, self.real_A, weight=self.image_loss_weight)
         cyc_B2A = self.criterionCycle(self.rec_B, self.real_B, weight=self.image_loss_weight)
         l1_A2B = self.criterionL1(self._fB_L1, self.real_B, weight=self.image_loss_weight)
         cyc_A2B = self.criterionCycle(self.rec_A, self.real_A)
-        self._join_net_stream((gan_B2A,))
+        if gloss_net:
+            self._join_net_stream((gan_B2A,))
         # loss_G = loss_G_A2B + loss_cycle_A2B + loss_cycle_B2A + loss_G_B2A + loss_A2B_L1 + loss_B2A_L1 (:252-254), the
         # lambda factors folded into one f32 product per term ((x * lambda_L1) * 5 upstream: at most one rounding apart)
         loss_G, terms = Fh.combine_losses([(gan_A2B, 1.0), (cyc_A2B, lam_A), (cyc_B2A, lam_B), (gan_B2A, 1.0),
@@ -507,7 +517,7 @@ class RDFCGAN:
         self._post_losses(stats)
         # the discriminators' own step needs nothing of G's backward: it forks HERE (see _enqueue_step)
         self._fork_D = None
-        if self._net_streams_on() and _D_UNDER_G:
+        if _D_UNDER_G and Fh.multi_stream() and self.device.type == 'cuda':
             self._fork_D = torch.cuda.Event()
             self._fork_D.record(torch.cuda.current_stream(self.device))
             if _D_UNDER_G == 'first' and self.__dict__.get('_D_hook') is not None:

@@ -1,6 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
-RDFC_D_UNDER_G=first python -m pytest tests/test_modules_gpu.py -x -q -m gpu -k "trace or full_size" 2>&1 | tail -3
 run() { tag=$1; shift; "$@" > gpurun_out/r2p_$tag.json 2> gpurun_out/r2p_$tag.err; python - $tag <<'PY'
 import json,sys
 try:
@@ -11,8 +10,9 @@ except Exception as e:
 PY
 }
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline"
-for rep in 1 2 3; do
-RDFC_D_UNDER_G=first run d_first $B
-RDFC_D_UNDER_G=1 run d_under_g $B
-RDFC_D_UNDER_G=0 run d_after_g $B
+for rep in 1 2 3 4; do
+run plain $B
+run rccl $B --rccl-self-test
 done
+run nlspn $B --nlspn
+run f16big $B --dtype f16 --height 480 --width 640 --batch 4
