@@ -311,7 +311,7 @@ def main():
                                step_gflop_per_pair=round(gflop_pair, 1)),
                    loss_readback='every step (reference API)' if not a.no_sync_losses else 'none in the timed region',
                    host_enqueue_ms_per_step=round(1e3 * host_one, 3),
-                   unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 3 streams (main, depth branch / D_B, weight gradients), batched calls' if not graphed else ('hip graphs (3 per step), ' + ('fork/join over the helper streams captured' if a.graph_multi_stream else 'one stream')),
+                   unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 4 streams (main | depth branch, then the discriminators\' step | weight gradients | D_B\'s G-loss pass), batched calls' if not graphed else ('hip graphs (3 per step), ' + ('fork/join over the helper streams captured' if a.graph_multi_stream else 'one stream')),
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
         if comm is not None:

@@ -2,8 +2,11 @@
 # usage (GPU box, repo root): bash tools/final_round.sh r02   -> every artefact of a round under gpurun_out/<tag>_*
 tag=${1:-r02}
 mkdir -p gpurun_out
-bash tools/profile_round.sh $tag                                            # default bench (with CPU baseline) + the same command under rocprofv3
 bash tools/pmc_bench.sh $tag                                                # HBM-side bytes per kernel (separate --pmc passes)
+cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json       # (this box's copy: the bench line below cites counters of THIS build)
+bash tools/profile_round.sh $tag                                            # default bench (with CPU baseline) + the same command under rocprofv3
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --rccl-self-test > gpurun_out/${tag}_rccl_one_rank_bench.json 2>/dev/null
+bash tools/timeline.sh > gpurun_out/${tag}_timeline.txt 2>&1
 # BASELINE config #3 (NLSPN on): bench line + kernel stats
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --nlspn > gpurun_out/${tag}_nlspn_bench.json 2>/dev/null
 root=$PWD; cd /tmp && export TMPDIR=/tmp && cd $root
@@ -15,7 +18,7 @@ python bench.py --steps 10 --warmup 3 --no-cpu-baseline --dtype f16 --height 480
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --dtype f32 > gpurun_out/${tag}_f32_bench.json 2>/dev/null
 # every conv shape alone (one stream)
 RDFC_BRANCH_STREAMS=0 RDFC_NET_STREAMS=0 RDFC_WGRAD_STREAM=0 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --event-every 1 --by-shape gpurun_out/${tag}_by_shape_one_stream.txt > gpurun_out/${tag}_bench_one_stream.json 2>/dev/null
-for f in ${tag}_bench ${tag}_bench_under_rocprof ${tag}_nlspn_bench ${tag}_f16_480x640_bench ${tag}_f32_bench ${tag}_bench_one_stream; do
+for f in ${tag}_bench ${tag}_bench_under_rocprof ${tag}_rccl_one_rank_bench ${tag}_nlspn_bench ${tag}_f16_480x640_bench ${tag}_f32_bench ${tag}_bench_one_stream; do
 python3 - gpurun_out/$f.json <<'PY'
 import json,sys
 try:
