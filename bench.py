@@ -384,7 +384,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:    # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(a.batch, a.height, a.width, True)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or a.rccl_self_test:
         dist.destroy_process_group()
 
 

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 bash tools/pmc_bench.sh $tag                                                # HBM-side bytes per kernel (separate --pmc passes)
 cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json       # (this box's copy: the bench line below cites counters of THIS build)
 bash tools/profile_round.sh $tag                                            # default bench (with CPU baseline) + the same command under rocprofv3
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --rccl-self-test > gpurun_out/${tag}_rccl_one_rank_bench.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --rccl-self-test > gpurun_out/${tag}_rccl_one_rank_bench.json 2> gpurun_out/${tag}_rccl.err
 bash tools/timeline.sh > gpurun_out/${tag}_timeline.txt 2>&1
 # BASELINE config #3 (NLSPN on): bench line + kernel stats
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --nlspn > gpurun_out/${tag}_nlspn_bench.json 2>/dev/null
