@@ -383,9 +383,15 @@ def main():
                     f.write(' '.join(map(str, k)) + f' | {v[2]} {1e3 * v[1]:.2f} {1e6 * v[1] / v[2]:.1f} {v[0] / v[1] / 1e12:.1f}\n')
         if not a.no_cpu_baseline and world == 1:    # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(a.batch, a.height, a.width, True)
-        print(json.dumps(out))
     if world > 1 or a.rccl_self_test:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST line on stdout: RCCL prints a version banner through C stdio, which -- block-buffered on a
+        # pipe -- would otherwise come out at exit, behind it
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
