@@ -66,6 +66,16 @@ def _worker(rank, world, port, q):
         stats = dict(a=torch.tensor(float(rank)), b=torch.tensor(10.0 * (rank + 1)))
         red = RDFCGAN.reduce_loss(None, stats)
         assert abs(red['a'] - 0.5) < 1e-6 and abs(red['b'] - 15.0) < 1e-6, red
+        # the step's loss read-back: groups posted as they become known, ONE averaging collective when they are collected,
+        # keys back in the order asked for
+        from rdfc_gan_amd.rdfc_gan import _LossReadback
+        rb = _LossReadback(torch.device('cpu'))
+        rb.begin()
+        rb.post(dict(loss_G=torch.tensor(1.0 + rank), loss_cycle_A=torch.tensor(2.0)))
+        rb.post(dict(loss_D_A=torch.tensor(4.0 * rank)))
+        got = rb.collect(['loss_D_A', 'loss_G', 'loss_cycle_A'])
+        assert list(got) == ['loss_D_A', 'loss_G', 'loss_cycle_A'] and got == dict(loss_D_A=2.0, loss_G=1.5, loss_cycle_A=2.0), got
+        assert all(isinstance(v, float) for v in got.values())
         # optimizer state round-trips in torch.optim.Adam's checkpoint format
         sd = opt.state_dict()
         assert set(sd) == {'state', 'param_groups'} and set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
