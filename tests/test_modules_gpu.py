@@ -337,6 +337,57 @@ def _step_cfg(hp):
                            D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')))
 
 
+def test_step_schedules_walk_the_same_trajectory(monkeypatch):
+    """Where the step's independent pieces are ENQUEUED must not change what they compute: the discriminators' step behind G's
+    backward (upstream's order), forked before it, or enqueued before it on the depth-branch stream (default); one stream or
+    four.  Three f32 steps each; whatever differs comes from the weight gradients' float atomics, which Adam amplifies (the
+    SAME schedule run twice drifts apart by the printed amount) -- a stream that read a buffer too early would be off by orders
+    of magnitude more, or not finite."""
+    import random
+    from rdfc_gan_amd import rdfc_gan as rg
+    from rdfc_gan_amd import functional as Fh
+    hp = STEP_HP
+    setup_dtype(torch.float32)
+
+    def run(d_under_g, multi):
+        monkeypatch.setattr(rg, '_D_UNDER_G', d_under_g)
+        Fh.set_multi_stream(multi)
+        m = rg.RDFCGAN(torch.device(DEV), False, _step_cfg(hp), is_train=True)
+        for key, net in m.models.items():
+            net.load_state_dict(det_state_dict(net.state_dict(), 0))
+        Fh.invalidate_packed_weights()
+        m.train()
+        random.seed(5)
+        np.random.seed(5)
+        trace = []
+        for it in range(3):
+            data, nA, _ = step_batch(it % 2, hp['B'], hp['H'], hp['W'])
+            data['gt_normal'] = nA
+            m.set_input(data)
+            trace.append(m.optimize_parameters())
+        torch.cuda.synchronize()
+        return trace
+
+    try:
+        ref = run(False, False)                              # upstream's order on one stream
+        worst = {}
+        for mode, multi in ((False, False), (False, True), (True, True), ('first', True), ('first', False)):
+            got = run(mode, multi)
+            dev = 0.0
+            for it, (a, b) in enumerate(zip(ref, got)):
+                assert list(a) == list(b)
+                for k in a:
+                    assert np.isfinite(b[k]), (mode, multi, it, k)
+                    dev = max(dev, abs(a[k] - b[k]) / (abs(a[k]) + 0.05))
+            worst[(mode, multi)] = dev
+        print('max relative loss deviation from the reference schedule over 3 steps:', worst)
+        noise = worst[(False, False)]                        # the same schedule twice: what the float atomics alone do
+        for key, dev in worst.items():
+            assert dev <= max(5 * noise, 5e-3), f'schedule {key}: {dev:.3e} against run-to-run noise {noise:.3e}'
+    finally:
+        Fh.set_multi_stream(True)
+
+
 @pytest.mark.parametrize('graph_streams', ['one_stream'])     # ('fork_join': hipStreamEndCapture of the full four-stream step segfaults on ROCm 7.2 -- opt-in only)
 def test_graph_mode_matches_eager(graph_streams):
     """RDFCGAN.enable_graph(): three captured HIP graphs (G step | D step | Adam) replayed per step must walk the
