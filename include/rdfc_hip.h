@@ -229,6 +229,9 @@ int rdfc_adain_bwd_apply(const void *dout, const void *x, const float *mean, con
 /* per-channel sum over all pixels (bias gradient): out[C] = sum_p x[p, c].
  * partial: scratch of min(4096, P) * C floats (upper bound on the chunk count of either code path). */
 int rdfc_channel_sum(const void *x, float *partial, float *out, int P, int C, int ld, int dtype, void *stream);
+/* same, and acc[c] += out[c] (f32, may be NULL): the bias gradient lands in the parameter's persistent .grad without a pass of
+ * autograd's own (torch accumulates a returned gradient with a stock elementwise add) */
+int rdfc_channel_sum_acc(const void *x, float *partial, float *out, float *acc, int P, int C, int ld, int dtype, void *stream);
 
 /* elementwise activation backward for conv epilogues without a norm:
  * dx = dy * act'(y) given the *output* y (relu / lrelu / tanh / sigmoid). */

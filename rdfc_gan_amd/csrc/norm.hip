@@ -896,6 +896,10 @@ extern "C" int rdfc_adain_bwd_apply(const void *dout, const void *x, const float
 }
 
 extern "C" int rdfc_channel_sum(const void *x, float *partial, float *out, int P, int C, int ld, int dtype, void *stream) {
+    return rdfc_channel_sum_acc(x, partial, out, nullptr, P, C, ld, dtype, stream);
+}
+
+extern "C" int rdfc_channel_sum_acc(const void *x, float *partial, float *out, float *acc, int P, int C, int ld, int dtype, void *stream) {
     RDFC_REQUIRE(rdfc_dtype_ok(dtype), "rdfc_channel_sum: bad dtype");
     RDFC_REQUIRE(P > 0 && C > 0 && ld >= C, "rdfc_channel_sum: bad size");
     const int vec = rdfc_vec(dtype);
@@ -910,7 +914,7 @@ extern "C" int rdfc_channel_sum(const void *x, float *partial, float *out, int P
         dim3 grid(nchunk, 1, cdiv(C, NT));
         DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, chunk, (const T *)x, partial));
     }
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(FNT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out, nullptr, nullptr);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(FNT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out, acc, nullptr);
     RDFC_LAUNCH_CHECK("rdfc_channel_sum");
     return 0;
 }

@@ -323,6 +323,7 @@ class _ConvBlock(torch.autograd.Function):
             hip.conv_dgrad(d, x, wb, bias, y)
         ctx.spec, ctx.training, ctx.shapes = spec, training, (Cout, Ho, Wo)
         ctx.has_bias = bias is not None
+        ctx.bias = bias                    # (a parameter: kept for its .grad, into which the bias gradient accumulates directly)
         if not has_norm:
             ctx.save_for_backward(x, weight, y if spec.act != 'none' else None)
             return (y, x.view(x.shape)) if spec.passthrough else y
@@ -378,7 +379,11 @@ class _ConvBlock(torch.autograd.Function):
             else:
                 dy = dz if dz.dtype == x.dtype else dz.to(x.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            g_bias = hip.channel_sum(dy)
+            bg = ctx.bias.grad
+            if _accumulable(bg) and not dy.dtype == torch.float64:
+                hip.channel_sum(dy, acc=bg)         # straight into the persistent .grad (FlatAdam's)
+            else:
+                g_bias = hip.channel_sum(dy)
         N, H, W, Cin = x.shape
         wf, wb = _packed(weight, x.dtype, spec.wscale)
         g_x = g_w = None

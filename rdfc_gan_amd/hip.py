@@ -549,12 +549,13 @@ def adain_backward(dout, x, mean, rstd, gb):
     return dx, dgb
 
 
-def channel_sum(x):
+def channel_sum(x, acc=None):
+    """out[c] = sum over pixels; acc (f32 [C], optional): acc += out in the same launch"""
     N, H, W, Cc = x.shape
     P = N * H * W
     partial = torch.empty(min(4096, P) * Cc, dtype=torch.float32, device=x.device)   # upper bound on chunks
     out = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    _chk(lib().rdfc_channel_sum(_p(x), _p(partial), _p(out), P, Cc, ld(x), dt(x), _st()), 'rdfc_channel_sum')
+    _chk(lib().rdfc_channel_sum_acc(_p(x), _p(partial), _p(out), _p(acc), P, Cc, ld(x), dt(x), _st()), 'rdfc_channel_sum_acc')
     return out
 
 
