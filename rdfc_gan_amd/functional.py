@@ -371,7 +371,8 @@ class _ConvBlock(torch.autograd.Function):
                 g_prelu = sums[:, 2].sum().view(1)
         else:
             x, weight, yout = ctx.saved_tensors
-            dz = dz.contiguous()
+            if not (hip.is_pm(dz) and dz.data_ptr() % 16 == 0):   # (a channel slice of a concatenation's cotangent is read in place through its ld)
+                dz = dz.contiguous()
             if spec.act != 'none':
                 if dz.dtype != x.dtype:
                     dz = dz.to(x.dtype)

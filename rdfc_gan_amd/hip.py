@@ -133,6 +133,18 @@ def ld(t):
     return l
 
 
+def is_pm(t):
+    """whether t is a pixel-major map the kernels can read through (pointer, ld): dense, or a channel slice of a wider dense map"""
+    if t.dim() != 4:
+        return False
+    if t.is_contiguous():
+        return True
+    N, H, W, Cc = t.shape
+    l = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else (t.stride(0) if N > 1 else Cc))
+    return (t.stride(3) == 1 or Cc == 1) and l >= Cc and (W == 1 or t.stride(2) == l) and (H == 1 or t.stride(1) == W * l) \
+        and (N == 1 or t.stride(0) == H * W * l)
+
+
 def _f(x):
     return float(x)
 
