@@ -94,6 +94,15 @@ int rdfc_pack_weights_batch(const rdfc_pack_job *jobs, int njobs, int nblocks, i
 int rdfc_unpack_wgrad(const float *dw_packed, float *grad_oihw, int O, int I, int KH, int KW,
                       float scale, void *stream);
 
+/* Reflection padding folded into the conv (resnet_generator.py:60-100: ReflectionPad2d(1) + Conv2d(3x3, padding 0) in every
+ * ResnetBlock): d describes the conv on the UNPADDED map x with ph = pw = the reflection width; out-of-image taps read the
+ * mirrored pixel.  Covered where forward and weight gradient run on the LDS-DMA 3x3 kernels (rdfc_conv2d_reflect_supported
+ * returns 1); elsewhere pad with rdfc_reflect_pad and run the pad-0 conv.  The input gradient is the pad-0 conv's
+ * (rdfc_conv2d_dgrad on the padded geometry) folded by rdfc_reflect_pad_adjoint[_add]. */
+int rdfc_conv2d_reflect_supported(const rdfc_conv_desc *d);
+int rdfc_conv2d_forward_reflect(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, void *stream);
+int rdfc_conv2d_wgrad_reflect(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream);
+
 /* y = act(conv(x, w_fwd) + bias).  bias: f32[Co] or NULL. */
 int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias,
                         void *y, void *stream);

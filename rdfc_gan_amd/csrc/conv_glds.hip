@@ -35,6 +35,7 @@ struct GParams {
     int stats_groups;            // fused statistics: 0 = off, 1 = one group (batch norm), N = one group per image (instance norm)
     const void *addend;          // optional map (2-byte elements, pixel stride ld_add) added to the result before the store: the
     int ld_add;                  // input gradient of a residual junction in one pass (rdfc_conv2d_dgrad_add)
+    int reflect;                 // forward only: out-of-image patch pixels read their mirror image (ReflectionPad2d folded into the loader)
 };
 
 constexpr int BK = 32, TC = 16, PW = TC + 2;
@@ -152,7 +153,11 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
             psrc[v][r] = zero;
             if (q < NPATCH) {
                 const int py = q / PW, px = q - py * PW;
-                const int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px;
+                int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px;
+                if (p.reflect) {           // LDS-DMA sources are per lane: the halo of a reflection-padded map is just another address
+                    iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);
+                    ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
+                }                          // (what is still outside belongs to output pixels beyond the map: zero page)
                 if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
                     psrc[v][r] = x + ((size_t)(n * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
                     plive[v] |= 1u << r;
@@ -584,10 +589,13 @@ int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G) {
 
 // Called by conv_igemm.hip's entry points before the register-staged 3x3 kernels. Returns 1 if it took the launch.
 // stats != nullptr (forward only): also write the per-tile normalisation statistics, G groups.
+int rdfc_conv3x3_glds_covers(const rdfc_conv_desc *d) { return glds_shape_ok(d, 0) ? 1 : 0; }
+
 int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
-                          hipStream_t st, float *stats = nullptr, int G = 0, const void *addend = nullptr, int ld_add = 0) {
+                          hipStream_t st, float *stats = nullptr, int G = 0, const void *addend = nullptr, int ld_add = 0, int reflect = 0) {
     static const int mode = getenv("RDFC_GLDS") ? atoi(getenv("RDFC_GLDS")) : 1;
     if (!glds_shape_ok(d, transposed)) return 0;
+    if (reflect && (transposed || d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     const int ld_in = transposed ? d->ldy : d->ldx;
     const bf16_t *zero = zero_page();
@@ -595,7 +603,7 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     const int pad = d->ph;
     GParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo,
               Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
-              d->act, d->slope, d->out_f32, 0, 0, stats != nullptr ? G : 0, addend, ld_add};
+              d->act, d->slope, d->out_f32, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect};
     p.tiles_x = cdiv(p.W, TC);
     if (d->dtype == RDFC_F16) {                      // f16: the default variants only (the A/B variants below are bf16 experiments)
         p.tiles_y = cdiv(p.H, Cout > 64 ? 8 : 16);

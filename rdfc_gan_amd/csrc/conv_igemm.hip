@@ -361,7 +361,9 @@ int rdfc_try_conv3x3_patch(const rdfc_conv_desc *d, int transposed, const void *
 int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                        hipStream_t st);                  // conv_thin.hip
 int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
-                          hipStream_t st, float *stats = nullptr, int G = 0, const void *addend = nullptr, int ld_add = 0);   // conv_glds.hip
+                          hipStream_t st, float *stats = nullptr, int G = 0, const void *addend = nullptr, int ld_add = 0, int reflect = 0);   // conv_glds.hip
+int rdfc_conv3x3_glds_covers(const rdfc_conv_desc *d);
+int rdfc_wgrad_glds_covers(const rdfc_conv_desc *d);                                       // conv_wgrad_glds.hip
 int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G);
 int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                         hipStream_t st, const void *addend = nullptr, int ld_add = 0);       // conv_igemm_glds.hip
@@ -391,6 +393,26 @@ extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const
     else if (d->dtype == RDFC_F16) launch_T<f16_t>(p, x, w_fwd, bias, y, st);
     else launch_T<float>(p, x, w_fwd, bias, y, st);
     RDFC_LAUNCH_CHECK("rdfc_conv2d_forward");
+    return 0;
+}
+
+// Reflection padding folded into the loaders (resnet_generator.py:60-100: ReflectionPad2d(1) in front of every 3x3 conv of a
+// ResnetBlock): d describes the conv on the UNPADDED map with ph = pw = the reflection width.  Covered where both the forward
+// and the weight gradient run on the LDS-DMA 3x3 kernels (their sources are per lane, so a mirrored halo pixel is just another
+// address); everywhere else the caller pads explicitly (rdfc_reflect_pad) and runs the pad-0 conv.
+extern "C" int rdfc_conv2d_reflect_supported(const rdfc_conv_desc *d) {
+    if (d == nullptr || !rdfc_dtype_ok(d->dtype) || !rdfc_is16(d->dtype)) return 0;
+    if (d->ph != d->pw || d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi) return 0;
+    return rdfc_conv3x3_glds_covers(d) && rdfc_wgrad_glds_covers(d) ? 1 : 0;
+}
+
+extern "C" int rdfc_conv2d_forward_reflect(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                                           void *stream) {
+    if (int e = check_desc(d, "rdfc_conv2d_forward_reflect")) return e;
+    RDFC_REQUIRE(rdfc_conv2d_reflect_supported(d), "rdfc_conv2d_forward_reflect: shape not covered (ask rdfc_conv2d_reflect_supported)");
+    RDFC_REQUIRE(rdfc_try_conv3x3_glds(d, 0, x, w_fwd, bias, y, (hipStream_t)stream, nullptr, 0, nullptr, 0, 1),
+                 "rdfc_conv2d_forward_reflect: launch refused");
+    RDFC_LAUNCH_CHECK("rdfc_conv2d_forward_reflect");
     return 0;
 }
 

@@ -252,9 +252,21 @@ void launch_T(const WgradParams &p, const void *x, const void *dy, float *dw, hi
 }  // namespace
 
 int rdfc_try_wgrad9(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad9.hip
-int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad_glds.hip
+int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st, int reflect = 0);   // conv_wgrad_glds.hip
 int rdfc_try_wgrad_gather_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad_gather_glds.hip
 int rdfc_try_wgrad_thin(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad_thin.hip
+
+extern "C" int rdfc_conv2d_reflect_supported(const rdfc_conv_desc *d);
+// weight gradient of a conv whose input is reflection-padded by ph = pw (x is the UNPADDED map): see rdfc_conv2d_forward_reflect
+extern "C" int rdfc_conv2d_wgrad_reflect(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream) {
+    RDFC_REQUIRE(d != nullptr && rdfc_conv2d_reflect_supported(d), "rdfc_conv2d_wgrad_reflect: shape not covered (ask rdfc_conv2d_reflect_supported)");
+    RDFC_REQUIRE(d->ldx >= d->Ci && d->ldy >= d->Co, "rdfc_conv2d_wgrad_reflect: ld smaller than channel count");
+    RDFC_REQUIRE((double)d->N * d->Hi * d->Wi * d->ldx < 2147483647.0 && (double)d->N * d->Ho * d->Wo * d->ldy < 2147483647.0,
+                 "rdfc_conv2d_wgrad_reflect: maps of 2^31 elements or more need 64-bit offsets (not built)");
+    RDFC_REQUIRE(rdfc_try_wgrad_glds(d, x, dy, dw_packed, (hipStream_t)stream, 1), "rdfc_conv2d_wgrad_reflect: launch refused");
+    RDFC_LAUNCH_CHECK("rdfc_conv2d_wgrad_reflect");
+    return 0;
+}
 
 extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream) {
     RDFC_REQUIRE(d != nullptr, "rdfc_conv2d_wgrad: null descriptor");

@@ -24,6 +24,7 @@ struct WGParams {
     int segs_per_row, total_segs, segs_per_slice;
     int tiles, xcd_group;
     int tiles_ci;
+    int reflect;                 // X pixels outside the image are their mirror images (reflection padding folded into the loader)
 };
 
 constexpr int SEG = 32, XPX = SEG + 2;
@@ -110,14 +111,15 @@ __global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParam
         ypx[k] = px;
         yoff[k] = px * p.ldy + co0 + ((slot ^ (2 * pair_swz<YROW>(px))) << 3);
     }
-    int xpx[NX], xoff[NX];
+    int xpx[NX], xoff[NX], xch[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         const int e = k * NT + tid, px = e / (TCI / 8), slot = e % (TCI / 8);
         // image row px = (patch row r, column c); pieces past the last row: always the zero page
         const int r = px / XPX, c = px - r * XPX;
         xpx[k] = px < NKY * XPX ? (r << 8 | c) : -1;
-        xoff[k] = (r * p.Wi + c) * p.ldx + ci0 + ((slot ^ (2 * pair_swz<XROW>(px))) << 3);
+        xch[k] = ci0 + ((slot ^ (2 * pair_swz<XROW>(px))) << 3);
+        xoff[k] = (r * p.Wi + c) * p.ldx + xch[k];
     }
 
     // uniform segment cursor of the NEXT k-step to issue
@@ -138,6 +140,14 @@ __global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParam
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             const int r = xpx[k] >> 8, c = xpx[k] & 255;
+            if (p.reflect) {            // mirrored halo: the source is no longer base + a lane constant
+                int yy = iy + r, xx = ix0 + c;
+                yy = yy < 0 ? -yy : (yy >= p.Hi ? 2 * p.Hi - 2 - yy : yy);
+                xx = xx < 0 ? -xx : (xx >= p.Wi ? 2 * p.Wi - 2 - xx : xx);
+                const bool ok = live && xpx[k] >= 0 && (unsigned)yy < (unsigned)p.Hi && (unsigned)xx < (unsigned)p.Wi;
+                glds16(ok ? x + ((long)(cn * p.Hi + yy) * p.Wi + xx) * p.ldx + xch[k] : zero, slot + YB + (k * NT + wave * 64) * 16);
+                continue;
+            }
             const bool ok = live && xpx[k] >= 0 && (unsigned)(iy + r) < (unsigned)p.Hi && (unsigned)(ix0 + c) < (unsigned)p.Wi;
             glds16(ok ? xb + xoff[k] : zero, slot + YB + (k * NT + wave * 64) * 16);
         }
@@ -251,17 +261,17 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
 }  // namespace
 
 // Called by rdfc_conv2d_wgrad (conv_wgrad.hip) before the register-staged kernels; returns 1 if it took the launch.
-int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st) {
+static bool wgrad_glds_shape_ok(const rdfc_conv_desc *d);
+int rdfc_wgrad_glds_covers(const rdfc_conv_desc *d) { return wgrad_glds_shape_ok(d) ? 1 : 0; }
+
+int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st, int reflect = 0) {
     static const int mode = getenv("RDFC_WGRAD_GLDS") ? atoi(getenv("RDFC_WGRAD_GLDS")) : 1;
-    if (!mode || !rdfc_is16(d->dtype)) return 0;
-    if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return 0;
-    if (d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
-    if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8) return 0;
+    if (!wgrad_glds_shape_ok(d)) return 0;
+    if (reflect && (d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return 0;
     const int spr = cdiv(d->Wo, SEG);
-    if ((double)d->Wo / (spr * SEG) < 0.55) return 0;              // too much padding per row segment
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
-    WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0};
+    WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0, 0, 0, reflect};
     // 128 x 128 tiles (8 waves, one workgroup per CU): A/B switch RDFC_WGRAD_GLDS=5 -- measured SLOWER at the batched step's sizes
     // (N = 16; 128 x 128 against the default): 256->256 @ 57x76 150-154 vs 146-148 us, 128->128 @ 114x152 189 vs 137 us, 512->512 @
     // 29x38 187 vs 181 us: halving the DMA'd bytes per MFMA does not pay for going from two 4-wave workgroups per CU to one
@@ -275,4 +285,14 @@ int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, 
     static const int nine = getenv("RDFC_WGRAD_GLDS_NINE") ? atoi(getenv("RDFC_WGRAD_GLDS_NINE")) : 0;
     if (nine && d->Co * d->Ci <= 128 * 64) return d->dtype == RDFC_F16 ? launch<64, 3, RDFC_F16>(p, x, dy, dw, zero, st) : launch<64, 3>(p, x, dy, dw, zero, st);
     return d->dtype == RDFC_F16 ? launch<64, 1, RDFC_F16>(p, x, dy, dw, zero, st) : launch<64, 1>(p, x, dy, dw, zero, st);
+}
+
+static bool wgrad_glds_shape_ok(const rdfc_conv_desc *d) {
+    static const int mode = getenv("RDFC_WGRAD_GLDS") ? atoi(getenv("RDFC_WGRAD_GLDS")) : 1;
+    if (!mode || !rdfc_is16(d->dtype)) return false;
+    if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return false;
+    if (d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return false;
+    if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8) return false;
+    const int spr = cdiv(d->Wo, SEG);
+    return (double)d->Wo / (spr * SEG) >= 0.55;                   // else: too much padding per row segment
 }

@@ -124,6 +124,7 @@ def _accumulable(g):
 # have to sit in the backward chain: it is launched on a second HIP stream (forked behind the kernel that produced dy)
 # and the MFMA-bound split-K GEMM overlaps the HBM-bound normalisation kernels of the layers below.  join_side_stream()
 # brings the streams back together; FlatAdam calls it before it touches the gradients.  RDFC_WGRAD_STREAM=0 disables it.
+_REFLECT_FOLD = os.environ.get('RDFC_REFLECT_FOLD', '1') != '0'      # A/B: reflection pads folded into the conv loaders
 _WGRAD_STREAM = os.environ.get('RDFC_WGRAD_STREAM', '1') != '0'
 _PRIO_HELPER = int(os.environ.get('RDFC_PRIO_HELPER', '0'))     # HIP stream priorities (lower = more urgent) for experiments
 _PRIO_WGRAD = int(os.environ.get('RDFC_PRIO_WGRAD', '0'))
@@ -229,7 +230,7 @@ def join_side_stream():
             side[1].clear()
 
 
-def _wgrad(d, a, b, weight, O, I, k, scale):
+def _wgrad(d, a, b, weight, O, I, k, scale, reflect=False):
     """weight gradient of one conv; -> tensor for autograd, or None after accumulating into weight.grad in place.
 
     rdfc_conv2d_wgrad produces [O][k*k][I], which IS the memory of a channels-last OIHW tensor.  When the parameter
@@ -240,33 +241,37 @@ def _wgrad(d, a, b, weight, O, I, k, scale):
         if _WGRAD_STREAM and _multi_stream and a.is_cuda and hip.PROFILE is None:
             stream, keep = _side_stream(a.device)
             stream.wait_stream(torch.cuda.current_stream(a.device))
-            hip.conv_wgrad(d, a, b, into=g, stream=stream.cuda_stream)      # launched straight onto the side stream
+            hip.conv_wgrad(d, a, b, into=g, stream=stream.cuda_stream, reflect=reflect)      # launched straight onto the side stream
             keep.append((a, b))         # their memory must not be recycled before the join
         elif _WGRAD_STREAM and _multi_stream and a.is_cuda:
             stream, keep = _side_stream(a.device)
             stream.wait_stream(torch.cuda.current_stream(a.device))
             with torch.cuda.stream(stream):                                 # (per-kernel events record on the current stream)
-                hip.conv_wgrad(d, a, b, into=g)
+                hip.conv_wgrad(d, a, b, into=g, reflect=reflect)
             keep.append((a, b))
         else:
-            hip.conv_wgrad(d, a, b, into=g)
+            hip.conv_wgrad(d, a, b, into=g, reflect=reflect)
         return None
     if scale == 1.0:
-        dw = hip.conv_wgrad(d, a, b)
+        dw = hip.conv_wgrad(d, a, b, reflect=reflect)
         return dw.view(O, k, k, I).permute(0, 3, 1, 2)
-    return hip.unpack_wgrad(hip.conv_wgrad(d, a, b), O, I, k, k, scale)
+    return hip.unpack_wgrad(hip.conv_wgrad(d, a, b, reflect=reflect), O, I, k, k, scale)
 
 
 class ConvSpec:
     """static description of one conv block (shared by forward and backward)"""
     __slots__ = ('k', 'stride', 'pad', 'transposed', 'out_pad', 'norm', 'act', 'slope', 'eps', 'momentum',
-                 'out_f32', 'wscale', 'dil', 'group_momenta', 'passthrough')
+                 'out_f32', 'wscale', 'dil', 'group_momenta', 'passthrough', 'reflect')
 
     def __init__(self, k, stride=1, pad=0, transposed=False, out_pad=0, norm='none', act='none', slope=0.0,
-                 eps=1e-5, momentum=0.1, out_f32=False, wscale=1.0, dil=1, group_momenta=None, passthrough=False):
+                 eps=1e-5, momentum=0.1, out_f32=False, wscale=1.0, dil=1, group_momenta=None, passthrough=False, reflect=0):
         """group_momenta (BatchNorm only): the batch is G = len(group_momenta) stacked batches of as many separate calls of
         this layer -- statistics per group, running statistics advanced once per group with its momentum"""
         assert dil == 1 or not transposed
+        # reflect = r > 0: the block stands for ReflectionPad2d(r) + this conv (whose own padding is 0).  Where the LDS-DMA kernels
+        # cover the shape the pad is folded into their loaders, elsewhere it is an explicit pass (decided per call in _ConvBlock)
+        assert not reflect or (pad == 0 and not transposed and stride == 1 and dil == 1)
+        self.reflect = int(reflect)
         # passthrough: the block also returns an alias of its input for a second consumer (a residual junction); the alias'
         # cotangent is added to the input gradient inside the input-gradient kernel (rdfc_conv2d_dgrad_add)
         self.passthrough = bool(passthrough) and not transposed
@@ -279,7 +284,7 @@ class ConvSpec:
 def _geometry(spec, x, weight):
     """-> (desc for conv-primitive orientation, Cout, Ho, Wo)"""
     N, H, W, Cin = x.shape
-    k, s, p = spec.k, spec.stride, spec.pad
+    k, s, p = spec.k, spec.stride, spec.pad + spec.reflect
     if not spec.transposed:
         Cout = weight.shape[0]
         Ho = (H + 2 * p - spec.dil * (k - 1) - 1) // s + 1
@@ -307,7 +312,22 @@ class _ConvBlock(torch.autograd.Function):
         gm = spec.group_momenta if spec.norm == 'bn' and training else None
         if gm is not None:
             assert N % len(gm) == 0, f'batch {N} does not split into {len(gm)} stacked batches'
-        if not spec.transposed:
+        folded = False
+        if spec.reflect:
+            # ReflectionPad2d(r) + conv: folded into the conv's loader where the LDS-DMA kernels cover the shape (forward and
+            # weight gradient), else an explicit pad pass in front of the pad-0 conv
+            d = hip.conv_desc(x.shape, Cout, spec.k, 1, spec.reflect, 1, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
+                              act=epi_act, slope=spec.slope, out_f32=out_f32)
+            folded = x.is_cuda and _REFLECT_FOLD and hip.conv_reflect_supported(d)
+            x_alias = x
+            if folded:
+                hip.conv_forward(d, x, wf, bias, y, reflect=True)
+            else:
+                x = hip.reflect_pad(x.contiguous(), spec.reflect)          # (saved for the weight gradient in place of x)
+                d = hip.conv_desc(x.shape, Cout, spec.k, 1, 0, 1, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
+                                  act=epi_act, slope=spec.slope, out_f32=out_f32)
+                hip.conv_forward(d, x, wf, bias, y)
+        elif not spec.transposed:
             d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
                               act=epi_act, slope=spec.slope, out_f32=out_f32)
             G_ = N if spec.norm == 'in' else 1
@@ -322,11 +342,14 @@ class _ConvBlock(torch.autograd.Function):
                               dtype=hip.dt(x), act=epi_act, slope=spec.slope, out_f32=out_f32, out_hw=(H, W))
             hip.conv_dgrad(d, x, wb, bias, y)
         ctx.spec, ctx.training, ctx.shapes = spec, training, (Cout, Ho, Wo)
+        ctx.folded, ctx.in_shape = folded, (N, H, W, Cin)
+        if not spec.reflect:
+            x_alias = x
         ctx.has_bias = bias is not None
         ctx.bias = bias                    # (a parameter: kept for its .grad, into which the bias gradient accumulates directly)
         if not has_norm:
             ctx.save_for_backward(x, weight, y if spec.act != 'none' else None)
-            return (y, x.view(x.shape)) if spec.passthrough else y
+            return (y, x_alias.view(x_alias.shape)) if spec.passthrough else y
         G = N if spec.norm == 'in' else (len(gm) if gm is not None else 1)
         if spec.norm == 'bn' and not training:
             mean = run_mean.view(1, -1).float()
@@ -346,7 +369,7 @@ class _ConvBlock(torch.autograd.Function):
                 mean, rstd = hip.norm_forward_onestage(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
                                                        run_mean if upd else None, run_var if upd else None, spec.momentum)
         ctx.save_for_backward(x, weight, y, mean, rstd, gamma, beta, res, prelu)
-        return (z, x.view(x.shape)) if spec.passthrough else z
+        return (z, x_alias.view(x_alias.shape)) if spec.passthrough else z
 
     @staticmethod
     def backward(ctx, dz, d_alias=None):
@@ -388,7 +411,26 @@ class _ConvBlock(torch.autograd.Function):
         N, H, W, Cin = x.shape
         wf, wb = _packed(weight, x.dtype, spec.wscale)
         g_x = g_w = None
-        if not spec.transposed:
+        if spec.reflect:
+            r = spec.reflect
+            N, H, W, Cin = ctx.in_shape                       # the unpadded input (x itself when the pad was folded, else x is padded)
+            if ctx.needs_input_grad[0]:
+                # input gradient on the padded geometry (a pad-0 conv's), folded back by the pad's adjoint (+ the alias' cotangent)
+                d = hip.conv_desc((N, H + 2 * r, W + 2 * r, Cin), Cout, spec.k, 1, 0, 1, ldx=Cin, ldy=hip.ld(dy), dtype=hip.dt(x))
+                g_pad = torch.empty(N, H + 2 * r, W + 2 * r, Cin, dtype=x.dtype, device=x.device)
+                hip.conv_dgrad(d, dy, wb, None, g_pad)
+                if d_alias is not None and d_alias.dtype != x.dtype:
+                    d_alias = d_alias.to(x.dtype)
+                g_x = hip.reflect_pad_adjoint(g_pad, r, addend=d_alias)
+            elif d_alias is not None:
+                g_x = d_alias
+            if ctx.needs_input_grad[1]:
+                if ctx.folded:
+                    d = hip.conv_desc(x.shape, Cout, spec.k, 1, r, 1, ldx=hip.ld(x), ldy=hip.ld(dy), dtype=hip.dt(x))
+                else:
+                    d = hip.conv_desc(x.shape, Cout, spec.k, 1, 0, 1, ldx=hip.ld(x), ldy=hip.ld(dy), dtype=hip.dt(x))
+                g_w = _wgrad(d, x, dy, weight, Cout, Cin, spec.k, spec.wscale, reflect=ctx.folded)
+        elif not spec.transposed:
             if ctx.needs_input_grad[0]:
                 d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=Cin, ldy=hip.ld(dy), dtype=hip.dt(x))
                 g_x = torch.empty(N, H, W, Cin, dtype=x.dtype, device=x.device)

@@ -238,9 +238,10 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x):
         cb = self.conv_block
-        xp, xr = Fh.reflect_pad(x, 1, passthrough=True)     # the skip's cotangent is added inside the pad's adjoint kernel
-        y = run_conv(xp, cb[1], cb[2], cb[3])
-        return run_conv(Fh.reflect_pad(y, 1), cb[5], cb[6], None, res=xr)     # out = x + conv_block(x)
+        # ReflectionPad2d(1) + conv as ONE block: the pad is folded into the conv's loaders (functional.ConvSpec.reflect); the skip's
+        # cotangent is added inside the pad's adjoint kernel in the backward
+        y, xr = run_conv(x, cb[1], cb[2], cb[3], reflect=1, passthrough=True)
+        return run_conv(y, cb[5], cb[6], None, res=xr, reflect=1)             # out = x + conv_block(x)
 
 
 class ResnetGenerator(nn.Module):

@@ -267,10 +267,26 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
-def conv_forward(d, x, w_fwd, bias, y):
+def conv_forward(d, x, w_fwd, bias, y, reflect=False):
+    """reflect: d.ph = d.pw is a REFLECTION padding (conv_reflect_supported(d) must hold)"""
     with _Timed('igemm_kernel (conv fwd / dgrad)', d):
-        _chk(lib().rdfc_conv2d_forward(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _st()), 'rdfc_conv2d_forward')
+        if reflect:
+            _chk(lib().rdfc_conv2d_forward_reflect(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _st()), 'rdfc_conv2d_forward_reflect')
+        else:
+            _chk(lib().rdfc_conv2d_forward(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _st()), 'rdfc_conv2d_forward')
     return y
+
+
+_reflect_ok = {}
+
+
+def conv_reflect_supported(d):
+    """whether forward and weight gradient of d run with the reflection padding folded into their loaders (cached per geometry)"""
+    key = (d.N, d.Hi, d.Wi, d.Ci, d.Co, d.KH, d.sh, d.ph, d.ldx, d.ldy, d.dtype, d.act, d.out_f32)
+    hit = _reflect_ok.get(key)
+    if hit is None:
+        hit = _reflect_ok[key] = bool(lib().rdfc_conv2d_reflect_supported(C.byref(d)))
+    return hit
 
 
 def conv_stats_nchunk(d, G):
@@ -314,15 +330,17 @@ def conv_dgrad(d, dy, w_bwd, bias, dx, addend=None):
     return dx
 
 
-def conv_wgrad(d, x, dy, into=None, stream=None):
+def conv_wgrad(d, x, dy, into=None, stream=None, reflect=False):
     """into: f32 buffer [Co][KH*KW][Ci] to ACCUMULATE into (e.g. a channels-last .grad); default a fresh zeroed one.
-    stream: raw HIP stream handle to launch on (default: the current stream)"""
+    stream: raw HIP stream handle to launch on (default: the current stream)
+    reflect: d.ph = d.pw is a REFLECTION padding of x (conv_reflect_supported(d) must hold)"""
     dw = into if into is not None else torch.zeros(d.Co, d.KH * d.KW, d.Ci, dtype=torch.float32, device=x.device)
+    fn, name = (lib().rdfc_conv2d_wgrad_reflect, 'rdfc_conv2d_wgrad_reflect') if reflect else (lib().rdfc_conv2d_wgrad, 'rdfc_conv2d_wgrad')
     if stream is not None and PROFILE is None:
-        _chk(lib().rdfc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), stream), 'rdfc_conv2d_wgrad')
+        _chk(fn(C.byref(d), _p(x), _p(dy), _p(dw), stream), name)
         return dw
     with _Timed('wgrad_kernel (conv weight grad)', d):
-        _chk(lib().rdfc_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _st() if stream is None else stream), 'rdfc_conv2d_wgrad')
+        _chk(fn(C.byref(d), _p(x), _p(dy), _p(dw), _st() if stream is None else stream), name)
     return dw
 
 

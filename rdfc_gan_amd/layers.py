@@ -67,11 +67,11 @@ def _count_batch(norm, k):
 _spec_cache = {}
 
 
-def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False, passthrough=False):
+def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False, passthrough=False, reflect=0):
     """conv (nn.Conv2d | nn.ConvTranspose2d) [+ norm (BatchNorm2d | InstanceNorm2d)] [+ res] [+ act module]"""
     # the static description of the block is the same on every call of the same modules: cache it (a train step runs
     # ~180 blocks, each used to rebuild its ConvSpec from a dozen attribute lookups)
-    key = (id(conv), id(norm), id(act), out_f32, BN_STAT_REPEAT, getattr(act, 'negative_slope', None), BN_GROUP_REPEATS, passthrough)
+    key = (id(conv), id(norm), id(act), out_f32, BN_STAT_REPEAT, getattr(act, 'negative_slope', None), BN_GROUP_REPEATS, passthrough, reflect)
     hit = _spec_cache.get(key)
     if hit is not None and hit[0] is conv and hit[1] is norm and hit[2] is act:
         _c, _n, _a, spec, nname, prelu = hit
@@ -108,7 +108,7 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False, passthrough=
         momentum = 1.0 - (1.0 - momentum) ** BN_STAT_REPEAT
     spec = ConvSpec(k, s, p, transposed, conv.output_padding[0] if transposed else 0, nname, aname, slope,
                     eps=getattr(norm, 'eps', 1e-5), momentum=momentum, out_f32=out_f32, dil=conv.dilation[0], group_momenta=gmom,
-                    passthrough=passthrough)
+                    passthrough=passthrough, reflect=reflect)
     gamma = beta = rm = rv = None
     training = True
     if nname == 'bn':

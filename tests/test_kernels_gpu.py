@@ -766,3 +766,32 @@ def test_batched_weight_pack_equals_single_packs(dtype):
         assert torch.equal(wf.view(O, KH, KW, I).permute(0, 3, 1, 2), ref)
         assert torch.equal(wb.view(I, KH, KW, O).permute(3, 0, 1, 2), ref)
     Fh.invalidate_packed_weights()
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('case', [(2, 57, 76, 256, 256), (3, 29, 38, 64, 128), (1, 17, 40, 128, 64), (2, 8, 20, 64, 64)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_reflection_pad_folded_into_conv_loaders(case, dtype):
+    """rdfc_conv2d_forward_reflect / rdfc_conv2d_wgrad_reflect (ReflectionPad2d(1) folded into the LDS-DMA loaders) against the
+    explicit pad pass followed by the pad-0 conv: the forward reads the same values in the same order (bit-equal), the weight
+    gradient differs by the order of its split-K float atomics only.  f32 maps are not covered (the caller pads explicitly)."""
+    h = hip()
+    N, H, W, Ci, Co = case
+    x = to_pm(rnd(N, Ci, H, W, seed=1), dtype, ld_extra=8)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=(Ci * 9) ** -0.5)
+    wf, _ = h.pack_weight(w.to(DEV), dtype)
+    bias = rnd(Co, seed=3).to(DEV)
+    d_r = h.conv_desc((N, H, W, Ci), Co, 3, 1, 1, ldx=h.ld(x), ldy=Co, dtype=h.dt(x))
+    assert h.conv_reflect_supported(d_r)
+    assert not h.conv_reflect_supported(h.conv_desc((N, H, W, Ci), Co, 3, 1, 1, ldx=Ci, ldy=Co, dtype=h.F32))
+    xp = h.reflect_pad(x.contiguous(), 1)
+    d_p = h.conv_desc(tuple(xp.shape), Co, 3, 1, 0, ldx=Ci, ldy=Co, dtype=h.dt(x))
+    y_ref = h.conv_forward(d_p, xp, wf, bias, torch.empty(N, H, W, Co, dtype=dtype, device=DEV))
+    y = h.conv_forward(d_r, x, wf, bias, torch.empty(N, H, W, Co, dtype=dtype, device=DEV), reflect=True)
+    assert torch.equal(y, y_ref)
+    ref = F.conv2d(F.pad(from_pm(x), (1, 1, 1, 1), mode='reflect'), w.to(dtype).float(), bias.cpu())
+    assert rel_err(from_pm(y), ref) < tol(dtype)
+    gy = to_pm(rnd(N, Co, H, W, seed=4), dtype)
+    dw_ref = h.conv_wgrad(d_p, xp, gy)
+    dw = h.conv_wgrad(h.conv_desc((N, H, W, Ci), Co, 3, 1, 1, ldx=h.ld(x), ldy=Co, dtype=h.dt(x)), x, gy, reflect=True)
+    assert rel_err(dw, dw_ref) < 1e-5
