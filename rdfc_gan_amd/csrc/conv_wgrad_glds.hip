@@ -187,6 +187,12 @@ __global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParam
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NTF; ++j) acc[t][i][j] = mma16<DT>(a[i], b[j], acc[t][i][j]);
+#ifdef RDFC_WGRAD_EXP_DUP   /* timing experiment only (wrong results): every MFMA twice -> how much of a k-step is not MFMA time */
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTF; ++j) acc[t][i][j] = mma16<DT>(a[i], b[j], acc[t][i][j]);
+#endif
         }
     }
     wait_vm<0>();
