@@ -337,6 +337,35 @@ def _step_cfg(hp):
                            D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['f32', 'bf16', 'f16'])
+def test_wadain_against_golden(golden, dtype):
+    """W-AdaIN (model_utils.py:72-90) alone against the fixture generated from the reference class: output,
+    both input gradients, the style weight's and bias' gradients, at the four channel counts of the fusion layers."""
+    from rdfc_gan_amd import functional as Fh
+    from rdfc_gan_amd.generator import AdaptiveInstanceNorm
+    setup_dtype(dtype)
+    g = golden('wadain')
+    lim = {torch.float32: 2e-6, torch.bfloat16: 7e-3, torch.float16: 9e-4}[dtype]      # relative L2; measured 7.4e-7 / 3.6e-3 / 4.4e-4
+
+    def rel(a, key):
+        ref = torch.from_numpy(np.asarray(g[key])).double()
+        return float((a.detach().double().cpu() - ref).norm() / (ref.norm() + 1e-30))
+
+    for i, (c, h, w) in enumerate([(512, 5, 7), (768, 6, 9), (384, 9, 8), (192, 12, 10)], 1):
+        m = AdaptiveInstanceNorm(c, c).to(DEV)
+        m.load_state_dict(det_state_dict(m.state_dict(), i))
+        Fh.invalidate_packed_weights()
+        x = det_tensor(4, f'wadain_x{i}', (2, c, h, w)).to(DEV).requires_grad_(True)
+        s_ = det_tensor(4, f'wadain_s{i}', (2, c, h, w)).to(DEV).requires_grad_(True)
+        y = Fh.to_nchw(m(Fh.to_pm(x), Fh.to_pm(s_)))
+        (y.float() * out_weights('wadain', str(i), y.shape).to(DEV)).sum().backward()
+        gw = m.style.linear.weight_orig.grad
+        errs = dict(y=rel(y, f'y{i}'), gx=rel(x.grad, f'gx{i}'), gs=rel(s_.grad, f'gs{i}'), gw=rel(gw[:32, :32], f'gw_corner{i}'),
+                    gb=rel(m.style.linear.bias.grad, f'gb{i}'))
+        assert all(v < lim for v in errs.values()), (i, c, errs)
+        assert abs(float(gw.double().norm()) / g[f'gw_summary{i}'][1] - 1) < lim
+
+
 def test_step_schedules_walk_the_same_trajectory(monkeypatch):
     """Where the step's independent pieces are ENQUEUED must not change what they compute: the discriminators' step behind G's
     backward (upstream's order), forked before it, or enqueued before it on the depth-branch stream (default); one stream or
