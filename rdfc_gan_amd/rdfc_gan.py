@@ -56,18 +56,22 @@ _D_UNDER_G = {'0': False, '1': True}.get(os.environ.get('RDFC_D_UNDER_G', 'first
 class _LossReadback:
     """base.py:121-132 (mean over ranks, python floats) without draining the queue: every post() packs one group of 0-d
     losses on the stream that produced them, copies it into pinned host memory and records an event; collect() waits for
-    those events only.  Data parallel: the groups are packed as they come, but averaged by ONE all-reduce at the end of the
-    step -- a collective issued on a compute stream in mid-step would queue behind the gradient buckets on the process
-    group's stream and hold the compute stream until every weight gradient before it has finished."""
+    those events only.
+    Data parallel: the groups are averaged by ONE all-reduce.  A collective issued on a compute stream in mid-step queues
+    behind whatever gradient buckets the process group's stream already holds and stalls the compute stream until the weight
+    gradients before it have finished -- so it goes out where no bucket of the step has been issued yet: the default schedule
+    computes all three groups (G, D_B, D_A) before G's backward and before the discriminators' buckets, and begin(expect=3)
+    makes the third post() run the all-reduce and the copy (on the stream of the discriminators' step, which waits for it;
+    G's backward does not).  Without `expect` (other schedules) the all-reduce runs at the end of the step, in collect()."""
     SLOTS = 64
 
     def __init__(self, device):
         self.device = device
         self.host = torch.empty(self.SLOTS, dtype=torch.float32).pin_memory() if device.type == 'cuda' else None
-        self.posts, self.used = [], 0
+        self.posts, self.used, self.expect, self.flushed = [], 0, None, None
 
-    def begin(self):
-        self.posts, self.used = [], 0
+    def begin(self, expect=None):
+        self.posts, self.used, self.expect, self.flushed = [], 0, expect, None
 
     def post(self, stats):
         keys = list(stats)
@@ -78,6 +82,13 @@ class _LossReadback:
                 ev = torch.cuda.Event()
                 ev.record()
             self.posts.append((keys, packed, ev))
+            if dp_active() and self.host is not None and self.expect is not None and len(self.posts) == self.expect:
+                keys, packed = self._reduce_dp()
+                dst = self.host[:len(keys)]
+                dst.copy_(packed, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self.flushed = (keys, dst, ev, packed)
             return
         assert self.used + len(keys) <= self.SLOTS
         dst = self.host[self.used:self.used + len(keys)]
@@ -87,22 +98,31 @@ class _LossReadback:
         self.posts.append((keys, dst, ev))
         self.used += len(keys)
 
+    def _reduce_dp(self):
+        """mean over the ranks of every group posted so far, on the current stream"""
+        for _, _, ev in self.posts:
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)              # a group packed on another stream
+        keys = [k for ks, _, _ in self.posts for k in ks]
+        packed = torch.cat([v for _, v, _ in self.posts]) / dist.get_world_size()
+        dist.all_reduce(packed)
+        return keys, packed
+
     def collect(self, order):
         got = {}
-        if dp_active():
-            for _, _, ev in self.posts:
-                if ev is not None:
-                    torch.cuda.current_stream().wait_event(ev)          # a group packed on another stream
-            keys = [k for ks, _, _ in self.posts for k in ks]
-            packed = torch.cat([v for _, v, _ in self.posts]) / dist.get_world_size()
-            dist.all_reduce(packed)
+        if self.flushed is not None:
+            keys, vals, ev, _keep = self.flushed
+            ev.synchronize()
+            got = dict(zip(keys, vals.tolist()))
+        elif dp_active():
+            keys, packed = self._reduce_dp()
             got = dict(zip(keys, packed.tolist()))
         else:
             for keys, vals, ev in self.posts:
                 if ev is not None:
                     ev.synchronize()
                 got.update(zip(keys, vals.tolist()))
-        self.posts = []
+        self.posts, self.flushed = [], None
         return {k: got[k] for k in order}
 
 
@@ -778,7 +798,9 @@ class RDFCGAN:
             rb = self.__dict__.get('_rb')
             if rb is None or rb.device != self.device:
                 rb = self._rb = _LossReadback(self.device)
-            rb.begin()
+            # (the default schedule posts G's, D_B's and D_A's losses before any gradient bucket of the step goes out: see _LossReadback)
+            early = self._batched() and _D_UNDER_G == 'first' and Fh.multi_stream() and self.device.type == 'cuda'
+            rb.begin(expect=3 if early else None)
         self._rb_active = rb
         try:
             self._enqueue_step(loss_stats)
