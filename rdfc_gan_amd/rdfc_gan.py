@@ -729,6 +729,8 @@ class RDFCGAN:
         # before the capture stream builds its own: drop every tensor that still holds that step's graph.
         import gc
         self.fake_A = self.fake_B = self.fake_normal_fakeA = None
+        self.rec_A = self.rec_B = self._fA_D = self._fA_L1 = self._fB_D = self._fB_L1 = None
+        self._D_hook = self._D_stats = self._fork_D = None
         Fh.invalidate_packed_weights()
         gc.collect()
         bns = self._bn_modules()
@@ -872,6 +874,8 @@ class RDFCGAN:
         if self.use_label_net:
             self.optimizer_Label.step()
         self.optimizer_D.step()
+        # nothing of this step's autograd graph may outlive it (a later HIP-graph capture builds its own nodes: _capture)
+        self._D_hook = self._D_stats = self._fork_D = None
 
     def reduce_loss(self, loss):
         """base.py:121-132 semantics (mean over ranks, python floats) with one collective and one D2H copy"""

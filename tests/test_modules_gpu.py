@@ -468,6 +468,33 @@ def test_graph_mode_matches_eager(graph_streams):
                 assert d <= 3.5 * hp['lr'] + 2e-2 * ref.abs().max().item() + 1e-4, (key, n, d)
 
 
+def test_graph_capture_after_eager_steps():
+    """bench.py --graph captures AFTER an eager warm-up step: nothing of that step's autograd graph (its nodes are bound to the
+    helper streams) may still be alive when the capture stream builds its own -- a leftover reference used to end in a
+    segmentation fault inside hipStreamEndCapture."""
+    import random
+    from rdfc_gan_amd import functional as Fh
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    hp = STEP_HP
+    setup_dtype(torch.bfloat16)
+    m = RDFCGAN(torch.device(DEV), False, _step_cfg(hp), is_train=True)
+    m.train()
+    random.seed(3)
+    np.random.seed(3)
+    try:
+        for it in range(4):
+            if it == 2:
+                m.enable_graph(True)
+            data, nA, _ = step_batch(it % 2, hp['B'], hp['H'], hp['W'])
+            data['gt_normal'] = nA
+            m.set_input(data)
+            losses = m.optimize_parameters()
+            assert all(np.isfinite(v) for v in losses.values()), (it, losses)
+        assert m._graph_mode and m._graphs is not None, 'capture fell back to eager launches'
+    finally:
+        m.enable_graph(False)
+
+
 @pytest.mark.parametrize('dtype', DT, ids=IDS)
 def test_eval_path_end_to_end_metrics_within_north_star_tolerance(dtype):
     """forward_test -> RDFGANMetric.evaluate_normalised (228x304) against the CPU oracle's generator + oracle.metrics on the same
