@@ -221,10 +221,13 @@ void launch(const ThinParams &p, const void *in, const void *w, const float *bia
 }  // namespace
 
 // Called by conv_igemm.hip's entry points before the MFMA kernels. Returns 1 if it took the launch.
+int rdfc_try_conv_thin_row(const rdfc_conv_desc *d, const void *in, const void *w, const float *bias, void *out, hipStream_t st);   // conv_thin_row.hip
+
 int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                        hipStream_t st) {
     static const bool off = getenv("RDFC_NO_THIN") != nullptr;
     if (off || !rdfc_is16(d->dtype)) return 0;
+    if (!transposed && rdfc_try_conv_thin_row(d, in, w, bias, out, st)) return 1;      // wide kernels (7x7 -> 3 channels): row GEMM + shift-add
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     const int ld_in = transposed ? d->ldy : d->ldx, ld_out = transposed ? d->ldx : d->ldy;
     if (Cout > 4 || Cin % 8 != 0 || ld_in % 8 != 0) return 0;

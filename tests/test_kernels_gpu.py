@@ -795,3 +795,28 @@ def test_reflection_pad_folded_into_conv_loaders(case, dtype):
     dw_ref = h.conv_wgrad(d_p, xp, gy)
     dw = h.conv_wgrad(h.conv_desc((N, H, W, Ci), Co, 3, 1, 1, ldx=h.ld(x), ldy=Co, dtype=h.dt(x)), x, gy, reflect=True)
     assert rel_err(dw, dw_ref) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('case', [(4, 134, 146, 64, 3, 7, 0, 'tanh', True), (2, 190, 190, 32, 4, 7, 3, 'none', False),
+                                  (3, 160, 150, 96, 2, 5, 2, 'lrelu', False), (1, 260, 270, 64, 1, 4, 1, 'none', True)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_wide_kernel_few_output_channels_row_gemm(case, dtype):
+    """conv_thin_row.hip (ResnetGenerator's 7x7 -> 3 output layer, resnet_generator.py:50-52): the conv as a 1x1 MFMA product per
+    kernel row followed by a shift-and-add, against torch's conv2d on identically rounded operands; the launch must have gone
+    to that kernel."""
+    h = hip()
+    N, H, W, Ci, Co, k, pad, act, f32out = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), b, 1, pad)
+    ref = {'tanh': torch.tanh, 'none': lambda t: t, 'lrelu': lambda t: F.leaky_relu(t, 0.2)}[act](ref)
+    x_pm = to_pm(x, dtype, ld_extra=8)
+    wf, _ = h.pack_weight(w.to(DEV), dtype)
+    Ho, Wo = ref.shape[2:]
+    y = torch.empty(N, Ho, Wo, Co, dtype=torch.float32 if f32out else dtype, device=DEV)
+    d = h.conv_desc(x_pm.shape, Co, k, 1, pad, ldx=h.ld(x_pm), ldy=Co, dtype=h.dt(x_pm), act=act, slope=0.2, out_f32=f32out)
+    h.conv_forward(d, x_pm, wf, b.to(DEV), y)
+    assert h.lib().rdfc_last_kernel().decode().startswith('thin_row_kernel')
+    assert rel_err(from_pm(y), ref) < tol(dtype)
