@@ -820,3 +820,16 @@ def test_wide_kernel_few_output_channels_row_gemm(case, dtype):
     h.conv_forward(d, x_pm, wf, b.to(DEV), y)
     assert h.lib().rdfc_last_kernel().decode().startswith('thin_row_kernel')
     assert rel_err(from_pm(y), ref) < tol(dtype)
+
+
+def test_reserve_streams_creates_the_step_streams_once():
+    """functional.reserve_streams (called before init_process_group so that the compute streams own their hardware queues): the
+    streams it touches are the ones the step later uses, and calling it twice is harmless."""
+    from rdfc_gan_amd import functional as Fh
+    dev = torch.device('cuda', torch.cuda.current_device())
+    Fh.reserve_streams(dev, with_net=True)
+    side, branch, net = Fh.wgrad_stream(dev), Fh.branch_stream(dev), Fh.net_stream(dev)
+    Fh.reserve_streams('cuda')
+    assert Fh.wgrad_stream(dev) is side and Fh.branch_stream(dev) is branch and Fh.net_stream(dev) is net
+    assert len({side.cuda_stream, branch.cuda_stream, net.cuda_stream, torch.cuda.default_stream(dev).cuda_stream}) == 4
+    assert set(s.cuda_stream for s in Fh.helper_streams(dev)) == {side.cuda_stream, branch.cuda_stream, net.cuda_stream}
