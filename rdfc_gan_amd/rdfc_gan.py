@@ -435,7 +435,9 @@ class RDFCGAN:
 
     def _start_G_B2A_bucket(self):
         if self.is_train and not getattr(self, '_graph_mode', False):
-            self.optimizer_G.all_reduce_bucket_async(0)
+            # (G_B2A's backward runs on the current stream and the weight-gradient stream only: no reason to hold the
+            #  weight gradients until the depth-branch stream -- busy with the discriminators' step -- has caught up)
+            self.optimizer_G.all_reduce_bucket_async(0, helpers=not self._batched())
 
     def _pepper(self, fake_B):
         if getattr(self, '_graph_mode', False):
