@@ -25,6 +25,8 @@ struct WGParams {
     int tiles, xcd_group;
     int tiles_ci;
     int reflect;                 // X pixels outside the image are their mirror images (reflection padding folded into the loader)
+    int flat;                    // k-steps walk a flat pixel index over rows padded to Wo + 2 instead of 32-pixel segments of one row:
+                                 // a 76-wide row fills 2.44 k-steps instead of 3, a 38-wide one 1.25 instead of 2 (NKY = 1 only)
 };
 
 constexpr int SEG = 32, XPX = SEG + 2;
@@ -104,12 +106,13 @@ __global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParam
 
     // ---- lane-constant parts of the DMA sources ---------------------------------------------------------------
     // dY piece e = k*NT + tid: pixel e / (TCO/8), 16-byte slot e % (TCO/8); the slot holds source chunk slot ^ 2*swz(pixel)
-    int ypx[NY], yoff[NY];
+    int ypx[NY], yoff[NY], ych[NY];
 #pragma unroll
     for (int k = 0; k < NY; ++k) {
         const int e = k * NT + tid, px = e / (TCO / 8), slot = e % (TCO / 8);
         ypx[k] = px;
-        yoff[k] = px * p.ldy + co0 + ((slot ^ (2 * pair_swz<YROW>(px))) << 3);
+        ych[k] = co0 + ((slot ^ (2 * pair_swz<YROW>(px))) << 3);
+        yoff[k] = px * p.ldy + ych[k];
     }
     int xpx[NX], xoff[NX], xch[NX];
 #pragma unroll
@@ -126,8 +129,55 @@ __global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParam
     int cn = seg0 / (p.Ho * p.segs_per_row);
     int rem = seg0 - cn * p.Ho * p.segs_per_row;
     int coy = rem / p.segs_per_row, csx = rem - coy * p.segs_per_row;
+    // flat mode: the k-step starts at flat position (image fn, output row fy, column fj of the row padded to L = Wo + 2 columns)
+    const int L = p.Wo + 2;
+    int fn = 0, fy = 0, fj = 0;
+    if (p.flat) {
+        const int f0 = seg0 * SEG;
+        fn = f0 / (p.Ho * L);
+        const int r0 = f0 - fn * p.Ho * L;
+        fy = r0 / L;
+        fj = r0 - fy * L;
+    }
     auto issue = [&](int s) {                                   // DMAs of k-step s (s >= nseg: zero page only) into ring slot s % WG_RING
         const bool live = s < nseg;
+        if (p.flat) {
+            // every piece derives its own (image, row, column) from the uniform cursor: one wrap at most (L >= 34).
+            // (Tried: the two candidate rows' base pointers and validity as uniform values and a per-piece select -- 6-12 % SLOWER.)
+            const unsigned slot = lds0 + (s % WG_RING) * SLOT;
+#pragma unroll
+            for (int k = 0; k < NY; ++k) {
+                int j = fj + ypx[k];
+                const int wrap = j >= L;
+                j -= wrap ? L : 0;
+                const int row = fn * p.Ho + fy + wrap;                          // dY rows are contiguous across images
+                const bool ok = live && j < p.Wo && row < p.N * p.Ho;
+                glds16(ok ? dy + ((size_t)row * p.Wo + j) * p.ldy + ych[k] : zero, slot + (k * NT + wave * 64) * 16);
+            }
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                int j = fj + (xpx[k] & 255);
+                const int wrap = j >= L;
+                j -= wrap ? L : 0;
+                int y = fy + wrap, img = fn;
+                if (y >= p.Ho) { y -= p.Ho; ++img; }
+                int yy = y + ky - p.pad, xx = j - p.pad;
+                if (p.reflect) {
+                    yy = yy < 0 ? -yy : (yy >= p.Hi ? 2 * p.Hi - 2 - yy : yy);
+                    xx = xx < 0 ? -xx : (xx >= p.Wi ? 2 * p.Wi - 2 - xx : xx);
+                }
+                const bool ok = live && xpx[k] >= 0 && img < p.N && (unsigned)yy < (unsigned)p.Hi && (unsigned)xx < (unsigned)p.Wi;
+                glds16(ok ? x + ((long)(img * p.Hi + yy) * p.Wi + xx) * p.ldx + xch[k] : zero, slot + YB + (k * NT + wave * 64) * 16);
+            }
+            if (live) {
+                fj += SEG;
+                while (fj >= L) {
+                    fj -= L;
+                    if (++fy == p.Ho) { fy = 0; ++fn; }
+                }
+            }
+            return;
+        }
         const int ox0 = csx * SEG, iy = coy - p.pad + ky, ix0 = ox0 - p.pad;
         const bf16_t *yb = dy + ((size_t)(cn * p.Ho + coy) * p.Wo + ox0) * p.ldy;
         const bf16_t *xb = x + ((long)(cn * p.Hi + iy) * p.Wi + ix0) * p.ldx;
@@ -277,7 +327,18 @@ int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, 
     const int spr = cdiv(d->Wo, SEG);
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
-    WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0, 0, 0, reflect};
+    WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0, 0, 0, reflect, 0};
+    // Flat pixel index where the rows leave more than 30 % of their 32-pixel segments empty (29x38: 41 %: 189 -> 154 us).  The
+    // per-piece address arithmetic of the flat walk costs ~9 % of a k-step: at 57x76 (21 % empty) it breaks even (153 -> 149, 149 -> 149 us),
+    // on wide rows (152, 304: 4 % empty) it loses 8-9 %.  RDFC_WGRAD_FLAT=0|1 forces.
+    static const int flat_env = getenv("RDFC_WGRAD_FLAT") ? atoi(getenv("RDFC_WGRAD_FLAT")) : -1;
+    const double ragged = 1.0 - (double)(d->Wo + 2) / (spr * SEG);
+    const bool flat_ok = d->Wo >= 32 && (long)d->N * d->Ho * (d->Wo + 2) < 2000000000L;
+    static const int nine_env = getenv("RDFC_WGRAD_GLDS_NINE") ? atoi(getenv("RDFC_WGRAD_GLDS_NINE")) : 0;
+    if (flat_ok && !nine_env && (flat_env == 1 || (flat_env != 0 && ragged > 0.30))) {
+        p.flat = 1;
+        p.total_segs = cdiv(d->N * d->Ho * (d->Wo + 2), SEG);
+    }
     // 128 x 128 tiles (8 waves, one workgroup per CU): A/B switch RDFC_WGRAD_GLDS=5 -- measured SLOWER at the batched step's sizes
     // (N = 16; 128 x 128 against the default): 256->256 @ 57x76 150-154 vs 146-148 us, 128->128 @ 114x152 189 vs 137 us, 512->512 @
     // 29x38 187 vs 181 us: halving the DMA'd bytes per MFMA does not pay for going from two 4-wave workgroups per CU to one

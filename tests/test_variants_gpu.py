@@ -19,6 +19,8 @@ VARIANTS = [
     ('RDFC_FUSED_STATS', '1', 'fused_statistics or stacked_batches'),               # conv-epilogue statistics (also under stacked-batch BatchNorm)
     ('RDFC_WGRAD_GLDS', '5', 'test_conv_fwd_dgrad_wgrad and bf16'),                 # 128 x 128 eight-wave weight-gradient tile
     ('RDFC_NORM_ONESTAGE', '1', 'test_norm_fwd_bwd or onestage'),                   # f64-atomic reductions
+    ('RDFC_WGRAD_FLAT', '1', '(test_conv_fwd_dgrad_wgrad and not f32) or reflection_pad_folded'),   # flat pixel walk of the weight gradient on every shape
+    ('RDFC_WGRAD_FLAT', '0', 'test_conv_fwd_dgrad_wgrad and bf16'),                  # ... and on none
 ]
 
 
