@@ -48,13 +48,15 @@ constexpr int WRING = 4;
 #endif
 // 128-co tiles: a ring of 3 (weights fetched two phases ahead) makes the workgroup 48 KB of LDS -> THREE per CU (the kernel needs
 // 168 registers): 256->256 @ 57x76 58.4 -> 52.7 us (its 640 workgroups now fit one round), 128->128 @ 114x152 60.2 -> 53.1,
-// 256->128 @ 114x152 98.2 -> 94.0; the 64-co tiles (2 x 21 KB of patch) stay at two per CU either way.  RDFC_GLDS_RING overrides.
+// 256->128 @ 114x152 98.2 -> 94.0.  The 64-co tiles (2 x 21 KB of patch) need a ring of TWO (weights fetched one phase ahead) to get
+// three workgroups on a CU (50 KB each): 64->64 @ 16x228x304 160 -> 134 us forward, 163 -> 136 input gradient, 128->64 244 -> 218.
+// RDFC_GLDS_RING overrides.
 #if defined(RDFC_GLDS_RING)
 template <int TCO> constexpr int ring_of() { return RDFC_GLDS_RING; }
 #elif defined(RDFC_GLDS_DEEP)
 template <int TCO> constexpr int ring_of() { return WRING; }
 #else
-template <int TCO> constexpr int ring_of() { return TCO == 128 ? 3 : WRING; }
+template <int TCO> constexpr int ring_of() { return TCO == 128 ? 3 : 2; }
 #endif
 
 __device__ inline int lay_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 2)) << 3); }
