@@ -15,8 +15,8 @@
 //   * a wave owns 64 co x 64 px (16 MFMAs per phase against 8 fragment reads, half the LDS traffic per MFMA
 //     of the 64x32 wave tile).
 // One barrier per tap.  Workgroups are 4 waves: 128 co x (8x16) px or 64 co x (16x16) px; LDS 2 x 12 KB patch +
-// 4 x 8 KB weights = 56 KB, or 2 x 21 KB + 4 x 4 KB + 1 KB = 59 KB: two workgroups per CU, 2 waves per SIMD
-// with the whole register file (64 accumulators + 32 fragment registers per lane; at the 128-register cap of a
+// 3 x 8 KB weights = 48 KB, or 2 x 21 KB + 2 x 4 KB + 1 KB = 51 KB (ring_of below): three workgroups per CU, 3 waves per
+// SIMD at 154-158 registers (64 accumulators + 32 fragment registers per lane; at the 128-register cap of a
 // 4-waves-per-SIMD build the compiler spilled, and a scratch reload is a vmcnt(0) that drains the DMA queue).
 #include "common.h"
 
