@@ -114,9 +114,59 @@ def cpu_baseline(B, H, W, exact_schedule=True, budget_s=150.0):
     times.sort()
     med = times[len(times) // 2]
     return dict(value=round(B / med, 5), unit='pairs/s', cores=torch.get_num_threads(), kind='port',
+                steps=len(times), warmup_steps=1, warmup_batch=1, budget_s=budget_s,
                 sample=f'{len(times)} timed train step(s) at batch {B} (median {med:.1f} s) after one warm-up step at batch 1 ({warm:.1f} s); '
                        f'upstream schedule incl. dead forwards, {H}x{W}, fp32 torch CPU oracle, torch threads {torch.get_num_threads()} on '
                        f'{os.cpu_count()} logical CPUs ({_cpu_model()})')
+
+
+def rmse_deviation(model, H, W, dev):
+    """North-star accuracy figure for the benchmarked storage type: |dense-depth RMSE (metres) of the eval path (forward_test ->
+    RDFGANMetric) - the same on the SAME weights and batch in the f32 parity mode|, max over 3 synthetic batches x 2 images.  The
+    f32 mode is what tests/test_modules_gpu.py::test_eval_path_end_to_end_* pins to the CPU oracle at 1e-4 m; nothing of oracle/
+    runs here."""
+    from rdfc_gan_amd import functional as Fh
+    from rdfc_gan_amd.metrics import RDFGANMetric
+    fast, worst = Fh.compute_dtype(), 0.0
+    if fast == torch.float32:
+        return 0.0
+    model.eval()
+    try:
+        for k in range(3):
+            b = synth_batch(2, H, W, 4242 + k, dev)
+            rm = {}
+            for dt in (fast, torch.float32):
+                Fh.set_compute_dtype(dt)
+                Fh.invalidate_packed_weights()
+                with torch.no_grad():
+                    out = model.forward_test(rgb=b['rgb'], raw_depth=b['raw_depth'], gt_normal=b['gt_normal'])
+                rm[dt] = RDFGANMetric().evaluate_normalised(b['gt_depth'], out['pred_depth'], None).double().cpu().numpy()[:, 0]
+            worst = max(worst, float(np.abs(rm[fast] - rm[torch.float32]).max()))
+    finally:
+        Fh.set_compute_dtype(fast)
+        Fh.invalidate_packed_weights()
+        model.train()
+    return worst
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run job (one process per GPU,
+    RCCL) before this process has touched the GPU -- a process that has initialised HIP must not exec another program on this
+    pool --, relay the ranks' output (rank 0 prints the JSON line last) and return the job's exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()          # (counting devices does not initialise the runtime)
+    if have < n:
+        print(f'bench.py: --gpus {n} but this node shows {have} GPU(s): refusing to report a smaller job under that label', file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -127,7 +177,10 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='pairs per GPU')
     ap.add_argument('--height', type=int, default=228)
     ap.add_argument('--width', type=int, default=304)
-    ap.add_argument('--dtype', choices=('bf16', 'f16', 'f32'), default='bf16')
+    ap.add_argument('--dtype', choices=('bf16', 'f16', 'f32'), default='f16',
+                    help='storage / MFMA operand type.  f16 (default): the one 16-bit format that meets the north-star accuracy figure '
+                         '(dense-depth RMSE within 1e-3 m of the f32 path; rounding the WEIGHTS to bf16 alone moves it by ~1.4e-3, '
+                         'tools/lowp_sim.py), same MFMA rate as bf16, dynamic loss scaling; bf16: BASELINE configs[1] as worded')
     ap.add_argument('--nlspn', action='store_true', help='BASELINE configs[2]: NLSPN refinement on')
     ap.add_argument('--exact-schedule', action='store_true', help="run upstream's two dead forwards too")
     ap.add_argument('--label-net', action='store_true', help='SURVEY 8f rank 1 (not the headline workload): G_label (PSPNet) twice '
@@ -147,6 +200,8 @@ def main():
     ap.add_argument('--by-shape', default=None, help='write a per-conv-shape time / TFLOP/s table (debug aid) to this file')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(_self_launch(a.gpus))
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -170,7 +225,7 @@ def main():
                 os.environ.setdefault(k, v)
         backend = os.environ.get('RDFC_BENCH_BACKEND', 'nccl')
         dist.init_process_group(backend, **(dict(device_id=dev) if backend == 'nccl' else {}))
-    assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}: the line would carry the wrong n_gpus'
 
     from rdfc_gan_amd import functional as Fh
     from rdfc_gan_amd import hip
@@ -273,6 +328,7 @@ def main():
         torch.cuda.synchronize()
         hip.PROFILE = None
         Fh.set_multi_stream(True)
+    rmse_dev = rmse_deviation(model, a.height, a.width, dev) if rank == 0 else None     # (untimed; no collective in the eval path)
     comm = None
     if world > 1 or a.rccl_self_test:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -314,6 +370,9 @@ def main():
                    unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 4 streams (main | depth branch, then the discriminators\' step | weight gradients | D_B\'s G-loss pass), batched calls' if not graphed else ('hip graphs (3 per step), ' + ('fork/join over the helper streams captured' if a.graph_multi_stream else 'one stream')),
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
+        out['rmse_dev_m'] = round(rmse_dev, 6)        # eval-path dense-depth RMSE of this dtype against the f32 parity mode, metres (north star: <= 1e-3)
+        if model.scaler is not None:
+            out['loss_scale'] = dict(scale=model.scaler.scale(), dynamic=model.scaler.dynamic, skipped_steps=model.scaler.skipped())
         if comm is not None:
             out['comm'] = comm
         if prof:
@@ -339,15 +398,15 @@ def main():
             # committed rocprofv3 passes over this same command (tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
             # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), apply to the default workload only and
             # are refused when they were taken from other kernel sources than the ones this library was built from
-            tfile = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
-            default_wl = (a.batch, a.height, a.width, a.dtype, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, 'bf16', False, False, False)   # (--full-objective sets label_net)
+            tfile = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+            default_wl = (a.batch, a.height, a.width, a.dtype, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, 'f16', False, False, False)   # (--full-objective sets label_net)
             if default_wl and os.path.exists(tfile):
-                from rdfc_gan_amd.build import source_hash
                 tab = json.load(open(tfile))
                 meta = tab.pop('_meta', {})
-                if meta.get('csrc_sha16') != source_hash():
-                    out['roofline']['traffic_note'] = (f"profiles/r02_pmc_traffic.json was measured on kernel sources {meta.get('csrc_sha16')}, this build is "
-                                                       f'{source_hash()}: stale counters refused (re-run tools/pmc_bench.sh)')
+                loaded = hip.build_hash()                  # compiled into the library that is actually loaded
+                if meta.get('csrc_sha16') != loaded:
+                    out['roofline']['traffic_note'] = (f"profiles/r03_pmc_traffic.json was measured on kernel sources {meta.get('csrc_sha16')}, the loaded library was built from "
+                                                       f'{loaded}: stale counters refused (re-run tools/pmc_bench.sh)')
                 else:
                     for k, v in tab.items():
                         if top + '(' in k:

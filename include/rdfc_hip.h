@@ -42,6 +42,9 @@ const char *rdfc_last_error(void);
  * Measurement aid only (bench.py's per-kernel roofline); no upstream counterpart. */
 const char *rdfc_last_kernel(void);
 int rdfc_version(void);
+/* sha256 (first 16 hex digits) of the kernel sources this library was built from (rdfc_gan_amd/build.py: source_hash()): measurement
+ * artefacts under profiles/ carry it, and bench.py refuses counters taken from another build.  No upstream counterpart. */
+const char *rdfc_build_hash(void);
 
 /* ------------------------------------------------------------------------------
  * Convolution family (implicit GEMM on MFMA).
@@ -286,6 +289,12 @@ int rdfc_mdconv_forward(const rdfc_mdconv_desc *d, const float *input, const flo
 int rdfc_mdconv_backward(const rdfc_mdconv_desc *d, const float *input, const float *offset, const float *mask,
                          const float *weight, const float *grad_out, float *grad_input, float *grad_offset,
                          float *grad_mask, float *grad_weight, float *grad_bias, void *stream);
+/* the same in double precision (upstream dispatches AT_DISPATCH_FLOATING_TYPES, modulated_deform_conv_cuda.cu:94,172) */
+int rdfc_mdconv_forward_f64(const rdfc_mdconv_desc *d, const double *input, const double *offset, const double *mask,
+                            const double *weight, const double *bias, double *output, void *stream);
+int rdfc_mdconv_backward_f64(const rdfc_mdconv_desc *d, const double *input, const double *offset, const double *mask,
+                             const double *weight, const double *grad_out, double *grad_input, double *grad_offset,
+                             double *grad_mask, double *grad_weight, double *grad_bias, void *stream);
 
 /* ------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam semantics (rdfc_gan.py:135-140) over one flat f32 buffer.
@@ -300,6 +309,21 @@ int rdfc_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_
  * can be captured into a HIP graph and replayed while the schedule advances. */
 int rdfc_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, const float *hyper,
                        float beta1, float beta2, float eps, float grad_scale, void *stream);
+
+/* Dynamic loss scaling for the f16 mode (the reference trains in f32 and has no counterpart; half precision needs the per-pixel
+ * loss gradients, ~1e-6, lifted into its normal range).  All state lives in device memory so that a step never waits for the host:
+ *   scaler  f32[4] = {scale, 1 / scale, steps since the last overflow, an optimizer skipped in this step}   (one per model)
+ *   ostate  f32[2] = {this step's gradients hold an inf / NaN, steps skipped so far}                          (one per optimizer)
+ * rdfc_grad_nonfinite sets ostate[0] from the (all-reduced) flat gradient; rdfc_adam_step_scaled is rdfc_adam_step / _adamw_step /
+ * _step_dev (hyper != NULL: {lr, step} from device memory) with the gradient scale grad_scale * scaler[1], skipped as a whole when
+ * ostate[0] != 0 (it then counts the skip and raises scaler[3]), bias corrections over the steps really taken; weight_decay = 0:
+ * Adam.  rdfc_loss_scale_update (once per step, after every optimizer): overflow -> scale *= backoff, else after `interval` clean
+ * steps scale *= growth (torch.cuda.amp.GradScaler's rule), clamped to [min_scale, max_scale]. */
+int rdfc_grad_nonfinite(const float *grad, size_t n, float *ostate, void *stream);
+int rdfc_adam_step_scaled(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, const float *hyper,
+                          int step, float beta1, float beta2, float eps, float weight_decay, float grad_scale, float *scaler,
+                          float *ostate, void *stream);
+int rdfc_loss_scale_update(float *scaler, float growth, float backoff, int interval, float min_scale, float max_scale, void *stream);
 
 /* Eval path: per-image RMSE, MAE, iRMSE, iMAE, REL, delta^1, delta^2, delta^3 of
  * RDFGANMetric.evaluate_all (lib/metrics/rdf_gan_metric.py:59-151) -> out[N][8] (f32), computed from the NORMALISED

@@ -9,6 +9,8 @@ sys.path as `DCN` and upstream's modulated_deform_conv_func.py 
 unchanged.  The deform_conv_* / deform_psroi_pooling_* exports of upstream are not on
 the hot path (never called by the model) and are not provided.
 """
+import torch
+
 from . import hip
 
 
@@ -22,8 +24,8 @@ def _check(input, weight, bias, offset, mask):
             raise RuntimeError(f'{name} must be a CUDA tensor (Not implement on cpu)')
         if t.dtype.is_floating_point and t.dtype != input.dtype:
             raise RuntimeError('all tensors must share one floating dtype')
-    if input.dtype.__str__() != 'torch.float32':
-        raise RuntimeError('rdfc_gan_amd.DCN implements float32 (upstream dispatches float32/float64)')
+    if input.dtype not in (torch.float32, torch.float64):      # AT_DISPATCH_FLOATING_TYPES (modulated_deform_conv_cuda.cu:94)
+        raise RuntimeError(f'"modulated_deform_conv_forward_cuda" not implemented for \'{input.dtype}\'')
 
 
 def modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w,
@@ -43,5 +45,12 @@ def modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, k
 def modulated_deform_conv_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w,
                                    pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, im2col_step):
     _check(input, weight, bias, offset, mask)
+    if weight.shape[2] != kernel_h or weight.shape[3] != kernel_w:
+        raise RuntimeError(f'Input shape and kernel shape wont match: ({weight.shape[2]} x {weight.shape[3]} vs {kernel_h} x {kernel_w}).')
+    if input.shape[1] != weight.shape[1] * group:
+        raise RuntimeError(f'Input shape and kernel channels wont match: ({input.shape[1]} vs {weight.shape[1] * group}).')
+    step = min(input.shape[0], im2col_step)
+    if input.shape[0] % step != 0:
+        raise RuntimeError(f'batch({input.shape[0]}) must divide im2col_step({step})')
     return list(hip.mdconv_backward(input, offset.contiguous(), mask.contiguous(), weight, grad_output.contiguous(),
                                     (stride_h, stride_w), (pad_h, pad_w), (dilation_h, dilation_w), group, deformable_group))

@@ -51,11 +51,27 @@ def _compile(src, hdr_mtime, force):
     return obj, True
 
 
+def _hash_object(force):
+    """rdfc_build_hash(): the hash of the kernel sources compiled INTO the library (bench.py compares measurement artefacts with
+    what is loaded, not with the files next to it; tests/test_abi_cpu.py requires it to equal source_hash(), so a stale
+    binary beside fresh sources is caught).  -> (object, rebuilt)"""
+    h = source_hash()
+    src, obj = os.path.join(OBJ, 'build_hash.cpp'), os.path.join(OBJ, 'build_hash.o')
+    text = f'extern "C" const char *rdfc_build_hash(void) {{ return "{h}"; }}\n'
+    if not force and os.path.exists(obj) and os.path.exists(src) and open(src).read() == text:
+        return obj, False
+    with open(src, 'w') as f:
+        f.write(text)
+    subprocess.check_call([os.environ.get('CXX', 'g++'), '-O2', '-fPIC', '-c', src, '-o', obj])
+    return obj, True
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hdr = _deps_mtime()
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
         res = list(ex.map(lambda s: _compile(s, hdr, force), _sources()))
+    res.append(_hash_object(force))
     objs = [o for o, _ in res]
     if force or any(ch for _, ch in res) or not os.path.exists(LIB):
         subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)

@@ -1,6 +1,6 @@
 // mdconv.hip -- modulated deformable convolution (DCNv2) forward / backward, the op
 // underneath upstream's `DCN` module (deformconv/src/cuda/modulated_deform_im2col_cuda.cuh,
-// modulated_deform_conv_cuda.cu).  NCHW f32.
+// modulated_deform_conv_cuda.cu).  NCHW f32 (and f64 through the generic kernels, like upstream's dispatch).
 //
 // Upstream materialises a [C*K, B*Ho*Wo] column buffer (im2col), runs a K=9 GEMM on it
 // and permutes the result.  Here the gather, the mask multiply and the tap sum are one
@@ -18,31 +18,34 @@ typedef rdfc_mdconv_desc D;
 
 __device__ inline int odim(int in, int pad, int dil, int k, int stride) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
 
-struct Corner {
+template <typename S> struct CornerT {
     int h0, w0;
-    float lh, lw;
+    S lh, lw;
     bool v00, v01, v10, v11;
 };
-__device__ inline Corner corners(float h, float w, int H, int W) {
-    Corner c;
-    c.h0 = (int)floorf(h);
-    c.w0 = (int)floorf(w);
+template <typename S> __device__ inline CornerT<S> corners(S h, S w, int H, int W) {
+    CornerT<S> c;
+    c.h0 = (int)floor(h);
+    c.w0 = (int)floor(w);
     c.lh = h - c.h0;
     c.lw = w - c.w0;
     const bool hl = c.h0 >= 0, hh = c.h0 + 1 <= H - 1, wl = c.w0 >= 0, wh = c.w0 + 1 <= W - 1;
     c.v00 = hl && wl; c.v01 = hl && wh; c.v10 = hh && wl; c.v11 = hh && wh;
     return c;
 }
-__device__ inline float bilinear(const float *im, int W, const Corner &c) {
-    const float a = c.v00 ? im[c.h0 * W + c.w0] : 0.f, b = c.v01 ? im[c.h0 * W + c.w0 + 1] : 0.f;
-    const float d = c.v10 ? im[(c.h0 + 1) * W + c.w0] : 0.f, e = c.v11 ? im[(c.h0 + 1) * W + c.w0 + 1] : 0.f;
-    const float hh = 1.f - c.lh, hw = 1.f - c.lw;
+template <typename S> __device__ inline S bilinear(const S *im, int W, const CornerT<S> &c) {
+    const S a = c.v00 ? im[c.h0 * W + c.w0] : S(0), b = c.v01 ? im[c.h0 * W + c.w0 + 1] : S(0);
+    const S d = c.v10 ? im[(c.h0 + 1) * W + c.w0] : S(0), e = c.v11 ? im[(c.h0 + 1) * W + c.w0 + 1] : S(0);
+    const S hh = S(1) - c.lh, hw = S(1) - c.lw;
     return hh * hw * a + hh * c.lw * b + c.lh * hw * d + c.lh * c.lw * e;
 }
 
-__global__ __launch_bounds__(NT) void fwd_kernel(D s, int Ho, int Wo, const float *__restrict__ in, const float *__restrict__ off,
-                                                 const float *__restrict__ msk, const float *__restrict__ wt,
-                                                 const float *__restrict__ bias, float *__restrict__ out) {
+typedef CornerT<float> Corner;
+
+template <typename S>
+__global__ __launch_bounds__(NT) void fwd_kernel(D s, int Ho, int Wo, const S *__restrict__ in, const S *__restrict__ off,
+                                                 const S *__restrict__ msk, const S *__restrict__ wt,
+                                                 const S *__restrict__ bias, S *__restrict__ out) {
     const int K = s.KH * s.KW, Cg = s.C / s.group, Cog = s.Co / s.group, Cdg = s.C / s.dgroup;
     const size_t HWo = (size_t)Ho * Wo, total = (size_t)s.B * s.Co * HWo;
     for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
@@ -50,19 +53,19 @@ __global__ __launch_bounds__(NT) void fwd_kernel(D s, int Ho, int Wo, const floa
         const int co = (int)((idx / HWo) % s.Co), b = (int)(idx / (HWo * s.Co));
         const int g = co / Cog;
         const size_t p = (size_t)h * Wo + w;
-        float acc = bias ? bias[co] : 0.f;
+        S acc = bias ? bias[co] : S(0);
         for (int cl = 0; cl < Cg; ++cl) {
             const int c = g * Cg + cl, dgi = c / Cdg;
-            const float *im = in + ((size_t)b * s.C + c) * s.H * s.W;
-            const float *o = off + ((size_t)b * s.dgroup + dgi) * 2 * K * HWo + p;
-            const float *m = msk + ((size_t)b * s.dgroup + dgi) * K * HWo + p;
-            const float *wp = wt + ((size_t)co * Cg + cl) * K;
+            const S *im = in + ((size_t)b * s.C + c) * s.H * s.W;
+            const S *o = off + ((size_t)b * s.dgroup + dgi) * 2 * K * HWo + p;
+            const S *m = msk + ((size_t)b * s.dgroup + dgi) * K * HWo + p;
+            const S *wp = wt + ((size_t)co * Cg + cl) * K;
             for (int i = 0; i < s.KH; ++i)
                 for (int j = 0; j < s.KW; ++j) {
                     const int k = i * s.KW + j;
-                    const float hi = h * s.sh - s.ph + i * s.dh + o[(size_t)(2 * k) * HWo];
-                    const float wi = w * s.sw - s.pw + j * s.dw + o[(size_t)(2 * k + 1) * HWo];
-                    if (hi > -1.f && wi > -1.f && hi < s.H && wi < s.W)
+                    const S hi = h * s.sh - s.ph + i * s.dh + o[(size_t)(2 * k) * HWo];
+                    const S wi = w * s.sw - s.pw + j * s.dw + o[(size_t)(2 * k + 1) * HWo];
+                    if (hi > -S(1) && wi > -S(1) && hi < s.H && wi < s.W)
                         acc += wp[k] * m[(size_t)k * HWo] * bilinear(im, s.W, corners(hi, wi, s.H, s.W));
                 }
         }
@@ -72,10 +75,11 @@ __global__ __launch_bounds__(NT) void fwd_kernel(D s, int Ho, int Wo, const floa
 
 // grad_offset / grad_mask (gather, deterministic) and grad_input (scatter, atomics):
 // one thread per (b, deformable group, tap, h, w).
-__global__ __launch_bounds__(NT) void bwd_kernel(D s, int Ho, int Wo, const float *__restrict__ in, const float *__restrict__ off,
-                                                 const float *__restrict__ msk, const float *__restrict__ wt,
-                                                 const float *__restrict__ go, float *__restrict__ gin, float *__restrict__ goff,
-                                                 float *__restrict__ gmsk) {
+template <typename S>
+__global__ __launch_bounds__(NT) void bwd_kernel(D s, int Ho, int Wo, const S *__restrict__ in, const S *__restrict__ off,
+                                                 const S *__restrict__ msk, const S *__restrict__ wt,
+                                                 const S *__restrict__ go, S *__restrict__ gin, S *__restrict__ goff,
+                                                 S *__restrict__ gmsk) {
     const int K = s.KH * s.KW, Cg = s.C / s.group, Cog = s.Co / s.group, Cdg = s.C / s.dgroup;
     const size_t HWo = (size_t)Ho * Wo, total = (size_t)s.B * s.dgroup * K * HWo;
     for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
@@ -84,30 +88,30 @@ __global__ __launch_bounds__(NT) void bwd_kernel(D s, int Ho, int Wo, const floa
         const int i = k / s.KW, j = k % s.KW;
         const size_t p = (size_t)h * Wo + w;
         const size_t ob = ((size_t)b * s.dgroup + dgi) * 2 * K * HWo + p, mb = ((size_t)b * s.dgroup + dgi) * K * HWo + p;
-        const float m = msk[mb + (size_t)k * HWo];
-        const float hi = h * s.sh - s.ph + i * s.dh + off[ob + (size_t)(2 * k) * HWo];
-        const float wi = w * s.sw - s.pw + j * s.dw + off[ob + (size_t)(2 * k + 1) * HWo];
-        const bool inside = !(hi <= -1.f || wi <= -1.f || hi >= s.H || wi >= s.W);
-        float g_oh = 0.f, g_ow = 0.f, g_m = 0.f;
+        const S m = msk[mb + (size_t)k * HWo];
+        const S hi = h * s.sh - s.ph + i * s.dh + off[ob + (size_t)(2 * k) * HWo];
+        const S wi = w * s.sw - s.pw + j * s.dw + off[ob + (size_t)(2 * k + 1) * HWo];
+        const bool inside = !(hi <= -S(1) || wi <= -S(1) || hi >= s.H || wi >= s.W);
+        S g_oh = S(0), g_ow = S(0), g_m = S(0);
         if (inside) {
-            const Corner c = corners(hi, wi, s.H, s.W);
-            const float hh = 1.f - c.lh, hw = 1.f - c.lw;
+            const CornerT<S> c = corners(hi, wi, s.H, s.W);
+            const S hh = S(1) - c.lh, hw = S(1) - c.lw;
             for (int cd = 0; cd < Cdg; ++cd) {
                 const int ch = dgi * Cdg + cd, g = ch / Cg, cl = ch % Cg;
-                float cg = 0.f;   // column gradient = W^T * grad_out
+                S cg = S(0);   // column gradient = W^T * grad_out
                 for (int q = 0; q < Cog; ++q) {
                     const int co = g * Cog + q;
                     cg += wt[((size_t)co * Cg + cl) * K + k] * go[((size_t)b * s.Co + co) * HWo + p];
                 }
-                const float *im = in + ((size_t)b * s.C + ch) * s.H * s.W;
-                const float a = c.v00 ? im[c.h0 * s.W + c.w0] : 0.f, bb = c.v01 ? im[c.h0 * s.W + c.w0 + 1] : 0.f;
-                const float d = c.v10 ? im[(c.h0 + 1) * s.W + c.w0] : 0.f, e = c.v11 ? im[(c.h0 + 1) * s.W + c.w0 + 1] : 0.f;
+                const S *im = in + ((size_t)b * s.C + ch) * s.H * s.W;
+                const S a = c.v00 ? im[c.h0 * s.W + c.w0] : S(0), bb = c.v01 ? im[c.h0 * s.W + c.w0 + 1] : S(0);
+                const S d = c.v10 ? im[(c.h0 + 1) * s.W + c.w0] : S(0), e = c.v11 ? im[(c.h0 + 1) * s.W + c.w0 + 1] : S(0);
                 g_m += cg * (hh * hw * a + hh * c.lw * bb + c.lh * hw * d + c.lh * c.lw * e);
                 g_oh += cg * m * (-hw * a - c.lw * bb + hw * d + c.lw * e);
                 g_ow += cg * m * (-hh * a + hh * bb - c.lh * d + c.lh * e);
                 if (gin) {
-                    float *gi = gin + ((size_t)b * s.C + ch) * s.H * s.W;
-                    const float t = cg * m;
+                    S *gi = gin + ((size_t)b * s.C + ch) * s.H * s.W;
+                    const S t = cg * m;
                     if (c.v00) atomicAdd(gi + c.h0 * s.W + c.w0, hh * hw * t);
                     if (c.v01) atomicAdd(gi + c.h0 * s.W + c.w0 + 1, hh * c.lw * t);
                     if (c.v10) atomicAdd(gi + (c.h0 + 1) * s.W + c.w0, c.lh * hw * t);
@@ -218,14 +222,15 @@ __global__ __launch_bounds__(NT) void bwd_c1_kernel(D s, int Ho, int Wo, int til
 }
 
 // grad_weight[co][cl][k] (block per element) and grad_bias[co] (extra blocks), block reduction over pixels
-__global__ __launch_bounds__(NT) void wgrad_kernel(D s, int Ho, int Wo, const float *__restrict__ in, const float *__restrict__ off,
-                                                   const float *__restrict__ msk, const float *__restrict__ go,
-                                                   float *__restrict__ gw, float *__restrict__ gb) {
+template <typename S>
+__global__ __launch_bounds__(NT) void wgrad_kernel(D s, int Ho, int Wo, const S *__restrict__ in, const S *__restrict__ off,
+                                                   const S *__restrict__ msk, const S *__restrict__ go,
+                                                   S *__restrict__ gw, S *__restrict__ gb) {
     const int K = s.KH * s.KW, Cg = s.C / s.group, Cog = s.Co / s.group, Cdg = s.C / s.dgroup;
     const size_t HWo = (size_t)Ho * Wo, npix = (size_t)s.B * HWo;
     const int nW = s.Co * Cg * K;
     const int e = blockIdx.x;
-    float acc = 0.f;
+    S acc = S(0);
     if (e < nW) {
         const int k = e % K, cl = (e / K) % Cg, co = e / (K * Cg);
         const int i = k / s.KW, j = k % s.KW, g = co / Cog, c = g * Cg + cl, dgi = c / Cdg;
@@ -234,9 +239,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(D s, int Ho, int Wo, const fl
             const size_t p = q % HWo;
             const int h = (int)(p / Wo), w = (int)(p % Wo);
             const size_t ob = ((size_t)b * s.dgroup + dgi) * 2 * K * HWo + p, mb = ((size_t)b * s.dgroup + dgi) * K * HWo + p;
-            const float hi = h * s.sh - s.ph + i * s.dh + off[ob + (size_t)(2 * k) * HWo];
-            const float wi = w * s.sw - s.pw + j * s.dw + off[ob + (size_t)(2 * k + 1) * HWo];
-            if (hi > -1.f && wi > -1.f && hi < s.H && wi < s.W)
+            const S hi = h * s.sh - s.ph + i * s.dh + off[ob + (size_t)(2 * k) * HWo];
+            const S wi = w * s.sw - s.pw + j * s.dw + off[ob + (size_t)(2 * k + 1) * HWo];
+            if (hi > -S(1) && wi > -S(1) && hi < s.H && wi < s.W)
                 acc += go[((size_t)b * s.Co + co) * HWo + p] * msk[mb + (size_t)k * HWo] *
                        bilinear(in + ((size_t)b * s.C + c) * s.H * s.W, s.W, corners(hi, wi, s.H, s.W));
         }
@@ -244,12 +249,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(D s, int Ho, int Wo, const fl
         const int co = e - nW;
         for (size_t q = threadIdx.x; q < npix; q += NT) acc += go[((size_t)(q / HWo) * s.Co + co) * HWo + q % HWo];
     }
-    acc = wave_sum(acc);
-    __shared__ float red[NT / 64];
+    for (int off_ = 32; off_ > 0; off_ >>= 1) acc += __shfl_down(acc, off_, 64);
+    __shared__ S red[NT / 64];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float t = red[0] + red[1] + red[2] + red[3];
+        const S t = red[0] + red[1] + red[2] + red[3];
         if (e < nW) { if (gw) gw[e] = t; }
         else if (gb) gb[e - nW] = t;
     }
@@ -268,49 +273,71 @@ inline int host_odim(int in, int pad, int dil, int k, int stride) { return (in +
 
 }  // namespace
 
-extern "C" int rdfc_mdconv_forward(const rdfc_mdconv_desc *d, const float *input, const float *offset, const float *mask,
-                                   const float *weight, const float *bias, float *output, void *stream) {
+template <typename S>
+static int mdconv_forward_t(const rdfc_mdconv_desc *d, const S *input, const S *offset, const S *mask, const S *weight, const S *bias,
+                            S *output, void *stream) {
     if (int e = check(d, "rdfc_mdconv_forward")) return e;
     const int Ho = host_odim(d->H, d->ph, d->dh, d->KH, d->sh), Wo = host_odim(d->W, d->pw, d->dw, d->KW, d->sw);
     RDFC_REQUIRE(Ho > 0 && Wo > 0, "rdfc_mdconv_forward: empty output");
     const size_t total = (size_t)d->B * d->Co * Ho * Wo;
     const int nb = (int)min((size_t)8192, (total + NT - 1) / NT);
-    hipLaunchKernelGGL(fwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, *d, Ho, Wo, input, offset, mask, weight, bias, output);
+    hipLaunchKernelGGL(fwd_kernel<S>, dim3(nb), dim3(NT), 0, (hipStream_t)stream, *d, Ho, Wo, input, offset, mask, weight, bias, output);
     RDFC_LAUNCH_CHECK("rdfc_mdconv_forward");
     return 0;
 }
 
-extern "C" int rdfc_mdconv_backward(const rdfc_mdconv_desc *d, const float *input, const float *offset, const float *mask,
-                                    const float *weight, const float *grad_out, float *grad_input, float *grad_offset,
-                                    float *grad_mask, float *grad_weight, float *grad_bias, void *stream) {
+template <typename S>
+static int mdconv_backward_t(const rdfc_mdconv_desc *d, const S *input, const S *offset, const S *mask, const S *weight, const S *grad_out,
+                             S *grad_input, S *grad_offset, S *grad_mask, S *grad_weight, S *grad_bias, void *stream) {
     if (int e = check(d, "rdfc_mdconv_backward")) return e;
     const int Ho = host_odim(d->H, d->ph, d->dh, d->KH, d->sh), Wo = host_odim(d->W, d->pw, d->dw, d->KW, d->sw);
     RDFC_REQUIRE(Ho > 0 && Wo > 0, "rdfc_mdconv_backward: empty output");
     hipStream_t st = (hipStream_t)stream;
     if (grad_input) {
-        if (hipMemsetAsync(grad_input, 0, sizeof(float) * d->B * d->C * d->H * d->W, st) != hipSuccess) {
+        if (hipMemsetAsync(grad_input, 0, sizeof(S) * d->B * d->C * d->H * d->W, st) != hipSuccess) {
             rdfc_set_error("rdfc_mdconv_backward: memset failed");
             return 2;
         }
     }
     static const bool c1_off = getenv("RDFC_MDCONV_GENERIC") != nullptr;
-    const bool c1 = !c1_off && d->C == 1 && d->Co == 1 && d->group == 1 && d->dgroup == 1 && d->sh == 1 && d->sw == 1 &&
+    const bool c1 = sizeof(S) == 4 && !c1_off && d->C == 1 && d->Co == 1 && d->group == 1 && d->dgroup == 1 && d->sh == 1 && d->sw == 1 &&
                     d->dh == 1 && d->dw == 1 && d->KH <= 3 && d->KW <= 3;
     if ((grad_input || grad_offset || grad_mask) && c1) {
         const int tiles_x = (Wo + C1_TW - 1) / C1_TW, tiles_y = (Ho + C1_TH - 1) / C1_TH;
         const size_t smem = 2 * sizeof(float) * (C1_TH + d->KH - 1 + 2 * C1_R) * (C1_TW + d->KW - 1 + 2 * C1_R);
-        hipLaunchKernelGGL(bwd_c1_kernel, dim3(tiles_x * tiles_y * d->B), dim3(NT), smem, st, *d, Ho, Wo, tiles_x, tiles_y, input,
-                           offset, mask, weight, grad_out, grad_input, grad_offset, grad_mask);
+        if constexpr (sizeof(S) == 4)
+            hipLaunchKernelGGL(bwd_c1_kernel, dim3(tiles_x * tiles_y * d->B), dim3(NT), smem, st, *d, Ho, Wo, tiles_x, tiles_y, input,
+                               offset, mask, weight, grad_out, grad_input, grad_offset, grad_mask);
     } else if (grad_input || grad_offset || grad_mask) {
         const size_t total = (size_t)d->B * d->dgroup * d->KH * d->KW * Ho * Wo;
         const int nb = (int)min((size_t)8192, (total + NT - 1) / NT);
-        hipLaunchKernelGGL(bwd_kernel, dim3(nb), dim3(NT), 0, st, *d, Ho, Wo, input, offset, mask, weight, grad_out, grad_input,
+        hipLaunchKernelGGL(bwd_kernel<S>, dim3(nb), dim3(NT), 0, st, *d, Ho, Wo, input, offset, mask, weight, grad_out, grad_input,
                            grad_offset, grad_mask);
     }
     if (grad_weight || grad_bias) {
         const int nW = d->Co * (d->C / d->group) * d->KH * d->KW;
-        hipLaunchKernelGGL(wgrad_kernel, dim3(nW + d->Co), dim3(NT), 0, st, *d, Ho, Wo, input, offset, mask, grad_out, grad_weight, grad_bias);
+        hipLaunchKernelGGL(wgrad_kernel<S>, dim3(nW + d->Co), dim3(NT), 0, st, *d, Ho, Wo, input, offset, mask, grad_out, grad_weight, grad_bias);
     }
     RDFC_LAUNCH_CHECK("rdfc_mdconv_backward");
     return 0;
+}
+
+extern "C" int rdfc_mdconv_forward(const rdfc_mdconv_desc *d, const float *input, const float *offset, const float *mask,
+                                   const float *weight, const float *bias, float *output, void *stream) {
+    return mdconv_forward_t<float>(d, input, offset, mask, weight, bias, output, stream);
+}
+extern "C" int rdfc_mdconv_backward(const rdfc_mdconv_desc *d, const float *input, const float *offset, const float *mask,
+                                    const float *weight, const float *grad_out, float *grad_input, float *grad_offset,
+                                    float *grad_mask, float *grad_weight, float *grad_bias, void *stream) {
+    return mdconv_backward_t<float>(d, input, offset, mask, weight, grad_out, grad_input, grad_offset, grad_mask, grad_weight, grad_bias, stream);
+}
+// double precision: upstream dispatches AT_DISPATCH_FLOATING_TYPES (modulated_deform_conv_cuda.cu:94) -- the generic kernels in f64
+extern "C" int rdfc_mdconv_forward_f64(const rdfc_mdconv_desc *d, const double *input, const double *offset, const double *mask,
+                                       const double *weight, const double *bias, double *output, void *stream) {
+    return mdconv_forward_t<double>(d, input, offset, mask, weight, bias, output, stream);
+}
+extern "C" int rdfc_mdconv_backward_f64(const rdfc_mdconv_desc *d, const double *input, const double *offset, const double *mask,
+                                        const double *weight, const double *grad_out, double *grad_input, double *grad_offset,
+                                        double *grad_mask, double *grad_weight, double *grad_bias, void *stream) {
+    return mdconv_backward_t<double>(d, input, offset, mask, weight, grad_out, grad_input, grad_offset, grad_mask, grad_weight, grad_bias, stream);
 }

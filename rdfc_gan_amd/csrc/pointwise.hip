@@ -334,6 +334,67 @@ __global__ void adam_dev_kernel(float *__restrict__ p, const float *__restrict__
     }
 }
 
+// ---- dynamic loss scaling (f16 mode): everything on the device, nothing the host has to wait for ---------------------------
+// scaler = {scale, 1 / scale, steps since the last overflow, overflow seen in this step}; ostate (per optimizer) = {a gradient of
+// this step is inf / NaN, steps skipped so far}.
+__global__ void grad_nonfinite_kernel(const float *__restrict__ g, size_t n, float *__restrict__ ostate) {
+    bool bad = false;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 t = reinterpret_cast<const f32x4 *>(g)[i];
+        // (x - x) is 0 for finite x, NaN for inf / NaN
+        const float z = (t[0] - t[0]) + (t[1] - t[1]) + (t[2] - t[2]) + (t[3] - t[3]);
+        bad |= !(z == 0.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float t = g[n4 * 4 + threadIdx.x];
+        bad |= !((t - t) == 0.f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) ostate[0] = 1.f;      // (same value from every writer)
+}
+// Adam / AdamW with the gradient scale 1 / (loss scale * world size) taken from the device, skipped as a whole when this
+// optimizer's gradients overflowed; bias corrections count the steps that were really taken (step - skipped)
+__global__ void adam_scaled_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                   size_t n, float lr_host, const float *__restrict__ hyper, int step_host, float b1, float b2, float eps,
+                                   float gscale, float weight_decay, const float *__restrict__ scaler, float *__restrict__ ostate,
+                                   float *__restrict__ scaler_flag) {
+    if (ostate[0] != 0.f) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ostate[1] += 1.f;
+            *scaler_flag = 1.f;
+        }
+        return;
+    }
+    const float lr = hyper != nullptr ? hyper[0] : lr_host;
+    const double t = (hyper != nullptr ? (double)hyper[1] : (double)step_host) - (double)ostate[1];
+    const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    const float gs = gscale * scaler[1], keep = 1.f - lr * weight_decay;
+    GRID_STRIDE(i, n) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] * keep - (lr / bc1) * (mi / denom);
+    }
+}
+__global__ void loss_scale_update_kernel(float *scaler, float growth, float backoff, float interval, float min_scale, float max_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = scaler[0], good = scaler[2];
+    if (scaler[3] != 0.f) {
+        s = fmaxf(s * backoff, min_scale);
+        good = 0.f;
+    } else if (++good >= interval) {
+        s = fminf(s * growth, max_scale);
+        good = 0.f;
+    }
+    scaler[0] = s;
+    scaler[1] = 1.f / s;
+    scaler[2] = good;
+    scaler[3] = 0.f;
+}
+
 // ---- evaluation metrics (eval path): one workgroup per image, one pass over (gt, pred[, mask]) ------------------------------
 // per image: RMSE, MAE, iRMSE, iMAE, REL, delta^1..3 over the pixels with gt > t_valid (& evaluate_mask); inputs are the
 // normalised maps, de-normalised on the fly (x * std + mean).  f64 accumulation, fixed order -> reproducible.
@@ -662,6 +723,39 @@ extern "C" int rdfc_adam_step_dev(float *param, const float *grad, float *m, flo
     hipLaunchKernelGGL(adam_dev_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, m, v, n, hyper, b1, b2, eps,
                        gscale);
     RDFC_LAUNCH_CHECK("rdfc_adam_step_dev");
+    return 0;
+}
+
+extern "C" int rdfc_grad_nonfinite(const float *grad, size_t n, float *ostate, void *stream) {
+    RDFC_REQUIRE(grad != nullptr && ostate != nullptr, "rdfc_grad_nonfinite: null pointer");
+    RDFC_REQUIRE(((uintptr_t)grad & 15) == 0, "rdfc_grad_nonfinite: the gradient buffer must be 16-byte aligned");
+    if (hipMemsetAsync(ostate, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        rdfc_set_error("rdfc_grad_nonfinite: hipMemsetAsync failed");
+        return 2;
+    }
+    hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(nblocks(n / 4 + 1)), dim3(NT), 0, (hipStream_t)stream, grad, n, ostate);
+    RDFC_LAUNCH_CHECK("rdfc_grad_nonfinite");
+    return 0;
+}
+
+extern "C" int rdfc_adam_step_scaled(float *param, const float *grad, float *m, float *v, size_t n, float lr, const float *hyper, int step,
+                                     float b1, float b2, float eps, float weight_decay, float gscale, float *scaler, float *ostate,
+                                     void *stream) {
+    RDFC_REQUIRE(scaler != nullptr && ostate != nullptr, "rdfc_adam_step_scaled: null scaler state");
+    RDFC_REQUIRE(hyper != nullptr || step >= 1, "rdfc_adam_step_scaled: step counts from 1");
+    hipLaunchKernelGGL(adam_scaled_kernel, dim3(nblocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, m, v, n, lr, hyper, step, b1, b2,
+                       eps, gscale, weight_decay, (const float *)scaler, ostate, scaler + 3);
+    RDFC_LAUNCH_CHECK("rdfc_adam_step_scaled");
+    return 0;
+}
+
+extern "C" int rdfc_loss_scale_update(float *scaler, float growth, float backoff, int interval, float min_scale, float max_scale,
+                                      void *stream) {
+    RDFC_REQUIRE(scaler != nullptr, "rdfc_loss_scale_update: null scaler state");
+    RDFC_REQUIRE(growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval >= 1, "rdfc_loss_scale_update: growth >= 1, 0 < backoff <= 1, interval >= 1");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler, growth, backoff, (float)interval, min_scale,
+                       max_scale);
+    RDFC_LAUNCH_CHECK("rdfc_loss_scale_update");
     return 0;
 }
 

@@ -394,7 +394,9 @@ class _ConvBlock(torch.autograd.Function):
                 g_prelu = sums[:, 2].sum().view(1)
         else:
             x, weight, yout = ctx.saved_tensors
-            if not (hip.is_pm(dz) and dz.data_ptr() % 16 == 0):   # (a channel slice of a concatenation's cotangent is read in place through its ld)
+            # a channel slice of a concatenation's cotangent is read in place through its pixel stride -- when base pointer AND pixel
+            # stride keep every pixel's vector aligned (a slice of a 64 + 3 channel map does not: copy it)
+            if not (hip.is_pm(dz) and dz.data_ptr() % 16 == 0 and hip.ld(dz) % (16 // dz.element_size()) == 0):
                 dz = dz.contiguous()
             if spec.act != 'none':
                 if dz.dtype != x.dtype:

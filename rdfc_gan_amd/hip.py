@@ -47,6 +47,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.rdfc_last_error.restype = C.c_char_p
         _lib.rdfc_last_kernel.restype = C.c_char_p
+        _lib.rdfc_build_hash.restype = C.c_char_p
         _declare_argtypes(_lib)
     return _lib
 
@@ -85,6 +86,11 @@ def _declare_argtypes(lib_):
         fn = getattr(lib_, name)
         fn.argtypes = types
         fn.restype = C.c_int
+
+
+def build_hash():
+    """hash of the kernel sources the LOADED library was compiled from (rdfc_build_hash)"""
+    return lib().rdfc_build_hash().decode()
 
 
 def _chk(rc, name):
@@ -648,6 +654,22 @@ def adam_step_dev(param, grad, m, v, hyper, b1, b2, eps, grad_scale=1.0):
                                   _f(eps), _f(grad_scale), _st()), 'rdfc_adam_step_dev')
 
 
+def grad_nonfinite(grad, ostate):
+    """ostate[0] <- 1 when the flat gradient holds an inf / NaN, else 0 (device side, no read-back)"""
+    _chk(lib().rdfc_grad_nonfinite(_p(grad), C.c_size_t(grad.numel()), _p(ostate), _st()), 'rdfc_grad_nonfinite')
+
+
+def adam_step_scaled(param, grad, m, v, lr, b1, b2, eps, step, scaler, ostate, grad_scale=1.0, weight_decay=0.0, hyper=None):
+    """Adam (weight_decay 0) / AdamW under dynamic loss scaling: include/rdfc_hip.h, rdfc_adam_step_scaled"""
+    _chk(lib().rdfc_adam_step_scaled(_p(param), _p(grad), _p(m), _p(v), C.c_size_t(param.numel()), _f(lr), _p(hyper), int(step), _f(b1),
+                                     _f(b2), _f(eps), _f(weight_decay), _f(grad_scale), _p(scaler), _p(ostate), _st()), 'rdfc_adam_step_scaled')
+
+
+def loss_scale_update(scaler, growth, backoff, interval, min_scale, max_scale):
+    _chk(lib().rdfc_loss_scale_update(_p(scaler), _f(growth), _f(backoff), int(interval), _f(min_scale), _f(max_scale), _st()),
+         'rdfc_loss_scale_update')
+
+
 def depth_metrics(gt_norm, pred_norm, evaluate_mask=None, std=5.0, mean=5.0, t_valid=1e-4):
     """normalised (N,1,H,W) | (N,H,W) f32 maps -> per-image metrics [N,8] (RMSE, MAE, iRMSE, iMAE, REL, d1, d2, d3)"""
     g, p_ = gt_norm.contiguous().float(), pred_norm.contiguous().float()
@@ -758,9 +780,9 @@ def mdconv_forward(inp, offset, mask, weight, bias, stride, pad, dil, group, dgr
     d = _md_desc(inp, weight, stride, pad, dil, group, dgroup)
     Ho = (d.H + 2 * d.ph - (d.dh * (d.KH - 1) + 1)) // d.sh + 1
     Wo = (d.W + 2 * d.pw - (d.dw * (d.KW - 1) + 1)) // d.sw + 1
-    out = torch.empty(d.B, d.Co, Ho, Wo, dtype=torch.float32, device=inp.device)
-    _chk(lib().rdfc_mdconv_forward(C.byref(d), _p(inp), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), _st()),
-         'rdfc_mdconv_forward')
+    out = torch.empty(d.B, d.Co, Ho, Wo, dtype=inp.dtype, device=inp.device)
+    fn = lib().rdfc_mdconv_forward_f64 if inp.dtype == torch.float64 else lib().rdfc_mdconv_forward
+    _chk(fn(C.byref(d), _p(inp), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), _st()), 'rdfc_mdconv_forward')
     return out
 
 
@@ -771,9 +793,10 @@ def mdconv_backward(inp, offset, mask, weight, grad_out, stride, pad, dil, group
     go = torch.empty_like(offset) if need[1] else None
     gm = torch.empty_like(mask) if need[2] else None
     gw = torch.empty_like(weight) if need[3] else None
-    gb = torch.empty(d.Co, dtype=torch.float32, device=inp.device) if need[4] else None
-    _chk(lib().rdfc_mdconv_backward(C.byref(d), _p(inp), _p(offset), _p(mask), _p(weight), _p(grad_out), _p(gi), _p(go),
-                                    _p(gm), _p(gw), _p(gb), _st()), 'rdfc_mdconv_backward')
+    gb = torch.empty(d.Co, dtype=inp.dtype, device=inp.device) if need[4] else None
+    fn = lib().rdfc_mdconv_backward_f64 if inp.dtype == torch.float64 else lib().rdfc_mdconv_backward
+    _chk(fn(C.byref(d), _p(inp), _p(offset), _p(mask), _p(weight), _p(grad_out), _p(gi), _p(go), _p(gm), _p(gw), _p(gb), _st()),
+         'rdfc_mdconv_backward')
     return gi, go, gm, gw, gb
 
 

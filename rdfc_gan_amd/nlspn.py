@@ -29,7 +29,7 @@ class ModulatedDeformConvFunction(Function):
         ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
         ctx.kernel_size = _pair(weight.shape[2:4])
         ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
-        output = DCN.modulated_deform_conv_forward(input.contiguous(), weight, bias, offset, mask, ctx.kernel_size[0],
+        output = DCN.modulated_deform_conv_forward(input, weight, bias, offset, mask, ctx.kernel_size[0],
                                                    ctx.kernel_size[1], ctx.stride[0], ctx.stride[1], ctx.padding[0],
                                                    ctx.padding[1], ctx.dilation[0], ctx.dilation[1], ctx.groups,
                                                    ctx.deformable_groups, ctx.im2col_step)
@@ -45,7 +45,7 @@ class ModulatedDeformConvFunction(Function):
         need = tuple(ctx.needs_input_grad[:5])
         if all(need):
             gi, go, gm, gw, gb = DCN.modulated_deform_conv_backward(
-                input.contiguous(), weight, bias, offset, mask, grad_output, ctx.kernel_size[0], ctx.kernel_size[1],
+                input, weight, bias, offset, mask, grad_output, ctx.kernel_size[0], ctx.kernel_size[1],
                 ctx.stride[0], ctx.stride[1], ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1], ctx.groups,
                 ctx.deformable_groups, ctx.im2col_step)
         else:

@@ -28,6 +28,45 @@ def _pview(buf, off, p):
     return buf[off:off + k].view(p.shape)
 
 
+class LossScaler:
+    """Loss scale of the f16 mode, kept on the device and shared by the optimizers of one model (include/rdfc_hip.h, "Dynamic
+    loss scaling").  Every backward starts from the cotangent `seed` (a 0-dim view of the device value); FlatAdam.step() checks
+    its all-reduced gradients for inf / NaN, skips the update when it finds one, and `update()` -- once per train step, behind
+    the optimizers -- halves the scale after an overflow and doubles it after `interval` clean steps (torch.cuda.amp.GradScaler's
+    rule).  dynamic=False: the scale stays put, an overflowing step is still skipped instead of poisoning Adam's moments and
+    the master weights.  Nothing here makes the host wait; `scale()` / `skipped()` read the device values back (reporting only)."""
+
+    def __init__(self, device, init_scale=1024.0, dynamic=True, growth=2.0, backoff=0.5, interval=2000, min_scale=1.0,
+                 max_scale=2.0 ** 24):
+        self.dynamic, self.growth, self.backoff, self.interval = bool(dynamic), float(growth), float(backoff), int(interval)
+        self.min_scale, self.max_scale = float(min_scale), float(max_scale)
+        self.state = torch.tensor([float(init_scale), 1.0 / float(init_scale), 0.0, 0.0], dtype=torch.float32, device=device)
+        self._optimizers = []
+
+    @property
+    def seed(self):
+        return self.state[0]
+
+    def attach(self, optimizer):
+        optimizer.scaler = self
+        optimizer._ostate = torch.zeros(2, dtype=torch.float32, device=self.state.device)
+        self._optimizers.append(optimizer)
+
+    def update(self):
+        g, b = (self.growth, self.backoff) if self.dynamic else (1.0, 1.0)
+        hip.loss_scale_update(self.state, g, b, self.interval, self.min_scale, self.max_scale)
+
+    def scale(self):
+        return float(self.state[0])
+
+    def set_scale(self, value):
+        self.state[:2] = torch.tensor([float(value), 1.0 / float(value)], dtype=torch.float32)
+
+    def skipped(self):
+        """steps each attached optimizer has skipped so far (host read-back)"""
+        return [int(o._ostate[1]) for o in self._optimizers]
+
+
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-3, betas=(0.5, 0.999), eps=1e-8, weight_decay=None):
         """weight_decay=None: torch.optim.Adam (rdfc_gan.py:135-140); a number: torch.optim.AdamW with that decoupled decay
@@ -55,7 +94,9 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = _pview(self.flat_grad, off, p)
                 off += k
         self.steps = 0
-        self.loss_scale = 1.0         # the gradients in flat_grad are this many times too large (static loss scaling, f16 mode)
+        self.loss_scale = 1.0         # the gradients in flat_grad are this many times too large (a fixed host-side factor)
+        self.scaler = None            # LossScaler.attach(): device-side (dynamic) loss scale + overflow check, replaces loss_scale
+        self._ostate = None           # device {overflow in this step, steps skipped}
         self._pending = []            # events of the in-flight bucket all-reduces
         self._buckets = [(0, n)]
         self._started = set()
@@ -78,6 +119,12 @@ class FlatAdam(torch.optim.Optimizer):
             if lr != self._hyper_lr:
                 self._hyper[0] = lr
                 self._hyper_lr = lr
+
+    def begin_step(self):
+        """per-step bookkeeping of the bucket exchange that must also run when zero_grad() does not -- a replayed HIP graph runs
+        the captured zero-fill but no Python: without this every bucket still counts as started from the capture on and the
+        replicas would stop exchanging gradients"""
+        self._started = set()
 
     def zero_grad(self, set_to_none=False):
         # (no join of the helper streams here: step() / the all-reduce joined them before they read the gradients, and the
@@ -193,14 +240,27 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         Fh.join_side_stream()
         self.wait_grads()
+        self._started = set()
         g = self.param_groups[0]
-        world = (dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1) * float(self.loss_scale)
+        nranks = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        world = nranks * float(self.loss_scale)
         if not self.flat.is_cuda:
             raise RuntimeError('FlatAdam.step runs the HIP kernel rdfc_adam_step: parameters must live on the GPU '
                                '(there is no CPU fallback)')
-        if self._adamw:
+        if self._adamw and self._hyper is not None:
+            raise RuntimeError('the AdamW update is not capturable (host-side lr / step arguments): graph mode covers Adam only')
+        if self.scaler is not None:
+            # f16 mode: the (all-reduced, so identical on every rank) gradients are checked on the device; an overflow skips the
+            # update as a whole and LossScaler.update() backs the scale off
+            hip.grad_nonfinite(self.flat_grad, self._ostate)
             if self._hyper is not None:
-                raise RuntimeError('the AdamW update is not capturable (host-side lr / step arguments): graph mode covers Adam only')
+                self._hyper[1:2] += 1.0
+            if self._hyper is None or self.host_counts:
+                self.steps += 1
+            hip.adam_step_scaled(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                                 self.steps, self.scaler.state, self._ostate, grad_scale=1.0 / world,
+                                 weight_decay=float(g.get('weight_decay') or 0.0) if self._adamw else 0.0, hyper=self._hyper)
+        elif self._adamw:
             self.steps += 1
             hip.adamw_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
                            float(g.get('weight_decay') or 0.0), self.steps, 1.0 / world)
@@ -216,12 +276,17 @@ class FlatAdam(torch.optim.Optimizer):
                           g['eps'], self.steps, 1.0 / world)
         Fh.weights_updated(self.flat)
 
+    def steps_taken(self):
+        """optimizer steps that really updated the parameters (steps minus those skipped for an overflow; reads the device)"""
+        return self.steps - (int(self._ostate[1]) if self._ostate is not None else 0)
+
     # ---- checkpoint format of torch.optim.Adam (lib/utils/checkpoint.py:21-58 stores optimizer.state_dict()) ----
     def state_dict(self):
         state, off = {}, 0
+        taken = self.steps_taken()
         for i, p in enumerate(self._params):
             k = p.numel()
-            state[i] = dict(step=torch.tensor(float(self.steps)),
+            state[i] = dict(step=torch.tensor(float(taken)),
                             exp_avg=_pview(self.exp_avg, off, p).clone(memory_format=torch.contiguous_format),
                             exp_avg_sq=_pview(self.exp_avg_sq, off, p).clone(memory_format=torch.contiguous_format))
             off += k
@@ -239,6 +304,8 @@ class FlatAdam(torch.optim.Optimizer):
                 _pview(self.exp_avg_sq, off, p).copy_(st['exp_avg_sq'])
                 self.steps = int(st['step'])
             off += k
+        if self._ostate is not None:
+            self._ostate.zero_()
         if self._hyper is not None:
             self._hyper[1] = float(self.steps)
         for k_, v in sd['param_groups'][0].items():
@@ -265,7 +332,7 @@ def dp_active():
 
 def broadcast_module_state(modules, src=0):
     """DDP-constructor semantics: every rank starts from rank `src`'s parameters and buffers."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not dp_active():         # (RDFC_DP_FORCE=1: a one-rank job broadcasts through the backend all the same)
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):

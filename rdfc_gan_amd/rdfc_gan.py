@@ -36,7 +36,7 @@ from .discriminator import build_discriminator
 from .gan_loss import GANLoss, L1_loss
 from .generator import build_generator
 from .init_weights import init_weights
-from .optim import FlatAdam, broadcast_module_state, dp_active
+from .optim import FlatAdam, LossScaler, broadcast_module_state, dp_active
 
 
 def norm_normalize(norm_out):
@@ -208,7 +208,7 @@ class RDFCGAN:
     def __init__(self, device, distributed, args, is_train=True, fixed_training_samples=None, fixed_testing_samples=None,
                  num_classes=14, out_height=224, out_width=304, label_wall=12, label_floor=5, label_ceiling=3,
                  normal_provider=None, exact_schedule=False, compute_dtype=None, use_label_net=False, normal_net=None,
-                 device_pepper=False, pepper_seed=0, batch_calls=None, loss_scale=None):
+                 device_pepper=False, pepper_seed=0, batch_calls=None, loss_scale=None, dynamic_loss_scale=True):
         self.device, self.distributed, self.args, self.is_train = device, distributed, args, is_train
         # G_label and the label / normal-consistency terms of loss_G (rdfc_gan.py:89,187-203,238-267): off by default -- the
         # benchmarked hot path is the four-network step; on, the step computes upstream's full objective except that the
@@ -235,12 +235,15 @@ class RDFCGAN:
         self.batch_calls = batch_calls
         if compute_dtype is not None:
             Fh.set_compute_dtype(compute_dtype)
-        # Static loss scaling: every backward starts from the cotangent `loss_scale` instead of 1 and the optimizers divide
-        # it out again (folded into the Adam kernel's gradient scale).  Needed in f16 mode only -- the per-pixel loss
-        # gradients (~1e-6) sit below half precision's normal range; f32 / bf16 keep 1.  Default 1024 for f16.
+        # Loss scaling (f16 mode only -- the per-pixel loss gradients, ~1e-6, sit below half precision's normal range; f32 / bf16
+        # keep 1): every backward starts from the cotangent `scale` instead of 1 and the optimizers divide it out again inside
+        # the Adam kernel.  The scale lives on the device (optim.LossScaler): the optimizers check their gradients for inf / NaN
+        # there, skip an overflowing step and -- dynamic_loss_scale, the default -- halve the scale after an overflow / double it
+        # after 2 000 clean steps.  loss_scale: the initial (or, dynamic_loss_scale=False, the fixed) value, default 1024.
         if loss_scale is None:
             loss_scale = 1024.0 if Fh.compute_dtype() == torch.float16 else 1.0
-        self.loss_scale = float(loss_scale)
+        self._init_loss_scale, self._dynamic_loss_scale = float(loss_scale), bool(dynamic_loss_scale)
+        self.scaler = None
         self.init_model()
         if self.is_train:
             self.init_optimizer()
@@ -278,8 +281,10 @@ class RDFCGAN:
         self.optimizer_G = FlatAdam(itertools.chain(self.G_A2B.parameters(), self.G_B2A.parameters()), lr=lr, betas=betas)
         self.optimizer_D = FlatAdam(itertools.chain(self.disc_A.parameters(), self.disc_B.parameters()), lr=lr, betas=betas)
         self.optimizers = dict(G=self.optimizer_G, D=self.optimizer_D)
-        for o in self.optimizers.values():
-            o.loss_scale = self.loss_scale
+        if self._init_loss_scale != 1.0:
+            self.scaler = LossScaler(self.device, self._init_loss_scale, dynamic=self._dynamic_loss_scale)
+            for o in self.optimizers.values():
+                self.scaler.attach(o)
         # Data-parallel exchange in buckets, in the order in which the gradients become final (upstream: DDP's 25 MB
         # reverse-order buckets, rdfc_gan.py:102-119).  G: G_B2A's backward completes first (bucket 0, started by a marker on
         # its input while G_A2B's backward still runs), then G_A2B in three chunks when the backward ends; D: one bucket per
@@ -298,12 +303,14 @@ class RDFCGAN:
         if self.use_label_net:
             self.optimizer_Label = FlatAdam(self.G_label.parameters(), lr=lr, betas=betas)   # rdfc_gan.py:145-147
             self.optimizers['label'] = self.optimizer_Label
-            self.optimizer_Label.loss_scale = self.loss_scale
+            if self.scaler is not None:
+                self.scaler.attach(self.optimizer_Label)
         if self.G_normal is not None:                                            # torch.optim.AdamW, lr / 2 (:141-144)
             self.optimizer_Normal = FlatAdam(self.G_normal.parameters(), lr=lr * 0.5, betas=betas,
                                              weight_decay=_cfg_get(a, 'weight_decay', 0.0))
             self.optimizers['Nor'] = self.optimizer_Normal
-            self.optimizer_Normal.loss_scale = self.loss_scale
+            if self.scaler is not None:
+                self.scaler.attach(self.optimizer_Normal)
 
     def init_lr_scheduler(self):
         a = self.args
@@ -634,14 +641,16 @@ class RDFCGAN:
         self._backward(loss_D)
         return loss_D_real, loss_D_fake, loss_D
 
+    @property
+    def loss_scale(self):
+        """current loss scale (reads the device value back: reporting only)"""
+        return self.scaler.scale() if self.scaler is not None else 1.0
+
     def _backward(self, loss):
-        if self.loss_scale == 1.0:
+        if self.scaler is None:
             loss.backward()
         else:
-            seed = self.__dict__.get('_scale_seed')
-            if seed is None or seed.device != loss.device:
-                seed = self._scale_seed = torch.full((), self.loss_scale, dtype=torch.float32, device=loss.device)
-            loss.backward(gradient=seed)
+            loss.backward(gradient=self.scaler.seed)
 
     def backward_D_A2B(self):
         r, f, d = self.backward_D_basic(self.disc_A, self.real_B, self.fake_B, names=('loss_D_A', 'loss_D_A_real', 'loss_D_A_fake'))
@@ -722,6 +731,8 @@ class RDFCGAN:
     def _seg_adam(self):
         self.optimizer_G.step()
         self.optimizer_D.step()
+        if self.scaler is not None:
+            self.scaler.update()
 
     def _bn_modules(self):
         return [m for net in self.models.values() for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
@@ -780,6 +791,8 @@ class RDFCGAN:
                 self.set_input(self._batch)
                 return self.optimize_parameters(sync_losses)
         g1, g2, g3, stats = self._graphs
+        for o in self.optimizers.values():
+            o.begin_step()                  # (a replay runs no Python: the buckets' per-step state is reset here)
         g1.replay()
         self.optimizer_G.all_reduce_grads_async()
         g2.replay()
@@ -876,6 +889,8 @@ class RDFCGAN:
         if self.use_label_net:
             self.optimizer_Label.step()
         self.optimizer_D.step()
+        if self.scaler is not None:
+            self.scaler.update()
         # nothing of this step's autograd graph may outlive it (a later HIP-graph capture builds its own nodes: _capture)
         self._D_hook = self._D_stats = self._fork_D = None
 

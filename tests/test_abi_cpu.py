@@ -44,3 +44,11 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f'{f} imports oracle'
+
+
+def test_loaded_library_was_built_from_these_sources():
+    """rdfc_build_hash() is compiled into the library; it must name the kernel sources that lie next to it (a stale binary
+    beside fresh sources would otherwise pass every source-level check of measurement artefacts)."""
+    from rdfc_gan_amd import build, hip
+    build.build(verbose=False)
+    assert hip.build_hash() == build.source_hash()

@@ -498,9 +498,13 @@ def test_graph_capture_after_eager_steps():
 @pytest.mark.parametrize('dtype', DT, ids=IDS)
 def test_eval_path_end_to_end_metrics_within_north_star_tolerance(dtype):
     """forward_test -> RDFGANMetric.evaluate_normalised (228x304) against the CPU oracle's generator + oracle.metrics on the same
-    weights and batch, with a ground truth UNRELATED to the prediction (RMSE ~2.5 m: a bias of the prediction moves it one for one).
-    f32 mode (the stated-fp32-tolerance mode of BASELINE.json's acceptance figure, dense-depth RMSE within 1e-3 m): 1e-4;
-    bf16 mode (the benchmarked one): 3e-3 -- measured 1.5e-3."""
+    weights and batch, with a ground truth UNRELATED to the prediction (RMSE ~2.5 m: a bias of the prediction moves it one for
+    one), three input seeds.  BASELINE.json's acceptance figure is "dense-depth RMSE within 1e-3 of reference":
+      f32 (parity mode)           1e-4 m;
+      f16 (the benchmarked mode)  1e-3 m -- measured <= 3.3e-4 over five weight seeds (tools/lowp_sim.py);
+      bf16                        3e-3 m -- measured 1.2-1.5e-3.  Rounding the conv WEIGHTS to 8 significant bits is a fixed
+        perturbation of the function: it shifts the mean prediction by ~3e-4 (normalised) = 1.5e-3 m whatever the activations
+        are stored in (weights alone: 1.47e-3; activations alone: 9e-5), which is why the benchmark's default is f16."""
     from oracle import metrics as om
     from oracle import nets as on
     from rdfc_gan_amd.metrics import RDFGANMetric
@@ -511,21 +515,25 @@ def test_eval_path_end_to_end_metrics_within_north_star_tolerance(dtype):
     from rdfc_gan_amd import functional as Fh
     Fh.invalidate_packed_weights()
     m.eval()
-    rgb, raw, normal = gen_inputs('eval_e2e', 2, 228, 304)
-    gt = (raw * 0.9 + 0.05).clamp(-1, 1)                       # any fixed "ground truth" with holes where raw has them
-    gt[raw <= -1.0] = -1.0
-    out = m.forward_test(rgb=rgb, raw_depth=raw, gt_normal=normal)
-    got = RDFGANMetric().evaluate_normalised(gt.to(DEV), out['pred_depth'], None).double().cpu().numpy()
     ref_net = on.RDFGenerator()
     ref_net.load_state_dict(det_state_dict(ref_net.state_dict(), 0))
     ref_net.eval()
-    with torch.no_grad():
-        pred_ref = ref_net(rgb, raw, normal)['pred_depth']
-    ref = np.stack([om.image_metrics(om.denormalise(gt[k].numpy()), om.denormalise(pred_ref[k].numpy()), acc=np.float64) for k in range(2)])
-    lim = 1e-4 if dtype == torch.float32 else 3e-3
-    assert np.abs(got[:, 0] - ref[:, 0]).max() < lim, (got[:, 0], ref[:, 0])             # RMSE, metres
-    assert np.abs(got[:, 1] - ref[:, 1]).max() < lim                                     # MAE
-    assert np.abs(got[:, 4:] - ref[:, 4:]).max() < (2e-4 if dtype == torch.float32 else 3e-3)   # REL, delta^1..3
+    lim = {torch.float32: 1e-4, torch.float16: 1e-3, torch.bfloat16: 3e-3}[dtype]
+    worst = 0.0
+    for tag in ('eval_e2e', 'eval_e2e_b', 'eval_e2e_c'):
+        rgb, raw, normal = gen_inputs(tag, 2, 228, 304)
+        gt = (raw * 0.9 + 0.05).clamp(-1, 1)                       # any fixed "ground truth" with holes where raw has them
+        gt[raw <= -1.0] = -1.0
+        out = m.forward_test(rgb=rgb, raw_depth=raw, gt_normal=normal)
+        got = RDFGANMetric().evaluate_normalised(gt.to(DEV), out['pred_depth'], None).double().cpu().numpy()
+        with torch.no_grad():
+            pred_ref = ref_net(rgb, raw, normal)['pred_depth']
+        ref = np.stack([om.image_metrics(om.denormalise(gt[k].numpy()), om.denormalise(pred_ref[k].numpy()), acc=np.float64) for k in range(2)])
+        worst = max(worst, float(np.abs(got[:, 0] - ref[:, 0]).max()))
+        assert np.abs(got[:, 0] - ref[:, 0]).max() < lim, (tag, got[:, 0], ref[:, 0])        # RMSE, metres
+        assert np.abs(got[:, 1] - ref[:, 1]).max() < lim, tag                                # MAE
+        assert np.abs(got[:, 4:] - ref[:, 4:]).max() < (2e-4 if dtype == torch.float32 else 3e-3), tag   # REL, delta^1..3
+    print(f'[eval path] {dtype}: worst |RMSE - reference RMSE| over 3 seeds x 2 images = {worst:.2e} m (limit {lim:.0e})')
 
 
 # ---- full-size step: the HIP train step in every compute dtype against the oracle's step on the same inputs ------------------

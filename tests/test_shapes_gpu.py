@@ -1,0 +1,241 @@
+"""GPU: the BASELINE.json configurations at their OWN shapes (the module / step parity tests run at 60x76 and B = 2 at 228x304):
+  * configs[4]: 480x640, batch 4, f16 activations with f32 loss accumulation -- one train step + the eval forward against the oracle;
+  * configs[1]: batch 8 (16 stacked samples per pass) at 228x304 -- the batched schedule against the unbatched one, BatchNorm
+    buffers included, and a bf16 / f16 step;
+  * configs[2]: NLSPN with 18 propagation steps at 228x304 against oracle.nlspn;
+  * the per-pixel loss kernel against the reference's own values (tests/golden/losses.npz);
+  * build_model() with the dict train.py:87-103 assembles from upstream's YAML."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from cases import NLSPN_CFG, gen_inputs, step_batch
+from detweights import det_state_dict, det_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def setup_dtype(dtype):
+    from rdfc_gan_amd import functional as Fh
+    Fh.set_compute_dtype(dtype)
+    Fh.invalidate_packed_weights()
+
+
+def _cfg(lr=2e-3):
+    return dict(local_rank=0, lr=lr, beta1=0.5, beta2=0.999, gan_loss_type='lsgan',
+                model=dict(G_A2B=dict(type='RDFGenerator', pretrained_on_imagenet=False),
+                           G_B2A=dict(type='ResnetGenerator', input_channels=1, output_channels=3, ngf=64, norm_layer='IN2d'),
+                           D_A=dict(type='PatchGANDiscriminator', in_channels=1, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'),
+                           D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU')))
+
+
+def _load_det(model):
+    from rdfc_gan_amd import functional as Fh
+    for name, net in model.models.items():
+        net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    Fh.invalidate_packed_weights()
+
+
+def _one_step(model, B, H, W, seed=0):
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    data, nA, _ = step_batch(0, B, H, W)
+    data['gt_normal'] = nA
+    model.set_input(data)
+    return model.optimize_parameters()
+
+
+def test_config5_480x640_batch4_f16_step_and_eval_forward():
+    """SUN RGB-D shape of BASELINE configs[4] (both sides divisible by 16: no crop path; 30x40 ... 480x640 maps): one optimisation
+    step in f16 with dynamic loss scaling -- finite losses, no skipped update, gradients exchanged at the initial scale -- and
+    G_A2B's eval forward at this size against the CPU oracle on the same weights (B = 1)."""
+    from oracle import nets as on
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    setup_dtype(torch.float16)
+    m = RDFCGAN(torch.device(DEV), False, _cfg(), is_train=True)
+    _load_det(m)
+    m.train()
+    losses = _one_step(m, 4, 480, 640)
+    assert len(losses) == 13 and all(np.isfinite(v) for v in losses.values()), losses
+    assert m.scaler is not None and m.scaler.skipped() == [0, 0] and m.scaler.scale() == 1024.0
+    for o in m.optimizers.values():
+        assert bool(torch.isfinite(o.flat).all())
+    # eval forward at 480x640 against the oracle: f16 storage, outputs in [-1, 1]
+    ref = on.RDFGenerator()
+    ref.load_state_dict(det_state_dict(ref.state_dict(), 0))
+    ref.eval()
+    net = m.G_A2B
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    from rdfc_gan_amd import functional as Fh
+    Fh.invalidate_packed_weights()
+    net.eval()
+    rgb, raw, normal = gen_inputs('cfg5', 1, 480, 640)
+    with torch.no_grad():
+        exp = ref(rgb, raw, normal)
+        got = net(rgb.to(DEV), raw.to(DEV), normal.to(DEV))
+    for k in ('pred_depth', 'depth_map_1', 'depth_map_2', 'confidence_map_1', 'confidence_map_2'):
+        e = (got[k].float().cpu() - exp[k]).abs()
+        assert float(e.max()) < 2e-2 and float(e.pow(2).mean().sqrt()) < 2e-3, (k, float(e.max()))      # (228x304, f16: 9.5e-3 max)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_config2_batch8_step_is_finite(dtype):
+    """the benchmark's launch sizes (16 stacked samples per pass at 228x304) in both 16-bit modes: two steps, finite losses and weights"""
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    setup_dtype(dtype)
+    m = RDFCGAN(torch.device(DEV), False, _cfg(), is_train=True)
+    _load_det(m)
+    m.train()
+    assert m._batched()
+    for it in range(2):
+        losses = _one_step(m, 8, 228, 304, seed=it)
+        assert all(np.isfinite(v) for v in losses.values()), (it, losses)
+    for o in m.optimizers.values():
+        assert bool(torch.isfinite(o.flat).all())
+    if m.scaler is not None:
+        assert m.scaler.skipped() == [0, 0]
+
+
+def test_config2_batch8_batched_schedule_equals_unbatched_f32():
+    """At batch 8 the batched schedule (each network once over [real | fake] stacked, BatchNorm statistics per half) must leave
+    behind what upstream's call-by-call schedule does: same losses, same BatchNorm running statistics and batch counts, same
+    updated weights (f32 mode; the two differ in launch shapes and summation order only)."""
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    setup_dtype(torch.float32)
+    out = {}
+    for batched in (True, False):
+        m = RDFCGAN(torch.device(DEV), False, _cfg(), is_train=True, batch_calls=batched)
+        _load_det(m)
+        m.train()
+        assert m._batched() == batched
+        losses = _one_step(m, 8, 228, 304)
+        bufs = {f'{n}.{k}': v.detach().double().cpu() for n, net in m.models.items() for k, v in net.named_buffers()}
+        wts = {n: o.flat.detach().double().cpu() for n, o in m.optimizers.items()}
+        out[batched] = (losses, bufs, wts)
+        del m
+        torch.cuda.empty_cache()
+    (la, ba, wa), (lb, bb, wb) = out[True], out[False]
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-5 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    assert ba.keys() == bb.keys() and any(k.endswith('num_batches_tracked') for k in ba)
+    for k in ba:
+        if k.endswith('num_batches_tracked'):
+            assert float(ba[k]) == float(bb[k]), k
+        else:
+            assert float((ba[k] - bb[k]).abs().max()) <= 1e-5 * float(bb[k].abs().max() + 1e-3), k
+    for n in wa:         # one Adam step moves every weight by ~lr whatever its gradient: compare the update directions in bulk
+        d = (wa[n] - wb[n]).abs()
+        # (entries whose gradient is rounding noise -- conv biases in front of an InstanceNorm -- take +-lr steps of either sign)
+        assert float(d.mean()) < 5e-5 and float((d > 1e-3).double().mean()) < 1e-2, (n, float(d.mean()), float((d > 1e-3).double().mean()))
+
+
+def test_config3_nlspn_18_steps_228x304_against_oracle():
+    """the shipped NLSPN configuration (prop_time 18, TGASS, confidence propagation) at the benchmark resolution, f32, against
+    oracle.nlspn on the same guidance-conv weights: output, and the gradients of the initial map / confidence / guidance"""
+    from oracle.nlspn import NLSPNProp
+    from rdfc_gan_amd import functional as Fh
+    from rdfc_gan_amd.nlspn import NLPSN
+    setup_dtype(torch.float32)
+    B, H, W, T = 1, 228, 304, NLSPN_CFG['prop_time']
+    guide = det_tensor(61, 'guide', (B, 8, H, W))
+    init = det_tensor(61, 'init', (B, 1, H, W))
+    conf = torch.sigmoid(det_tensor(61, 'conf', (B, 1, H, W)))
+    gout = det_tensor(61, 'gout', (B, 1, H, W))
+    w, b = det_tensor(61, 'w', (24, 8, 3, 3)) * 0.1, det_tensor(61, 'b', (24,)) * 0.1
+    ref = NLSPNProp(8, 3, T, 'TGASS', 0.5, conf_prop=True)
+    m = NLPSN(8, 1, 3, 3, T, 'TGASS', 0.5, True, False).to(DEV)
+    with torch.no_grad():
+        for mod in (ref, m):
+            mod.conv_offset_aff.weight.copy_(w)
+            mod.conv_offset_aff.bias.copy_(b)
+    Fh.invalidate_packed_weights()
+    g_r, i_r, c_r = (t.clone().requires_grad_(True) for t in (guide, init, conf))
+    y_r, _, _ = ref(i_r, g_r, c_r)
+    y_r.backward(gout)
+    g_d = guide.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    i_d, c_d = init.to(DEV).requires_grad_(True), conf.to(DEV).requires_grad_(True)
+    assert m._fused()
+    y_d, feats, _, _, _ = m(i_d, g_d, c_d)
+    assert len(feats) == T
+    y_d.backward(gout.to(DEV))
+
+    def rel(a, b_):
+        a, b_ = a.double().cpu(), b_.double()
+        return float((a - b_).norm() / (b_.norm() + 1e-30))
+    assert float((y_d.detach().cpu() - y_r.detach()).abs().max()) < 1e-4
+    assert rel(i_d.grad, i_r.grad) < 2e-4 and rel(c_d.grad, c_r.grad) < 2e-4
+    assert rel(g_d.grad.permute(0, 3, 1, 2), g_r.grad) < 5e-4
+    assert abs(float(m.aff_scale_const.grad) - float(ref.aff_scale_const.grad)) < 5e-4 * max(1.0, abs(float(ref.aff_scale_const.grad)))
+
+
+def test_loss_kernel_against_reference_values(golden):
+    """GANLoss('lsgan') / L1_loss / L2_loss (lib/losses/gan_loss.py:6-42, 104-120, 169-206) on the HIP reduction against the values
+    and gradients the reference's own functions returned for these inputs (tests/golden/losses.npz, make_golden.py:losses)"""
+    from rdfc_gan_amd.gan_loss import GANLoss, L1_loss, L2_loss
+    g = golden('losses')
+    p = det_tensor(5, 'p', (2, 1, 26, 36)).to(DEV).requires_grad_(True)
+    crit = GANLoss('lsgan').to(DEV)
+    for real in (True, False):
+        v = crit(p, real)
+        gr, = torch.autograd.grad(v, p)
+        np.testing.assert_allclose(float(v), g[f'gan.lsgan.{int(real)}'], rtol=2e-6)
+        np.testing.assert_allclose(gr.cpu().numpy(), g[f'gan.lsgan.{int(real)}.grad'], rtol=1e-5, atol=1e-9)
+    for C in (1, 3):
+        a = det_tensor(5, f'a{C}', (2, C, 20, 24)).to(DEV).requires_grad_(True)
+        b = det_tensor(5, f'b{C}', (2, C, 20, 24)).to(DEV)
+        msk = det_tensor(5, 'm', (2, 1, 20, 24), 'rand') > 0.3
+        w = (msk / (msk.sum() + 1e-6)).to(DEV)
+        for nm, fn in (('l1', L1_loss), ('l2', L2_loss)):
+            for wn, ww in (('w', w), ('u', None)):
+                v = fn(a, b, weight=ww)
+                gr, = torch.autograd.grad(v, a)
+                np.testing.assert_allclose(float(v), g[f'{nm}.{C}.{wn}'], rtol=2e-6)
+                np.testing.assert_allclose(gr.cpu().numpy(), g[f'{nm}.{C}.{wn}.grad'], rtol=1e-5, atol=1e-9)
+
+
+def test_build_model_with_the_dict_train_py_assembles():
+    """train.py:84-103: model_cfg = dict(type=cfg.model.type, device, distributed, args=cfg, is_train, fixed_*_samples, num_classes,
+    out_height, out_width, label_wall, label_floor, label_ceiling) with cfg = upstream's attribute-style config (the YAML of
+    config/rdf_cycle_patchgan_config.yaml merged with config.py's defaults) -> build_model(model_cfg).  The object must offer
+    the surface train.py / test.py touch (base.py:28-157) and step on a batch with upstream's keys."""
+    from rdfc_gan_amd.build_model import build_model
+    setup_dtype(torch.bfloat16)
+
+    def ns(d):
+        return types.SimpleNamespace(**{k: ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+    yaml_model = dict(type='RDFCGAN',
+                      G_A2B=dict(type='RDFGenerator', encoder_rgb='resnet18', encoder_depth='resnet18', pretrained_on_imagenet=True,
+                                 semantic_channels_in=3, fuse_depth_in_rgb_decoder='WAdaIN', bn=True, rgb_skip_connection_type='concat',
+                                 depth_skip_connection_type='concat', adain_weighting=False,
+                                 rgb_channels_encoder=[64, 64, 128, 256, 512, 512], depth_channels_encoder=[64, 64, 128, 256, 512, 512],
+                                 rgb_channels_decoder=[256, 128, 64, 64], depth_channels_decoder=[256, 128, 64, 64]),
+                      G_B2A=dict(type='ResnetGenerator', input_channels=1, output_channels=3, ngf=64, norm_layer='IN2d'),
+                      Normal_G=dict(sampling_ratio=0.4, importance_ratio=0.7, architecture='BN'),
+                      D_A=dict(type='PatchGANDiscriminator', in_channels=1, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'),
+                      D_B=dict(type='PatchGANDiscriminator', in_channels=3, norm_cfg=dict(type='BN2d'), activation='LeakyReLU'))
+    cfg = ns(dict(model=yaml_model, local_rank=0, lr=2e-4, beta1=0.5, beta2=0.999, gan_loss_type='lsgan', lambda_A=10.0, lambda_B=10.0,
+                  lambda_L1=100.0, scheduler='linear', epoch=0, decay_epoch=100, n_epochs=200, num_classes=14, out_height=224,
+                  out_width=304, label_wall=12, label_floor=5, label_ceiling=3, steps_per_epoch=10, load_from=None))
+    model_cfg = dict(type=cfg.model.type, device=torch.device(DEV), distributed=False, args=cfg, is_train=True,
+                     fixed_testing_samples=None, fixed_training_samples=None, num_classes=cfg.num_classes, out_height=cfg.out_height,
+                     out_width=cfg.out_width, label_wall=cfg.label_wall, label_floor=cfg.label_floor, label_ceiling=cfg.label_ceiling)
+    model = build_model(model_cfg)
+    for attr in ('set_input', 'optimize_parameters', 'forward_test', '__call__', 'eval', 'train', 'load_from', 'resume_from', 'save_ckpt',
+                 'save_samples', 'update_learning_rate', 'generator', 'reduce_loss'):
+        assert callable(getattr(model, attr)), attr
+    model.train()
+    data, nA, _ = step_batch(0, 2, 60, 76)
+    data['gt_normal'] = nA
+    model.set_input(data)
+    losses = model.optimize_parameters()
+    assert set(losses) >= {'loss_G', 'loss_D_A', 'loss_D_B', 'loss_G_A2B', 'loss_G_B2A', 'loss_cycle_A2B', 'loss_cycle_B2A', 'loss_A2B_L1'} and len(losses) == 13
+    assert all(isinstance(v, float) and np.isfinite(v) for v in losses.values())
+    model.eval()
+    out = model(rgb=data['rgb'], raw_depth=data['raw_depth'], gt_normal=data['gt_normal'])
+    assert tuple(out['pred_depth'].shape) == (2, 1, 60, 76)
+    with pytest.raises(KeyError):
+        build_model(dict(model_cfg, type='NoSuchModel'))
