@@ -593,10 +593,15 @@ int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G) {
 // stats != nullptr (forward only): also write the per-tile normalisation statistics, G groups.
 int rdfc_conv3x3_glds_covers(const rdfc_conv_desc *d) { return glds_shape_ok(d, 0) ? 1 : 0; }
 
+int rdfc_try_conv3x3_pp(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
+                        hipStream_t st, const void *addend, int ld_add, int reflect);          // conv_pp.hip
+
 int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st, float *stats = nullptr, int G = 0, const void *addend = nullptr, int ld_add = 0, int reflect = 0) {
     static const int mode = getenv("RDFC_GLDS") ? atoi(getenv("RDFC_GLDS")) : 1;
     if (!glds_shape_ok(d, transposed)) return 0;
+    // the ping-pong kernel (8 waves, one workgroup per CU) takes the shapes it covers unless the fused statistics are wanted
+    if (stats == nullptr && rdfc_try_conv3x3_pp(d, transposed, in, w, bias, out, st, addend, ld_add, reflect)) return 1;
     if (reflect && (transposed || d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     const int ld_in = transposed ? d->ldy : d->ldx;

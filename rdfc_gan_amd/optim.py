@@ -240,7 +240,6 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         Fh.join_side_stream()
         self.wait_grads()
-        self._started = set()
         g = self.param_groups[0]
         nranks = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         world = nranks * float(self.loss_scale)

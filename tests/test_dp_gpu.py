@@ -24,6 +24,20 @@ def test_two_ranks_stay_identical(full):
         assert "optimizers ['D', 'G', 'Nor', 'label']" in out, out[-3000:]
 
 
+def test_two_ranks_stay_identical_under_graph_replay():
+    """HIP-graph mode under data parallelism: a replay runs no Python, so the buckets' per-step state has to be reset outside
+    zero_grad() (FlatAdam.begin_step) -- otherwise every bucket counts as started from the capture on, no collective is issued
+    and the replicas drift apart on their own shards.  One eager step, then four replayed ones; f16 (device-side loss scale
+    and overflow check inside the captured Adam segment)."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_SMOKE_FULL='0', DP_SMOKE_GRAPH='1', DP_SMOKE_DTYPE='f16')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29523', os.path.join(ROOT, 'tools', 'dp_smoke.py')]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert 'max parameter difference between replicas after 5 steps = 0.000e+00' in out, out[-3000:]
+
+
 def test_rccl_one_rank_step_equals_plain_step():
     """every collective of the step through RCCL itself (one rank on the one GPU, RDFC_DP_FORCE): broadcast, the bucketed
     all-reduces on the communication stream, the packed loss all-reduces; results must match the step without a process group

@@ -441,6 +441,41 @@ def test_fusion_head_losses_adam_pepper():
     assert rel_err(got, ref) == 0
 
 
+def test_dynamic_loss_scale_skips_overflow_and_backs_off():
+    """rdfc_grad_nonfinite / rdfc_adam_step_scaled / rdfc_loss_scale_update (f16 mode's device-side scaler): a clean step equals
+    torch.optim.Adam on the unscaled gradients; a step whose (scaled) gradients hold an inf / NaN changes nothing, is counted and
+    halves the scale; the bias corrections of later steps count the steps really taken; growth after `interval` clean steps."""
+    h = hip()
+    n = 1003                                        # (not a multiple of 4: the check's scalar tail)
+    prm = torch.nn.Parameter(rnd(n, seed=1))
+    opt = torch.optim.AdamW([prm], lr=2e-3, betas=(0.5, 0.999), weight_decay=0.01)
+    pd, md, vd = prm.detach().clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    scaler = torch.tensor([1024.0, 1.0 / 1024.0, 0.0, 0.0], device=DEV)
+    ost = torch.zeros(2, device=DEV)
+    host_step = 0
+    for it, bad in enumerate([None, 'inf', None, 'nan', None]):
+        g = rnd(n, seed=10 + it)
+        gs = (g * float(scaler[0])).to(DEV)          # what a backward started from the cotangent `scale` leaves in .grad
+        if bad is not None:
+            gs[n - 1 if bad == 'inf' else 17] = float(bad)
+        before = (pd.clone(), md.clone(), vd.clone())
+        host_step += 1
+        h.grad_nonfinite(gs, ost)
+        h.adam_step_scaled(pd, gs, md, vd, 2e-3, 0.5, 0.999, 1e-8, host_step, scaler, ost, grad_scale=1.0, weight_decay=0.01)
+        h.loss_scale_update(scaler, 2.0, 0.5, 2, 1.0, 2.0 ** 24)
+        if bad is None:
+            prm.grad = g.clone()
+            opt.step()
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(before, (pd, md, vd))), 'an overflowing step must not touch the state'
+        assert rel_err(pd, prm.detach()) < 2e-6, (it, bad)
+    # skipped twice; scale: 1024 -> (clean, 1 of 2) -> 512 (inf) -> (clean) -> 256 (nan) -> (clean, 1 of 2) = 256
+    assert float(ost[1]) == 2.0 and float(scaler[0]) == 256.0 and abs(float(scaler[1]) - 1.0 / 256.0) < 1e-9
+    h.grad_nonfinite(torch.zeros(8, device=DEV), ost)
+    h.loss_scale_update(scaler, 2.0, 0.5, 2, 1.0, 2.0 ** 24)             # second clean step in a row: grows
+    assert float(scaler[0]) == 512.0 and float(scaler[2]) == 0.0 and float(ost[0]) == 0.0
+
+
 MD_CASES = [dict(B=2, C=1, H=9, W=11, Co=1, k=3, s=1, p=1, g=1, dg=1),
             dict(B=2, C=1, H=21, W=150, Co=1, k=3, s=1, p=1, g=1, dg=1),      # several 8x64 tiles of the LDS-window backward
             dict(B=1, C=1, H=19, W=70, Co=1, k=1, s=1, p=0, g=1, dg=1),

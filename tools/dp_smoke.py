@@ -25,7 +25,9 @@ if backend == 'nccl':
     dist.init_process_group('nccl', device_id=dev)
 else:
     dist.init_process_group('gloo')
-Fh.set_compute_dtype(torch.bfloat16)
+Fh.set_compute_dtype(dict(bf16=torch.bfloat16, f16=torch.float16)[os.environ.get('DP_SMOKE_DTYPE', 'bf16')])
+graph = os.environ.get('DP_SMOKE_GRAPH') == '1'       # the step captured into HIP graphs after one eager step, then replayed
+nsteps = 5 if graph else 2
 torch.manual_seed(100 + rank)           # different initial weights per rank: the broadcast must equalise them
 random.seed(rank); np.random.seed(rank)
 full = os.environ.get('DP_SMOKE_FULL') == '1'          # all six networks: label net + G_normal (stand-in encoder), three more reducers
@@ -43,12 +45,17 @@ def two_steps(distributed):
     m = RDFCGAN(dev, distributed, bench.model_cfg(False), is_train=True, **kw)
     m.train()
     trace = []
-    for it in range(2):
+    for it in range(nsteps):
+        if graph and it == 1:
+            m.enable_graph(True)
         m.set_input(bench.synth_batch(2, 64, 80, 50 + 10 * rank + it, dev))
         losses = m.optimize_parameters()
         assert all(np.isfinite(v) for v in losses.values()), losses
         trace.append(losses)
     torch.cuda.synchronize()
+    if graph:
+        assert m._graph_mode and m._graphs is not None, 'capture fell back to eager launches'
+        m.enable_graph(False)
     return m, trace
 
 
@@ -79,6 +86,6 @@ other = [torch.empty_like(mine) for _ in range(world)]
 dist.all_gather(other, mine)
 diff = max((o - other[0]).abs().max().item() for o in other)
 if rank == 0:
-    print(f'dp_smoke: optimizers {sorted(m.optimizers)}; world {world}, max parameter difference between replicas after 2 steps = {diff:.3e}; losses {losses}')
+    print(f'dp_smoke: optimizers {sorted(m.optimizers)}; world {world}, max parameter difference between replicas after {nsteps} steps = {diff:.3e}; losses {losses}')
 assert diff == 0.0, diff
 dist.destroy_process_group()
