@@ -209,26 +209,6 @@ int rdfc_norm_backward(const void *dz, const void *x, const float *mean, const f
                        int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope, const float *prelu,
                        int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream);
 
-/* One-stage variants of the four calls above: workgroups add their sums to pre-zeroed f64 accumulators with hardware
- * atomics (sums64[G][2][C] = {sum x, sum x^2}, resp. [G][3][C]) and the consumer derives what it needs from them, so the
- * two finalize launches per layer and the partial buffers disappear.  rdfc_norm_apply_sums also writes mean / rstd
- * (for the backward) and updates the running statistics; rdfc_norm_bwd_apply_sums also writes the f32 sums[G][3][C]
- * and adds sum du / sum du*xhat to dbeta_acc / dgamma_acc (G == 1).  The addition order is not fixed: results agree
- * with the two-stage path to f64 rounding, not bitwise. */
-int rdfc_norm_stats_acc(const void *x, double *sums64, int G, int P, int C, int ld, int dtype, void *stream);
-int rdfc_norm_apply_sums(const void *x, const double *sums64, const float *gamma, const float *beta, const void *res,
-                         void *z, float *mean_out, float *rstd_out, int G, int P, int C, int ldx, int ldr, int ldz,
-                         int dtype, float eps, int act, float slope, const float *prelu, float *run_mean,
-                         float *run_var, float momentum, void *stream);
-int rdfc_norm_bwd_reduce_acc(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
-                             const float *beta, const void *res, double *sums64, int G, int P, int C, int lddz,
-                             int ldx, int ldr, int dtype, int act, float slope, const float *prelu, void *stream);
-int rdfc_norm_bwd_apply_sums(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
-                             const float *beta, const void *res, const double *sums64, void *dx, void *dres,
-                             float *sums_out, float *dbeta_acc, float *dgamma_acc, int G, int P, int C, int lddz,
-                             int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
-                             const float *prelu, int frozen_stats, void *stream);
-
 /* W-AdaIN (model_utils.py:72-90): out = gb[:, 0:C] * IN(x) + gb[:, C:2C], gb = per-pixel style affine. */
 int rdfc_adain_apply(const void *x, const float *mean, const float *rstd, const void *gb, void *out,
                      int N, int P, int C, int ldx, int ldgb, int ldo, int dtype, void *stream);

@@ -9,8 +9,8 @@
 //     the XOR bank swizzle of the LDS image is applied on the SOURCE side (LDS-DMA destinations are lane-linear);
 //     out-of-image and out-of-range pieces read a 64-byte zero page, so every wave issues the same number of
 //     DMAs and the vmcnt arithmetic below stays static;
-//   * the weights run through a ring of 4 tap slots filled three taps ahead, the patch is double buffered and
-//     its DMAs are spread over the first taps of the previous slab; loads stay in flight across the (raw)
+//   * the weights run through a ring of 3 (128-co tiles) or 2 (64-co tiles) tap slots filled two / one taps ahead, the patch is
+//     double buffered and its DMAs are spread over the first taps of the previous slab; loads stay in flight across the (raw)
 //     barrier: each phase waits with a counted s_waitcnt vmcnt(N) for exactly the DMAs it is about to read;
 //   * a wave owns 64 co x 64 px (16 MFMAs per phase against 8 fragment reads, half the LDS traffic per MFMA
 //     of the 64x32 wave tile).
@@ -39,25 +39,11 @@ struct GParams {
 };
 
 constexpr int BK = 32, TC = 16, PW = TC + 2;
-// weight ring: WRING tap slots filled WRING-1 phases ahead.  RDFC_GLDS_DEEP: one more slot, and the fragments of phase p+1 are
-// read from LDS while phase p's MFMAs run (their data is complete one barrier earlier), so no MFMA waits on an LDS read
-#ifdef RDFC_GLDS_DEEP
-constexpr int WRING = 5;
-#else
-constexpr int WRING = 4;
-#endif
-// 128-co tiles: a ring of 3 (weights fetched two phases ahead) makes the workgroup 48 KB of LDS -> THREE per CU (the kernel needs
-// 168 registers): 256->256 @ 57x76 58.4 -> 52.7 us (its 640 workgroups now fit one round), 128->128 @ 114x152 60.2 -> 53.1,
+// weight ring: a ring of 3 tap slots (weights fetched two phases ahead) makes the 128-co workgroup 48 KB of LDS -> THREE per CU (the
+// kernel needs 168 registers): 256->256 @ 57x76 58.4 -> 52.7 us (its 640 workgroups now fit one round), 128->128 @ 114x152 60.2 -> 53.1,
 // 256->128 @ 114x152 98.2 -> 94.0.  The 64-co tiles (2 x 21 KB of patch) need a ring of TWO (weights fetched one phase ahead) to get
 // three workgroups on a CU (50 KB each): 64->64 @ 16x228x304 160 -> 134 us forward, 163 -> 136 input gradient, 128->64 244 -> 218.
-// RDFC_GLDS_RING overrides.
-#if defined(RDFC_GLDS_RING)
-template <int TCO> constexpr int ring_of() { return RDFC_GLDS_RING; }
-#elif defined(RDFC_GLDS_DEEP)
-template <int TCO> constexpr int ring_of() { return WRING; }
-#else
 template <int TCO> constexpr int ring_of() { return TCO == 128 ? 3 : 2; }
-#endif
 
 __device__ inline int lay_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 2)) << 3); }
 
@@ -85,53 +71,42 @@ __device__ unsigned long long g_stamps[8][9][6];
 #define RDFC_STAMP(TAP, K)
 #endif
 
-// SPEC: NW consumer waves (fragment reads + MFMA + epilogue) plus NW producer waves that do nothing but issue the LDS-DMAs and
-// wait for them, and the consumers read phase p+1's fragments while phase p's MFMAs run (two register sets, no copies).
-// In-kernel stamps of the unspecialised kernel (tools/glds_stamps.sh, 256->256 @ 57x76, cycles per phase of a wave that
-// has its SIMD to itself): vmcnt wait 20, barrier 45, DMA issue 130 (2-3 pieces at ~55), fragment reads until the data
-// is back 125, 16 MFMAs 280 -- 600 in all, the matrix pipe busy 43 %.  Here a consumer's phase is barrier + MFMAs.
-// JR: pixel rows (of 16) per wave: 4 -> a wave owns 64 co x 64 px; 8 -> 64 co x 128 px (32 MFMAs per phase and barrier against 12
-// fragment reads, and the tap's weights serve twice the pixels: 45 % fewer DMA'd bytes and L2 requests per MFMA; 128 accumulators)
-template <int TCO, int NW, int NPROD = 0, int JR = 4, int DT = RDFC_BF16>     // DT: RDFC_BF16 | RDFC_F16 (2-byte elements moved as opaque bits)
-__global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds_kernel(GParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
-                                                                  const float *__restrict__ bias, void *__restrict__ yout,
-                                                                  const bf16_t *__restrict__ zero, float *__restrict__ stats) {
-    constexpr bool SPEC = NPROD > 0;
-    constexpr int NT = NW * 64;                                // threads the tile and the DMA piece numbering are laid out for
-    constexpr int VPW = SPEC ? NW / NPROD : 1;                 // DMA shares ("virtual waves") per issuing wave
-    static_assert(!SPEC || NW % NPROD == 0, "producer waves must split the DMA shares evenly");
-    constexpr int WCO = TCO / 64, WPX = NW / WCO;              // waves along co / along pixel rows (64 co x 4 rows x 16 px each)
-    static_assert(JR == 4 || NPROD == 0, "the specialised variants keep two fragment sets: 4-row wave tiles only");
+// Variants measured and removed in round 3 (numbers in DESIGN.md section 7 and profiles/r01_conv_glds_stamps.txt): producer / consumer
+// specialisation (4 consumer + 4 | 2 producer waves, fragment reads pipelined one phase ahead), 64 co x 128 px wave tiles, 8-wave
+// 128 co x 256 px and 2-wave workgroups, a fifth ring slot with fragment reads one phase ahead, and an 8-wave ping-pong schedule with
+// two barriers per tap (profiles/r03_pingpong_experiment.txt): none beat this one on the step's layer sizes.
+template <int TCO, int DT = RDFC_BF16>     // DT: RDFC_BF16 | RDFC_F16 (2-byte elements moved as opaque bits)
+__global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
+                                                              const float *__restrict__ bias, void *__restrict__ yout,
+                                                              const bf16_t *__restrict__ zero, float *__restrict__ stats) {
+    constexpr int NW = 4, JR = 4;                              // waves per workgroup; pixel rows (of 16) per wave: a wave owns 64 co x 64 px
+    constexpr int NT = NW * 64;
+    constexpr int WCO = TCO / 64, WPX = NW / WCO;              // waves along co / along pixel rows
     constexpr int TR = JR * WPX, PH = TR + 2, NPATCH = PH * PW; // tile rows, patch rows, patch pixels (180 / 324)
     constexpr int NPIECE = NPATCH * 4;                         // 16-byte pieces per slab
     constexpr int PATCH_BYTES = (NPIECE + 63) / 64 * 1024;     // whole DMA instructions (1 KB each): 12 KB / 21 KB
     constexpr int NR = (NPIECE + NT - 1) / NT;                 // patch DMA rounds per slab (3 / 6)
     constexpr int NWP = TCO * 4 / NT;                          // weight DMAs per thread and tap (2 / 1)
     constexpr int WSLOT = TCO * BK * 2;                        // bytes per weight slot
-    constexpr int RING = SPEC ? 5 : (JR == 4 && NW == 4 ? ring_of<TCO>() : WRING);   // SPEC reads a phase's fragments one phase early: one more slot
-    constexpr int WLOOK = RING - 1;                            // unspecialised kernel: phases between a weight block's DMA and its use
+    constexpr int RING = ring_of<TCO>();
+    constexpr int WLOOK = RING - 1;                            // phases between a weight block's DMA and its use
     constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + RING * WSLOT;
     static_assert(NR <= 6, "patch rounds must be issued at least three phases before the slab ends");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
-    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool producer = SPEC && wave_all >= NW;
-    // consumers: `wave` places the wave in the output tile; a DMA-issuing wave (every wave, or producer pw) carries the shares
-    // dwave(v) = pw + v * NPROD of the NW-share piece numbering
-    const int wave = producer ? wave_all - NW : wave_all;
-    const int tid = (int)threadIdx.x;                            // (statistics epilogue, unspecialised kernel only)
-    auto dwave = [&](int v) { return SPEC ? wave + v * NPROD : wave; };
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = (int)threadIdx.x;
+    constexpr int VPW = 1;                                       // DMA shares per issuing wave (every wave issues its own)
+    auto dwave = [&](int) { return wave; };
     const int co0 = blockIdx.y * TCO;
     // Workgroups are dealt to the 8 XCDs round-robin; renumber so that each XCD (own L2) gets a contiguous run of
     // tiles: neighbouring tiles share halo rows and then hit in the same L2.
     int t = blockIdx.x;
-#ifndef RDFC_GLDS_NO_XCD
     {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = t & 7, k = t >> 3;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-#endif
     const int t_all = t;                                        // tile index after the renumbering (unique)
     const int tx = t % p.tiles_x;
     t /= p.tiles_x;
@@ -180,11 +155,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
     }
     auto issue_w = [&](int it) {                                 // weights of global phase `it` -> ring slot it % RING
         const int cc = it / 9, tap = it - cc * 9;
-#ifdef RDFC_GLDS_EXP_WHIT   /* timing experiment only (wrong results): every phase re-reads the first weight block -> L1 hits */
-        const int off = 0 * tap;
-#else
         const int off = cc < ncc ? tap * p.Cin + cc * BK : 0;
-#endif
 #pragma unroll
         for (int v = 0; v < VPW; ++v)
 #pragma unroll
@@ -218,26 +189,15 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
     const unsigned a_off = (unsigned)((arow << 6) | (kg << 4)) ^ (unsigned)((arow & 4) << 3);     // + i*1024: rows arow + 16 i share bit 2
     auto read_frags = [&](int it, int cc, int tap, bf16x8 (&a)[4], bf16x8 (&b)[JR]) {
         const int kh = tap / 3, kw = tap - kh * 3;
-        int shift = p.transposed ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
-#ifdef RDFC_GLDS_RECOMPUTE
-        asm volatile("" : "+s"(shift));                          // keep the nine taps' B addresses out of registers (recomputed per phase)
-#else
-        if (JR > 4) asm volatile("" : "+s"(shift));              // 128 accumulators + 48 fragment registers: no room for 72 hoisted addresses
-#endif
+        const int shift = p.transposed ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
         const unsigned char *Wt = smem + OFF_W + (it % RING) * WSLOT + a_off;
         const unsigned char *Pt = smem + (cc & 1) * PATCH_BYTES;
-        if (!SPEC) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
-        }
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
 #pragma unroll
         for (int j = 0; j < JR; ++j) {
             const int row = bpp[j] + shift;
             b[j] = *reinterpret_cast<const bf16x8 *>(Pt + (((row << 6) | (kg << 4)) ^ ((row & 4) << 3)));
-        }
-        if (SPEC) {          // pipelined reads, in the order the next phase's MFMAs need them: a[0] and every b first, a[3] last
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
         }
     };
     auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[JR]) {
@@ -246,101 +206,19 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
 #pragma unroll
             for (int j = 0; j < JR; ++j) acc[i][j] = mma16<DT>(a[i], b[j], acc[i][j]);
     };
-    auto compute = [&](int it, int cc, int tap) {
-        bf16x8 a[4], b[JR];
-        read_frags(it, cc, tap, a, b);
-        mma(a, b);
-    };
 #ifdef RDFC_GLDS_STAMPS
     unsigned long long sbuf[9][6];
     const bool stamp_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;
+    const int wave_all = wave;
 #endif
 
-    if constexpr (SPEC) {
-        // Phase q = (slab, tap).  Barrier B(q): "the data of phase q is in LDS" (the producers waited for it) and "every consumer
-        // has issued the MFMAs of phase q-2" (so its fragment reads are complete: their slot and, at a slab boundary, their
-        // patch buffer may be overwritten).  Producers after B(q): weights of phase q+3 into slot (q+3) % 5 (held phase q-2),
-        // patch rounds of the next slab on taps 1..NR (its buffer held slab cc-1, last read in phase 9cc-1).
-        if (producer) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) issue_p(r, 0);
-#pragma unroll
-            for (int h = 0; h < 3; ++h) issue_w(h);
-#define RDFC_GLDS_PRODUCE(TAP)                                                                                 \
-    {                                                                                                          \
-        constexpr int ALLOW = VPW * (2 * NWP + (((TAP + 6) % 9) < NR ? 1 : 0) + (((TAP + 7) % 9) < NR ? 1 : 0)); \
-        wait_vm<ALLOW>();                                                                                      \
-        __builtin_amdgcn_s_barrier();                                                                          \
-        issue_w(it0 + TAP + 3);                                                                                \
-        if (TAP >= 1 && TAP <= NR) issue_p(TAP >= 1 && TAP <= NR ? TAP - 1 : 0, cc + 1);                       \
-    }
-            for (int cc = 0; cc < ncc; ++cc) {
-                const int it0 = cc * 9;
-                RDFC_GLDS_PRODUCE(0) RDFC_GLDS_PRODUCE(1) RDFC_GLDS_PRODUCE(2) RDFC_GLDS_PRODUCE(3) RDFC_GLDS_PRODUCE(4)
-                RDFC_GLDS_PRODUCE(5) RDFC_GLDS_PRODUCE(6) RDFC_GLDS_PRODUCE(7) RDFC_GLDS_PRODUCE(8)
-            }
-#undef RDFC_GLDS_PRODUCE
-            wait_vm<0>();                                        // (the trailing zero-page pieces land in LDS this workgroup owns)
-            __builtin_amdgcn_s_barrier();                        // B(P): the consumers' last step reads one phase past the end
-            return;                                              // an ended wave no longer counts at s_barrier
-        }
-        bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
-        __builtin_amdgcn_s_barrier();                            // B(0)
-        read_frags(0, 0, 0, fa0, fb0);
-        // one step: B(q+1), start reading phase q+1 into the other register set, run phase q's MFMAs on this one
-#define RDFC_GLDS_CONSUME(CC, TAP, CA, CB, NA_, NB_)                                                           \
-    {                                                                                                          \
-        const int q_ = (CC) * 9 + TAP;                                                                         \
-        RDFC_STAMP(TAP, 0)                                                                                     \
-        __builtin_amdgcn_s_barrier();                                                                          \
-        RDFC_STAMP(TAP, 2)                                                                                     \
-        read_frags(q_ + 1, TAP == 8 ? (CC) + 1 : (CC), (TAP + 1) % 9, NA_, NB_);                               \
-        mma(CA, CB);                                                                                           \
-        /* schedule: one fragment read, two MFMAs, ... -- the reads ride in the MFMAs' issue slack and land a phase early; left \
-           alone the compiler sinks every read to just before its use and the MFMA waits out the LDS latency */ \
-        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                     \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                 \
-        }                                                                                                      \
-        RDFC_STAMP(TAP, 5)                                                                                     \
-    }
-        for (int cc = 0; cc < ncc; cc += 2) {                    // two slabs per trip: 18 phases, the register sets alternate
-            RDFC_GLDS_CONSUME(cc, 0, fa0, fb0, fa1, fb1) RDFC_GLDS_CONSUME(cc, 1, fa1, fb1, fa0, fb0)
-            RDFC_GLDS_CONSUME(cc, 2, fa0, fb0, fa1, fb1) RDFC_GLDS_CONSUME(cc, 3, fa1, fb1, fa0, fb0)
-            RDFC_GLDS_CONSUME(cc, 4, fa0, fb0, fa1, fb1) RDFC_GLDS_CONSUME(cc, 5, fa1, fb1, fa0, fb0)
-            RDFC_GLDS_CONSUME(cc, 6, fa0, fb0, fa1, fb1) RDFC_GLDS_CONSUME(cc, 7, fa1, fb1, fa0, fb0)
-            RDFC_GLDS_CONSUME(cc, 8, fa0, fb0, fa1, fb1)
-            RDFC_GLDS_CONSUME(cc + 1, 0, fa1, fb1, fa0, fb0) RDFC_GLDS_CONSUME(cc + 1, 1, fa0, fb0, fa1, fb1)
-            RDFC_GLDS_CONSUME(cc + 1, 2, fa1, fb1, fa0, fb0) RDFC_GLDS_CONSUME(cc + 1, 3, fa0, fb0, fa1, fb1)
-            RDFC_GLDS_CONSUME(cc + 1, 4, fa1, fb1, fa0, fb0) RDFC_GLDS_CONSUME(cc + 1, 5, fa0, fb0, fa1, fb1)
-            RDFC_GLDS_CONSUME(cc + 1, 6, fa1, fb1, fa0, fb0) RDFC_GLDS_CONSUME(cc + 1, 7, fa0, fb0, fa1, fb1)
-            RDFC_GLDS_CONSUME(cc + 1, 8, fa1, fb1, fa0, fb0)
-        }
-#undef RDFC_GLDS_CONSUME
-    } else {
-    // ---- prologue: slab 0 patch, weights of the first WRING-1 phases -------------------------------------------------------
+    // ---- prologue: slab 0 patch, weights of the first RING-1 phases --------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < NR; ++r) issue_p(r, 0);
 #pragma unroll
     for (int h = 0; h < WLOOK; ++h) issue_w(h);
 
     // phase (cc, TAP): DMAs still allowed in flight at its wait = those issued in the two previous phases
-#if defined(RDFC_GLDS_EXP_NODMA)      /* timing experiment only (wrong results): no DMA in the main loop */
-#define RDFC_GLDS_PHASE(TAP)                                                                                   \
-    {                                                                                                          \
-        __builtin_amdgcn_s_barrier();                                                                          \
-        compute(it0 + TAP, cc, TAP);                                                                           \
-    }
-#elif defined(RDFC_GLDS_EXP_NOBARRIER)  /* timing experiment only (races): DMA but no barrier */
-#define RDFC_GLDS_PHASE(TAP)                                                                                   \
-    {                                                                                                          \
-        constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
-        wait_vm<ALLOW>();                                                                                      \
-        issue_w(it0 + TAP + WLOOK);                                                                            \
-        if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
-        compute(it0 + TAP, cc, TAP);                                                                           \
-    }
-#elif !defined(RDFC_GLDS_DEEP)
 #define RDFC_GLDS_PHASE(TAP)                                                                                   \
     {                                                                                                          \
         constexpr int ALLOW = (WLOOK - 1) * NWP + (WLOOK >= 3 && ((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0); \
@@ -360,33 +238,6 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
         }                                                                                                      \
         RDFC_STAMP(TAP, 5)                                                                                     \
     }
-#else
-    // deep variant: the wait of phase p retires the DMAs of phase p+1 (issued four phases ahead), the barrier publishes them,
-    // and phase p+1's fragments are read while phase p's MFMAs (operands read one phase ago) execute
-    bf16x8 fa[4], fb[JR];
-    wait_vm<(WRING - 2) * NWP>();                               // patch 0 and weights 0 are in
-    __builtin_amdgcn_s_barrier();
-    read_frags(0, 0, 0, fa, fb);
-#define RDFC_GLDS_PHASE(TAP)                                                                                   \
-    {                                                                                                          \
-        constexpr int ALLOW = 2 * NWP + (((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0);       \
-        RDFC_STAMP(TAP, 0)                                                                                     \
-        wait_vm<ALLOW>();                                                                                      \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
-        RDFC_STAMP(TAP, 1)                                                                                     \
-        __builtin_amdgcn_s_barrier();                                                                          \
-        RDFC_STAMP(TAP, 2)                                                                                     \
-        issue_w(it0 + TAP + 4);                                                                                \
-        if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
-        RDFC_STAMP(TAP, 3)                                                                                     \
-        RDFC_STAMP(TAP, 4)                                                                                     \
-        bf16x8 na[4], nb[JR];                                                                                  \
-        read_frags(it0 + TAP + 1, TAP == 8 ? cc + 1 : cc, (TAP + 1) % 9, na, nb);                              \
-        mma(fa, fb);                                                                                           \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) { fa[q] = na[q]; fb[q] = nb[q]; }                        \
-        RDFC_STAMP(TAP, 5)                                                                                     \
-    }
-#endif
     for (int cc = 0; cc < ncc; ++cc) {
         const int it0 = cc * 9;
         RDFC_GLDS_PHASE(0)
@@ -401,7 +252,6 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
     }
 #undef RDFC_GLDS_PHASE
     wait_vm<0>();
-    }
 #ifdef RDFC_GLDS_STAMPS
     if (stamp_on && lane == 0 && ncc > 2)
         for (int t_ = 0; t_ < 9; ++t_)
@@ -426,7 +276,7 @@ __global__ __launch_bounds__((NW + NPROD) * 64, NPROD ? 3 : 2) void conv3x3_glds
     }
     // ---- fused normalisation statistics: per-tile partial {sum, sum of squares} of the STORED values, one row per tile in
     //      stats[g][tile][2][Cout] (the fixed-order f64 finalize of norm.hip reads them; no atomics) --------------------
-    if (!SPEC && stats != nullptr) {
+    if (stats != nullptr) {
         float s1[4][4], s2[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -550,22 +400,19 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO, int NW, int NPROD = 0, int JR = 4, int DT = RDFC_BF16>
+template <int TCO, int DT = RDFC_BF16>
 int launch(const GParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, float *stats, hipStream_t st) {
-    constexpr bool SPEC = NPROD > 0;
-    constexpr int NT = NW * 64, TR = JR * NW / (TCO / 64);
+    constexpr int NT = 256, TR = 4 * 4 / (TCO / 64);
     constexpr int NPIECE = (TR + 2) * PW * 4, PATCH = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;
-    constexpr int SMEM = 2 * PATCH + (SPEC ? 5 : (JR == 4 && NW == 4 ? ring_of<TCO>() : WRING)) * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
+    constexpr int SMEM = 2 * PATCH + ring_of<TCO>() * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, NW, NPROD, JR, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM + 65536) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
-    rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d, %d, %d>", TCO, NW, NPROD, JR, DT);         // the symbol as rocprofv3 prints it
-    // experiment knob: extra (unused) dynamic LDS, e.g. 40960 leaves room for ONE workgroup per CU
-    static const int pad_lds = getenv("RDFC_GLDS_PAD_LDS") ? atoi(getenv("RDFC_GLDS_PAD_LDS")) : 0;
-    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, NW, NPROD, JR, DT>), grid, dim3((NW + NPROD) * 64), SMEM + pad_lds, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
+    rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, DT);         // the symbol as rocprofv3 prints it
+    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, DT>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
     return 1;
 }
 
@@ -593,15 +440,9 @@ int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G) {
 // stats != nullptr (forward only): also write the per-tile normalisation statistics, G groups.
 int rdfc_conv3x3_glds_covers(const rdfc_conv_desc *d) { return glds_shape_ok(d, 0) ? 1 : 0; }
 
-int rdfc_try_conv3x3_pp(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
-                        hipStream_t st, const void *addend, int ld_add, int reflect);          // conv_pp.hip
-
 int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st, float *stats = nullptr, int G = 0, const void *addend = nullptr, int ld_add = 0, int reflect = 0) {
-    static const int mode = getenv("RDFC_GLDS") ? atoi(getenv("RDFC_GLDS")) : 1;
     if (!glds_shape_ok(d, transposed)) return 0;
-    // the ping-pong kernel (8 waves, one workgroup per CU) takes the shapes it covers unless the fused statistics are wanted
-    if (stats == nullptr && rdfc_try_conv3x3_pp(d, transposed, in, w, bias, out, st, addend, ld_add, reflect)) return 1;
     if (reflect && (transposed || d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     const int ld_in = transposed ? d->ldy : d->ldx;
@@ -612,42 +453,10 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
               Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
               d->act, d->slope, d->out_f32, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect};
     p.tiles_x = cdiv(p.W, TC);
-    if (d->dtype == RDFC_F16) {                      // f16: the default variants only (the A/B variants below are bf16 experiments)
-        p.tiles_y = cdiv(p.H, Cout > 64 ? 8 : 16);
-        return Cout > 64 ? launch<128, 4, 0, 4, RDFC_F16>(p, in, w, bias, out, zero, stats, st)
-                         : launch<64, 4, 0, 4, RDFC_F16>(p, in, w, bias, out, zero, stats, st);
-    }
-    if (Cout > 64) {
-        // 8 waves on 128 co x (16x16) px, one workgroup per CU: 43 % fewer DMA instructions per MFMA (the weights of a tap
-        // serve twice the pixels).  Faster when its grid is one partial round or many rounds (512 ch @ 29x38, 192
-        // workgroups: 692 vs 634 TFLOP/s; 64->128 @ 228x304, 2280: 602 vs 559), slower when it ends in a short second round
-        // (256 ch @ 57x76, 320 workgroups on 256 CUs: 633 vs 688).  Choosing it by grid size gained nothing inside the
-        // multi-stream step (178 vs 181 pairs/s: a one-workgroup-per-CU kernel shares the chip worse), so it stays an A/B
-        // switch: RDFC_GLDS=3.
-        if (stats == nullptr && mode == 3) {
-            p.tiles_y = cdiv(p.H, 16);
-            return launch<128, 8>(p, in, w, bias, out, zero, stats, st);
-        }
-        p.tiles_y = cdiv(p.H, 8);
-        // A/B switches RDFC_GLDS=4 / 5: specialised variants, 4 consumer + 4 (one workgroup per CU) or + 2 (two per CU) producer
-        // waves.  A workgroup alone on its CU runs 16 % faster (256->256 @ 57x76, 160 workgroups: 21.2 vs 25.3 us) but a CU's
-        // throughput does not move: 62.9 / 63.6 vs 58.2 us on 640 workgroups -- see DESIGN.md section 7 for the stamp and counter data.
-        if (stats == nullptr && mode == 6) {                    // 4 waves x (64 co x 128 px): 128 co x (16x16) px per workgroup
-            p.tiles_y = cdiv(p.H, 16);
-            return launch<128, 4, 0, 8>(p, in, w, bias, out, zero, stats, st);
-        }
-        if (stats == nullptr && mode == 4 && (Cin / BK) % 2 == 0) return launch<128, 4, 4>(p, in, w, bias, out, zero, stats, st);
-        if (stats == nullptr && mode == 5 && (Cin / BK) % 2 == 0) return launch<128, 4, 2>(p, in, w, bias, out, zero, stats, st);
-        return launch<128, 4>(p, in, w, bias, out, zero, stats, st);
-    }
-    if (mode == 2 && stats == nullptr) {               // A/B switch: 2-wave workgroups (4 per CU) measured 1-4 % slower
-        p.tiles_y = cdiv(p.H, 8);
-        return launch<64, 2>(p, in, w, bias, out, zero, stats, st);
-    }
-    p.tiles_y = cdiv(p.H, 16);
-    if (stats == nullptr && mode == 4 && (Cin / BK) % 2 == 0) return launch<64, 4, 4>(p, in, w, bias, out, zero, stats, st);
-    if (stats == nullptr && mode == 5 && (Cin / BK) % 2 == 0) return launch<64, 4, 2>(p, in, w, bias, out, zero, stats, st);
-    return launch<64, 4>(p, in, w, bias, out, zero, stats, st);
+    p.tiles_y = cdiv(p.H, Cout > 64 ? 8 : 16);                 // 128 co x (8 x 16) px or 64 co x (16 x 16) px per workgroup
+    if (d->dtype == RDFC_F16)
+        return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, stats, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, stats, st);
+    return Cout > 64 ? launch<128>(p, in, w, bias, out, zero, stats, st) : launch<64>(p, in, w, bias, out, zero, stats, st);
 }
 
 #ifdef RDFC_GLDS_STAMPS

@@ -1,4 +1,8 @@
 // conv_wgrad_glds.hip -- weight gradient of 3x3 / stride-1 convolutions (bf16), staged by LDS-DMA.
+// Since round 3 the default dispatch runs conv_wgrad_ring.hip (flat pixel walk, slab reduction: deterministic, 15-20 % faster on the
+// 76-wide maps, within -6 % elsewhere: profiles/r03_wgrad_ring_ab.txt); this kernel is what RDFC_WGRAD_RING=0 selects for A/B runs and
+// what maps narrower than 24 pixels fall back to.  Removed in round 3, measured slower in round 2: the 128 co x 128 ci eight-wave tile,
+// the nine-taps-per-workgroup tile, the per-lane flat walk.
 //
 //   dW[co][ky][kx][ci] += sum over pixels m of dY[m][co] * X[m + (ky, kx) - pad][ci]
 //
@@ -25,8 +29,6 @@ struct WGParams {
     int tiles, xcd_group;
     int tiles_ci;
     int reflect;                 // X pixels outside the image are their mirror images (reflection padding folded into the loader)
-    int flat;                    // k-steps walk a flat pixel index over rows padded to Wo + 2 instead of 32-pixel segments of one row:
-                                 // a 76-wide row fills 2.44 k-steps instead of 3, a 38-wide one 1.25 instead of 2 (NKY = 1 only)
 };
 
 constexpr int SEG = 32, XPX = SEG + 2;
@@ -54,8 +56,10 @@ template <int ROWB> __device__ inline bf16x8 tr_frag(const unsigned char *img, i
     const unsigned char *a1 = img + r1 * ROWB + ((cp ^ pair_swz<ROWB>(r1)) << 5) + pp * 8;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a1);
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    // (assembled from 32-bit halves: an element-wise s16x8 initialiser costs four v_mov per read -- 96 per k-step, as much
+    //  vector-issue time as the k-step's 24 MFMAs)
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    const u32x4 r = {l2[0], l2[1], h2[0], h2[1]};
     return __builtin_bit_cast(bf16x8, r);
 }
 
@@ -129,55 +133,8 @@ __global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParam
     int cn = seg0 / (p.Ho * p.segs_per_row);
     int rem = seg0 - cn * p.Ho * p.segs_per_row;
     int coy = rem / p.segs_per_row, csx = rem - coy * p.segs_per_row;
-    // flat mode: the k-step starts at flat position (image fn, output row fy, column fj of the row padded to L = Wo + 2 columns)
-    const int L = p.Wo + 2;
-    int fn = 0, fy = 0, fj = 0;
-    if (p.flat) {
-        const int f0 = seg0 * SEG;
-        fn = f0 / (p.Ho * L);
-        const int r0 = f0 - fn * p.Ho * L;
-        fy = r0 / L;
-        fj = r0 - fy * L;
-    }
     auto issue = [&](int s) {                                   // DMAs of k-step s (s >= nseg: zero page only) into ring slot s % WG_RING
         const bool live = s < nseg;
-        if (p.flat) {
-            // every piece derives its own (image, row, column) from the uniform cursor: one wrap at most (L >= 34).
-            // (Tried: the two candidate rows' base pointers and validity as uniform values and a per-piece select -- 6-12 % SLOWER.)
-            const unsigned slot = lds0 + (s % WG_RING) * SLOT;
-#pragma unroll
-            for (int k = 0; k < NY; ++k) {
-                int j = fj + ypx[k];
-                const int wrap = j >= L;
-                j -= wrap ? L : 0;
-                const int row = fn * p.Ho + fy + wrap;                          // dY rows are contiguous across images
-                const bool ok = live && j < p.Wo && row < p.N * p.Ho;
-                glds16(ok ? dy + ((size_t)row * p.Wo + j) * p.ldy + ych[k] : zero, slot + (k * NT + wave * 64) * 16);
-            }
-#pragma unroll
-            for (int k = 0; k < NX; ++k) {
-                int j = fj + (xpx[k] & 255);
-                const int wrap = j >= L;
-                j -= wrap ? L : 0;
-                int y = fy + wrap, img = fn;
-                if (y >= p.Ho) { y -= p.Ho; ++img; }
-                int yy = y + ky - p.pad, xx = j - p.pad;
-                if (p.reflect) {
-                    yy = yy < 0 ? -yy : (yy >= p.Hi ? 2 * p.Hi - 2 - yy : yy);
-                    xx = xx < 0 ? -xx : (xx >= p.Wi ? 2 * p.Wi - 2 - xx : xx);
-                }
-                const bool ok = live && xpx[k] >= 0 && img < p.N && (unsigned)yy < (unsigned)p.Hi && (unsigned)xx < (unsigned)p.Wi;
-                glds16(ok ? x + ((long)(img * p.Hi + yy) * p.Wi + xx) * p.ldx + xch[k] : zero, slot + YB + (k * NT + wave * 64) * 16);
-            }
-            if (live) {
-                fj += SEG;
-                while (fj >= L) {
-                    fj -= L;
-                    if (++fy == p.Ho) { fy = 0; ++fn; }
-                }
-            }
-            return;
-        }
         const int ox0 = csx * SEG, iy = coy - p.pad + ky, ix0 = ox0 - p.pad;
         const bf16_t *yb = dy + ((size_t)(cn * p.Ho + coy) * p.Wo + ox0) * p.ldy;
         const bf16_t *xb = x + ((long)(cn * p.Hi + iy) * p.Wi + ix0) * p.ldx;
@@ -294,7 +251,7 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     // workgroups the chip holds at once: the 64-co kernel (48 KB of LDS, 104 registers) fits three per CU, the 128-co one two.
     // Sizing the 64-co launches for 768 instead of 512: 64->64 @ 228x304 87 -> 80 us, 256->128 @ 114x152 154 -> 132, 128->64 @ 228x304 158 -> 141
     static const int slots_env = getenv("RDFC_WGRAD_SLOTS") ? atoi(getenv("RDFC_WGRAD_SLOTS")) : 0;
-    const int slots = slots_env ? slots_env : (TCI == 128 ? 256 : (TCO == 64 && NKY == 1 ? 768 : 512));     // 128 x 128: one 8-wave workgroup per CU
+    const int slots = slots_env ? slots_env : (TCO == 64 && NKY == 1 ? 768 : 512);
     int slices = slots / tiles;
     const int atomic_cap = (int)(cap_mb * 1.0e6 / (4.0 * p.Co * p.Ci * 9));
     if (slices > atomic_cap) slices = atomic_cap;
@@ -320,37 +277,19 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
 static bool wgrad_glds_shape_ok(const rdfc_conv_desc *d);
 int rdfc_wgrad_glds_covers(const rdfc_conv_desc *d) { return wgrad_glds_shape_ok(d) ? 1 : 0; }
 
+int rdfc_try_wgrad_ring(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st, int reflect);   // conv_wgrad_ring.hip
+
 int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st, int reflect = 0) {
     static const int mode = getenv("RDFC_WGRAD_GLDS") ? atoi(getenv("RDFC_WGRAD_GLDS")) : 1;
+    if (mode == 1 && rdfc_try_wgrad_ring(d, x, dy, dw, st, reflect)) return 1;       // flat walk + slab reduction (deterministic)
     if (!wgrad_glds_shape_ok(d)) return 0;
     if (reflect && (d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return 0;
     const int spr = cdiv(d->Wo, SEG);
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
-    WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0, 0, 0, reflect, 0};
-    // Flat pixel index where the rows leave more than 30 % of their 32-pixel segments empty (29x38: 41 %: 189 -> 154 us).  The
-    // per-piece address arithmetic of the flat walk costs ~9 % of a k-step: at 57x76 (21 % empty) it breaks even (153 -> 149, 149 -> 149 us),
-    // on wide rows (152, 304: 4 % empty) it loses 8-9 %.  RDFC_WGRAD_FLAT=0|1 forces.
-    static const int flat_env = getenv("RDFC_WGRAD_FLAT") ? atoi(getenv("RDFC_WGRAD_FLAT")) : -1;
-    const double ragged = 1.0 - (double)(d->Wo + 2) / (spr * SEG);
-    const bool flat_ok = d->Wo >= 32 && (long)d->N * d->Ho * (d->Wo + 2) < 2000000000L;
-    static const int nine_env = getenv("RDFC_WGRAD_GLDS_NINE") ? atoi(getenv("RDFC_WGRAD_GLDS_NINE")) : 0;
-    if (flat_ok && !nine_env && (flat_env == 1 || (flat_env != 0 && ragged > 0.30))) {
-        p.flat = 1;
-        p.total_segs = cdiv(d->N * d->Ho * (d->Wo + 2), SEG);
-    }
-    // 128 x 128 tiles (8 waves, one workgroup per CU): A/B switch RDFC_WGRAD_GLDS=5 -- measured SLOWER at the batched step's sizes
-    // (N = 16; 128 x 128 against the default): 256->256 @ 57x76 150-154 vs 146-148 us, 128->128 @ 114x152 189 vs 137 us, 512->512 @
-    // 29x38 187 vs 181 us: halving the DMA'd bytes per MFMA does not pay for going from two 4-wave workgroups per CU to one
-    if (mode == 5 && d->Co % 128 == 0 && d->Ci % 128 == 0)
-        return d->dtype == RDFC_F16 ? launch<128, 1, RDFC_F16, 128>(p, x, dy, dw, zero, st) : launch<128, 1, RDFC_BF16, 128>(p, x, dy, dw, zero, st);
+    WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, spr, d->N * d->Ho * spr, 0, 0, 0, 0, reflect};
     // 128-co tiles from 256 output channels up; below that the 64-co tile's larger grid wins (128->128: 82 vs 92 us)
     if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return d->dtype == RDFC_F16 ? launch<128, 1, RDFC_F16>(p, x, dy, dw, zero, st) : launch<128, 1>(p, x, dy, dw, zero, st);
-    // all nine taps per workgroup (dY and X staged once instead of once per kernel row): measured SLOWER on the
-    // full-resolution 64-channel layers (120 vs 97 us: 36 MFMAs against 40 transposing reads per k-step, 244 VGPRs), so
-    // L2 traffic is not what bounds them; kept behind RDFC_WGRAD_GLDS_NINE=1 for A/B runs
-    static const int nine = getenv("RDFC_WGRAD_GLDS_NINE") ? atoi(getenv("RDFC_WGRAD_GLDS_NINE")) : 0;
-    if (nine && d->Co * d->Ci <= 128 * 64) return d->dtype == RDFC_F16 ? launch<64, 3, RDFC_F16>(p, x, dy, dw, zero, st) : launch<64, 3>(p, x, dy, dw, zero, st);
     return d->dtype == RDFC_F16 ? launch<64, 1, RDFC_F16>(p, x, dy, dw, zero, st) : launch<64, 1>(p, x, dy, dw, zero, st);
 }
 

@@ -1,0 +1,394 @@
+// conv_wgrad_ring.hip -- weight gradient of 3x3 / stride-1 convolutions (2-byte elements), LDS-DMA staging, flat pixel walk,
+// deterministic split-K (partial slabs + a fixed-order reduction instead of float atomics).
+//
+//   dW[co][ky][kx][ci] += sum over output pixels m of dY[m][co] * X'[m + (ky, kx)][ci]        X' = X zero-padded by `pad`
+//
+// GEMM view as conv_wgrad_glds.hip: M = co, N = (kx, ci), K = pixels; a workgroup (4 waves) owns one kernel row ky, a 128 | 64 co x
+// 64 ci tile and a slice of K.  What is different:
+//   * K walks a FLAT pixel index over rows padded to L pixels (L = the next multiple of 8 >= Wo + 2): output position f = row * L + x
+//     reads X' at f + ky * L + kx.  No k-step is part of an "empty" row segment -- conv_wgrad_glds.hip's 32-pixel segments of one
+//     row leave 21 % (W = 76) / 41 % (W = 38) of the pixels of its k-steps empty.
+//   * X' is staged ONCE, as a ring of consecutive 32-position blocks contiguous in LDS (block b = positions 32 b .. 32 b + 31 of the
+//     workgroup's range, landed one step ahead of dY's block b): tap kx of step s reads ring rows 32 s + kx .. + 31 -- the 34-row
+//     image per step of the old kernel re-fetched two halo pixels per step and needed a per-lane row / column for every piece.
+//   * L is a multiple of 8 and a DMA instruction covers 4 or 8 consecutive positions, so every instruction's pixels lie in ONE row:
+//     row, column and base pointer of a piece are wave-uniform (SALU, advanced incrementally from step to step); a lane adds its
+//     constant offset and tests its column (5-6 VALU per piece; the per-lane div / mod walk of the old flat mode cost ~18).
+//   * split-K partials go to a scratch slab per slice (plain stores) and a second kernel adds the slices in a fixed order to dW:
+//     bitwise reproducible, and 50 MB of stores + a 50 MB read instead of 50 MB of memory-side float atomics (~1.3 TB/s).
+#include "common.h"
+
+#include <mutex>
+#include <stdlib.h>
+
+namespace {
+
+struct RParams {
+    int N, Hi, Wi, Ci, Ho, Wo, Co, pad;
+    int ldx, ldy;
+    int L, nrows;                // padded row length, N * Ho
+    int total_steps, steps_per_slice, nslices;
+    int tiles, tiles_ci, xcd_group;
+    int reflect;
+};
+
+constexpr int SEG = 32, NT = 256;
+
+__device__ inline void glds16(const void *gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
+template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// swizzle of the 32-byte channel-pair index by image row (conv_wgrad_glds.hip: conflict-free transposing reads for every kx)
+template <int ROWB> __device__ inline int pair_swz(int row) {
+    if constexpr (ROWB == 256) return (row & 3) | (((row >> 3) & 1) << 2);
+    else return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+}
+
+// fragment: 16 channels [cbase, cbase+16) x 32 pixels (image rows (row0 + i) & MASK, i = 0..31) -> 8 consecutive pixels per lane
+template <int ROWB, int MASK> __device__ inline bf16x8 tr_frag(const unsigned char *img, int row0, int cbase, int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int r0 = (row0 + 8 * g + q) & MASK, r1 = (r0 + 4) & MASK, cp = cbase >> 4;
+    const unsigned char *a0 = img + r0 * ROWB + ((cp ^ pair_swz<ROWB>(r0)) << 5) + pp * 8;
+    const unsigned char *a1 = img + r1 * ROWB + ((cp ^ pair_swz<ROWB>(r1)) << 5) + pp * 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a1);
+    // (assembled from 32-bit halves: an element-wise s16x8 initialiser costs four v_mov per read -- 96 per k-step, as much
+    //  vector-issue time as the k-step's 24 MFMAs)
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    const u32x4 r = {l2[0], l2[1], h2[0], h2[1]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int TCO, int DT>
+__global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
+                                                                          float *__restrict__ slab, const bf16_t *__restrict__ zero) {
+    constexpr int TCI = 64, LOOK = 3, RY = LOOK + 1, XR = 8;
+    constexpr int YROW = TCO * 2, XROW = TCI * 2;               // bytes per pixel row of the two images
+    constexpr int YB = SEG * YROW, XBLK = SEG * XROW;           // 8 | 4 KB per dY slot, 4 KB per X block
+    constexpr int NY = YB / (NT * 16), NX = XBLK / (NT * 16);   // DMAs per thread and k-step: dY 2 | 1, X 1
+    constexpr int PER_STEP = NY + NX;
+    constexpr int CPY = TCO / 8, CPX = TCI / 8;                 // 16-byte chunks per pixel
+    constexpr int OFF_X = RY * YB, XMASK = XR * SEG - 1;
+    constexpr int WCO = TCO / 64, WCI = 4 / WCO;                // waves along co / ci
+    constexpr int WTCO = TCO / WCO, WTCI = TCI / WCI;           // wave tile: 64 co x (32 | 16) ci
+    constexpr int MT = WTCO / 16, NTF = WTCI / 16;
+    static_assert(XR >= LOOK + 2 && (XR & (XR - 1)) == 0, "X ring: a power of two, at least LOOK + 2 blocks");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.y, slice = blockIdx.x;
+    if (p.xcd_group) {           // all the tiles of one K slice on ONE XCD (they re-read the same dY / X pixels), eight slices side by side
+        const int k = blockIdx.x >> 3;
+        tile = k % p.tiles;
+        slice = (k / p.tiles) * 8 + (blockIdx.x & 7);
+    }
+    if (slice >= p.nslices) return;
+    const int ky = tile % 3;
+    tile /= 3;
+    const int ci0 = (tile % p.tiles_ci) * TCI, co0 = (tile / p.tiles_ci) * TCO;
+    const int seg0 = slice * p.steps_per_slice;
+    int nseg = p.total_steps - seg0;
+    if (nseg > p.steps_per_slice) nseg = p.steps_per_slice;
+
+    // ---- lane-constant parts of the DMA sources -------------------------------------------------------------------------------
+    // piece k of a step: wave-instruction (k * 4 + wave) of the block = positions g .. g + 64 / CP - 1, g = (k * NT + wave * 64) / CP;
+    // lane: position g + lane / CP, LDS slot lane % CP, which holds source chunk slot ^ 2 * swz(row in block)
+    int ylane[NY], ygrp[NY], xlane[NX], xgrp[NX], xcol[NX];
+    const int ylp = lane / CPY, xlp = lane / CPX;
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+        ygrp[k] = (k * NT + wave * 64) / CPY;
+        const int px = ygrp[k] + ylp, slot = lane % CPY;
+        ylane[k] = ylp * p.ldy + co0 + ((slot ^ (2 * pair_swz<YROW>(px))) << 3);
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        xgrp[k] = (k * NT + wave * 64) / CPX;
+        const int px = xgrp[k] + xlp, slot = lane % CPX;
+        xcol[k] = ci0 + ((slot ^ (2 * pair_swz<XROW>(px))) << 3);
+        xlane[k] = xlp * p.ldx + xcol[k];
+    }
+
+    // ---- wave-uniform cursors of the next dY / X' block to issue, advanced incrementally (no multiply in the loop) ---------------
+    // a cursor's base pointer addresses the pixel at (its row, its column) of the UNPADDED map -- "virtually" while the column is
+    // one of the L - Wo padding positions: it is only ever dereferenced by lanes whose column is inside the row
+    int jy, rowy, jx, yx, imgx;
+    const bf16_t *ybase, *xbase;
+    {
+        const long f = (long)seg0 * SEG;
+        const int row = (int)(f / p.L), j = (int)(f - (long)row * p.L), img = row / p.Ho, y = row - img * p.Ho;
+        jy = jx = j;
+        rowy = row;
+        yx = y;
+        imgx = img;
+        ybase = dy + ((long)row * p.Wo + j) * p.ldy;
+        xbase = x + (((long)img * p.Hi + y + ky - p.pad) * p.Wi + (j - p.pad)) * p.ldx;
+    }
+    const int ywrap = (p.Wo - p.L) * p.ldy;                       // element offsets added when a column wraps into the next row ...
+    const int xwrap = (p.Wi - p.L) * p.ldx, ximg = (p.Hi - p.Ho) * p.Wi * p.ldx;      // ... / the next image
+    int ny_issued = 0, nx_issued = 0;                          // block indices of the next issues
+    auto issue_y = [&]() {                                     // dY block ny_issued -> slot ny_issued % RY
+        const bool live = ny_issued < nseg;
+        const unsigned slot = lds0 + (ny_issued % RY) * YB;
+#pragma unroll
+        for (int k = 0; k < NY; ++k) {
+            int j = jy + ygrp[k], row = rowy, off = ygrp[k] * p.ldy;
+            if (j >= p.L) { j -= p.L; ++row; off += ywrap; }
+            const int bound = (live && row < p.nrows) ? p.Wo - j : 0;            // lanes of this piece with a column below it are valid
+            glds16(ylp < bound ? ybase + off + ylane[k] : zero, slot + (k * NT + wave * 64) * 16);
+        }
+        if (live) {
+            jy += SEG;
+            ybase += SEG * p.ldy;
+            if (jy >= p.L) { jy -= p.L; ++rowy; ybase += ywrap; }
+        }
+        ++ny_issued;
+    };
+    auto issue_x = [&]() {                                     // X' block nx_issued -> ring block nx_issued % XR
+        const bool live = nx_issued <= nseg;                   // (one block beyond the last dY block: its first two positions are read)
+        const unsigned blk = lds0 + OFF_X + (nx_issued % XR) * XBLK;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            int j = jx + xgrp[k], yy = yx, img = imgx, off = xgrp[k] * p.ldx;
+            if (j >= p.L) {
+                j -= p.L;
+                off += xwrap;
+                if (++yy == p.Ho) { yy = 0; ++img; off += ximg; }
+            }
+            int yin = yy + ky - p.pad;
+            int xin = j + xlp - p.pad;                             // per lane
+            const bf16_t *src;
+            if (p.reflect) {                                       // mirrored halo: row and column of the source follow the reflection
+                yin = yin < 0 ? -yin : (yin >= p.Hi ? 2 * p.Hi - 2 - yin : yin);
+                xin = xin < 0 ? -xin : (xin >= p.Wi ? 2 * p.Wi - 2 - xin : xin);
+                src = x + (((long)img * p.Hi + yin) * p.Wi + xin) * p.ldx + xcol[k];
+            } else
+                src = xbase + off + xlane[k];
+            const bool rowok = live && img < p.N && (unsigned)yin < (unsigned)p.Hi;
+            glds16(rowok && (unsigned)xin < (unsigned)p.Wi ? src : zero, blk + (k * NT + wave * 64) * 16);
+        }
+        if (live) {
+            jx += SEG;
+            xbase += SEG * p.ldx;
+            if (jx >= p.L) {
+                jx -= p.L;
+                xbase += xwrap;
+                if (++yx == p.Ho) { yx = 0; ++imgx; xbase += ximg; }
+            }
+        }
+        ++nx_issued;
+    };
+
+    const int wr = wave / WCI, wc = wave % WCI;
+    f32x4 acc[3][MT][NTF];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTF; ++j) acc[t][i][j] = f32x4{0, 0, 0, 0};
+
+    if (nseg > 0) {
+        issue_x();                                               // X' block 0
+#pragma unroll
+        for (int h = 0; h < LOOK; ++h) {                         // dY block h, X' block h + 1
+            issue_y();
+            issue_x();
+        }
+        for (int s = 0; s < nseg; ++s) {
+            wait_vm<(LOOK - 1) * PER_STEP>();                    // everything issued up to step s - LOOK has landed: dY(s), X'(s), X'(s+1)
+            __builtin_amdgcn_s_barrier();
+            issue_y();                                           // dY(s + LOOK) -> the slot of step s - 1; X'(s + LOOK + 1) -> block s + LOOK + 1 - XR <= s - 1
+            issue_x();
+            const unsigned char *Ys = smem + (s % RY) * YB, *Xs = smem + OFF_X;
+            bf16x8 a[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = tr_frag<YROW, SEG - 1>(Ys, 0, wr * WTCO + 16 * i, lane);
+            const int xrow0 = (s % XR) * SEG;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                bf16x8 b[NTF];
+#pragma unroll
+                for (int j = 0; j < NTF; ++j) b[j] = tr_frag<XROW, XMASK>(Xs, xrow0 + t, wc * WTCI + 16 * j, lane);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTF; ++j) acc[t][i][j] = mma16<DT>(a[i], b[j], acc[t][i][j]);
+            }
+        }
+        wait_vm<0>();
+    }
+
+    // ---- this slice's partial tile -> slab[slice][co][ky * 3 + t][ci] (row co = 4 * (lane >> 4) + r, column ci = lane & 15) -------------
+    float *out = slab + (size_t)slice * p.Co * 9 * p.Ci;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTF; ++j) {
+                const int ci = ci0 + wc * WTCI + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wr * WTCO + 16 * i + 4 * (lane >> 4) + r;
+                    if (co < p.Co && ci < p.Ci) out[((size_t)co * 9 + ky * 3 + t) * p.Ci + ci] = acc[t][i][j][r];
+                }
+            }
+}
+
+// dW[i] += slab[0][i] + slab[1][i] + ... in a FIXED order, whatever order the workgroups finished in.  A workgroup owns 16
+// consecutive f32x4 columns; its 256 threads are 16 slice groups x 16 columns: group g adds slices g, g + 16, ... (in that order,
+// four loads in flight), then the 16 group sums are added in group order through LDS.  (One thread per column summing every slice
+// in turn left a 64 -> 64 layer's 256 slices to 9 216 threads: a ~64-deep chain of dependent memory round trips.)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dw, size_t n4, int nslices) {
+    __shared__ f32x4 red[16][16];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + col;
+    f32x4 s = f32x4{0, 0, 0, 0};
+    if (i < n4) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(slab) + i;
+        int k = grp;
+        for (; k + 48 < nslices; k += 64) {
+            const f32x4 v0 = src[(size_t)k * n4], v1 = src[(size_t)(k + 16) * n4], v2 = src[(size_t)(k + 32) * n4], v3 = src[(size_t)(k + 48) * n4];
+            s = ((s + v0) + v1) + v2;
+            s = s + v3;
+        }
+        for (; k < nslices; k += 16) s = s + src[(size_t)k * n4];
+    }
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && i < n4) {
+        f32x4 t = red[0][col];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t = t + red[g][col];
+        // (atomic: with RDFC_WGRAD_STREAM=0 two uses of one parameter may run their weight gradients on different streams; in the
+        //  default configuration every weight gradient is on the one side stream, i.e. one add per element at a time, in launch order)
+        float *d = dw + 4 * i;
+        atomicAdd(d, t[0]);
+        atomicAdd(d + 1, t[1]);
+        atomicAdd(d + 2, t[2]);
+        atomicAdd(d + 3, t[3]);
+    }
+}
+
+const bf16_t *zero_page() {
+    static void *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (pages[dev] == nullptr) {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
+        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = ptr;
+    }
+    return (const bf16_t *)pages[dev];
+}
+
+// Scratch for the partial slabs: one buffer per (device, stream) -- launches on one stream run one after the other, so the next
+// launch's workgroups cannot overwrite slabs a reduction still reads.  Grown on demand (never while the stream is being captured).
+float *slab_for(hipStream_t st, size_t bytes) {
+    struct Ent {
+        int dev;
+        hipStream_t st;
+        void *ptr;
+        size_t cap;
+    };
+    static Ent tab[64];
+    static int n = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    Ent *e = nullptr;
+    for (int i = 0; i < n; ++i)
+        if (tab[i].dev == dev && tab[i].st == st) e = &tab[i];
+    if (e != nullptr && e->cap >= bytes) return (float *)e->ptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // no allocation inside a capture
+    if (e == nullptr) {
+        if (n == 64) return nullptr;
+        e = &tab[n++];
+        *e = Ent{dev, st, nullptr, 0};
+    }
+    if (e->ptr != nullptr) {
+        if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+        (void)hipFree(e->ptr);
+        e->ptr = nullptr;
+        e->cap = 0;
+    }
+    size_t cap = bytes < (size_t)(64u << 20) ? (size_t)(64u << 20) : bytes + bytes / 4;
+    if (hipMalloc(&e->ptr, cap) != hipSuccess) {
+        e->ptr = nullptr;
+        return nullptr;
+    }
+    e->cap = cap;
+    return (float *)e->ptr;
+}
+
+template <int TCO, int DT>
+int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
+    constexpr int SMEM = 4 * (SEG * TCO * 2) + 8 * (SEG * 64 * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)wgrad_ring_kernel<TCO, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        attr_set = true;
+    }
+    p.tiles_ci = cdiv(p.Ci, 64);
+    const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * 3;
+    // one round of the chip's workgroup slots (2 per CU with the 128-co tile, 3 with the 64-co one) within a slab budget: every
+    // workgroup writes its tile once (plain stores) and the reduction reads it once
+    static const int slots_env = getenv("RDFC_WGRAD_SLOTS") ? atoi(getenv("RDFC_WGRAD_SLOTS")) : 0;
+    static const double cap_mb = getenv("RDFC_WGRAD_SLAB_MB") ? atof(getenv("RDFC_WGRAD_SLAB_MB")) : 64.0;
+    const int slots = slots_env ? slots_env : (TCO == 64 ? 768 : 512);
+    int slices = slots / tiles;
+    const size_t dw_bytes = (size_t)4 * p.Co * p.Ci * 9;
+    const int cap = (int)(cap_mb * 1.0e6 / (double)dw_bytes);
+    if (slices > cap) slices = cap;
+    if (slices > cdiv(p.total_steps, 8)) slices = cdiv(p.total_steps, 8);
+    if (slices < 1) slices = 1;
+    p.steps_per_slice = cdiv(p.total_steps, slices);
+    slices = cdiv(p.total_steps, p.steps_per_slice);
+    p.nslices = slices;
+    p.tiles = tiles;
+    float *slab = slab_for(st, dw_bytes * slices);
+    if (slab == nullptr) return 0;
+    static const bool xcd_group = !(getenv("RDFC_WGRAD_XCD") && atoi(getenv("RDFC_WGRAD_XCD")) == 0);
+    p.xcd_group = xcd_group && tiles <= 3 && slices >= 8;
+    const dim3 grid = p.xcd_group ? dim3(cdiv(slices, 8) * 8 * tiles, 1) : dim3(slices, tiles);
+    rdfc_note_kernel("wgrad_ring_kernel<%d, %d>", TCO, DT);
+    hipLaunchKernelGGL((wgrad_ring_kernel<TCO, DT>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab, zero);
+    const size_t n4 = dw_bytes / 16;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float *)slab, dw, n4, slices);
+    return 1;
+}
+
+}  // namespace
+
+// Called by rdfc_try_wgrad_glds (conv_wgrad_glds.hip) ahead of its own kernels; returns 1 if it took the launch.
+// RDFC_WGRAD_RING=0 switches it off (A/B against the segment walk + float atomics).
+int rdfc_try_wgrad_ring(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st, int reflect) {
+    const char *env_ = getenv("RDFC_WGRAD_RING");               // (read per call: tools/wgrad_ring_bench.py switches it between launches)
+    if (env_ != nullptr && atoi(env_) == 0) return 0;
+    if (!rdfc_is16(d->dtype)) return 0;
+    if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return 0;
+    if (d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
+    if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8 || d->Wo < 24) return 0;
+    if (((uintptr_t)dw & 15) != 0) return 0;
+    if (reflect && (d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return 0;
+    const int L = (d->Wo + 2 + 7) / 8 * 8;
+    if ((double)d->N * d->Ho * L >= 2.0e9) return 0;
+    const bf16_t *zero = zero_page();
+    if (zero == nullptr) return 0;
+    RParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, L < 32 ? 32 : L, d->N * d->Ho, 0, 0, 0, 0, 0, 0, reflect};
+    p.total_steps = cdiv((long)p.nrows * p.L, SEG);
+    // 128-co tiles from 256 output channels up (as conv_wgrad_glds.hip: below that the 64-co tile's larger grid wins)
+    if (d->Co % 128 == 0 && d->Co >= 256)
+        return d->dtype == RDFC_F16 ? launch<128, RDFC_F16>(p, x, dy, dw, zero, st) : launch<128, RDFC_BF16>(p, x, dy, dw, zero, st);
+    return d->dtype == RDFC_F16 ? launch<64, RDFC_F16>(p, x, dy, dw, zero, st) : launch<64, RDFC_BF16>(p, x, dy, dw, zero, st);
+}

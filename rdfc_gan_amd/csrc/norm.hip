@@ -119,12 +119,8 @@ inline dim3 grid_for(const Map &m, int vec) {
 // When the channel-vector count CVT divides 64, rows that share a channel vector sit in the same wave at lane
 // stride CVT: butterfly over those lanes first (xor CVT, 2CVT, ...), then one LDS slot per wave -- instead of a
 // handful of threads serially adding up to 64 rows out of LDS (that tail used to cost more than the streaming part).
-// acc64 != nullptr: the workgroup's sums go straight into acc64[g][k][c] (f64, pre-zeroed) with one hardware atomic each
-// instead of into the partial buffer -- no finalize launch; the order of the additions is then not fixed (f64 keeps the
-// result within rounding of the two-stage path, bitwise reproducibility is what RDFC_DETERMINISTIC=1 buys back).
 template <typename T, int K>
-__device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K][Elem<T>::VEC], float *partial,
-                                   double *acc64 = nullptr) {
+__device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K][Elem<T>::VEC], float *partial) {
     // Every thread deposits its K x VEC sums in LDS ([k][thread][v], 16-byte stores), then the K * CVT * VEC outputs are dealt to
     // ALL 256 threads: output o = (k, channel vector, v) sums its RPB rows (fixed order r = 0 .. RPB-1: reproducible) and is stored
     // with its neighbours in one coalesced line.  (Before: a butterfly of 24 runtime-offset shuffles plus a tail in which CVT
@@ -148,8 +144,7 @@ __device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K]
         float a = 0.f;
         for (int r = 0; r < RPB; ++r) a += red[(k * NT + r * CVT + cvt) * VEC + v];
         const int c = cbase + cvv;
-        if (acc64 != nullptr) unsafeAtomicAdd(&acc64[((size_t)cx.g * K + k) * m.C + c], (double)a);
-        else partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + c] = a;
+        partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + c] = a;
     }
 }
 
@@ -170,8 +165,7 @@ __device__ __forceinline__ void load_consts(const float *__restrict__ p, int idx
 
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ x, int ld, float *__restrict__ partial,
-                                                   double *__restrict__ acc64) {
+__global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ x, int ld, float *__restrict__ partial) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[2][VEC];
@@ -191,7 +185,7 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
         };
         ROW_LOOP(cx, body);
     }
-    block_reduce_store<T, 2>(cx, m, s, partial, acc64);
+    block_reduce_store<T, 2>(cx, m, s, partial);
 }
 
 // fixed-order sum over the chunk partials of one (group, k, channel): 32 channels x FL lanes per workgroup,
@@ -286,26 +280,7 @@ struct ApplyArgs {
     const float *mean, *rstd, *gamma, *beta, *prelu;
     int act;            // none | relu | lrelu | prelu only: all piecewise linear -> act(u) = u > 0 ? u : u * neg_slope
     float slope;
-    // one-stage statistics (rdfc_norm_apply_sums): mean / rstd are derived from the f64 sums {sum x, sum x^2}[g][c] here,
-    // written to mean_out / rstd_out (for the backward) and into the running statistics by the first workgroup
-    const double *sums64 = nullptr;
-    float eps = 0.f;
-    float *mean_out = nullptr, *rstd_out = nullptr, *run_mean = nullptr, *run_var = nullptr;
-    float momentum = 0.f;
 };
-__device__ inline void stats_of(const ApplyArgs &a, const Map &m, int g, int c, float &mu, float &rs) {
-    if (a.sums64 == nullptr) {
-        mu = a.mean[g * m.C + c];
-        rs = a.rstd[g * m.C + c];
-        return;
-    }
-    const double s1 = a.sums64[((size_t)g * 2 + 0) * m.C + c], s2 = a.sums64[((size_t)g * 2 + 1) * m.C + c];
-    const double mean = s1 / m.P;
-    double var = s2 / m.P - mean * mean;
-    if (var < 0) var = 0;
-    mu = (float)mean;
-    rs = (float)(1.0 / sqrt(var + (double)a.eps));
-}
 __device__ inline float neg_slope_of(const ApplyArgs &a) {
     return a.act == RDFC_ACT_NONE ? 1.f : (a.act == RDFC_ACT_RELU ? 0.f : (a.act == RDFC_ACT_PRELU ? *a.prelu : a.slope));
 }
@@ -317,7 +292,7 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
     Ctx<T> cx(m);
     if (!cx.active) return;
     float sc[VEC], sh[VEC];
-    if (a.sums64 == nullptr) {          // two-stage path (the default): constants by 16-byte loads
+    {                                   // per-channel constants by 16-byte loads
         float gav[VEC], bev[VEC], rsv[VEC], muv[VEC];
         load_consts<VEC>(a.gamma, cx.c0, 1.f, gav);
         load_consts<VEC>(a.beta, cx.c0, 0.f, bev);
@@ -327,27 +302,6 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
         for (int v = 0; v < VEC; ++v) {
             sc[v] = gav[v] * rsv[v];
             sh[v] = bev[v] - muv[v] * gav[v] * rsv[v];
-        }
-    } else
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        const int c = cx.c0 + v;
-        const float ga = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
-        float r, mu;
-        stats_of(a, m, cx.g, c, mu, r);
-        sc[v] = ga * r;
-        sh[v] = be - mu * ga * r;
-        if (a.sums64 != nullptr && cx.chunk == 0 && cx.r0 == 0) {        // exactly one thread per (group, channel)
-            if (a.mean_out) a.mean_out[cx.g * m.C + c] = mu;
-            if (a.rstd_out) a.rstd_out[cx.g * m.C + c] = r;
-            if (a.run_mean != nullptr && cx.g == 0) {                     // nn.BatchNorm2d running statistics (G == 1)
-                const double s1 = a.sums64[c], s2 = a.sums64[m.C + c], mean = s1 / m.P;
-                double var = s2 / m.P - mean * mean;
-                if (var < 0) var = 0;
-                const double unb = m.P > 1 ? var * m.P / (m.P - 1) : var;
-                a.run_mean[c] = (float)((1.0 - a.momentum) * a.run_mean[c] + a.momentum * mean);
-                a.run_var[c] = (float)((1.0 - a.momentum) * a.run_var[c] + a.momentum * unb);
-            }
         }
     }
     const float ns = neg_slope_of(a);
@@ -371,7 +325,7 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
 template <typename T>
 __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
                                                         const T *__restrict__ res, float *__restrict__ partial, int lddz,
-                                                        int ldx, int ldr, double *__restrict__ acc64) {
+                                                        int ldx, int ldr) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[3][VEC];
@@ -416,20 +370,28 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
         ROW_LOOP(cx, body);
 #endif
     }
-    block_reduce_store<T, 3>(cx, m, s, partial, acc64);
+    block_reduce_store<T, 3>(cx, m, s, partial);
 }
 
 __global__ __launch_bounds__(FNT) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
                                                           float *__restrict__ sums, float *__restrict__ acc0, float *__restrict__ acc1) {
     __shared__ double red[FL * 32];
-    const int g = blockIdx.y / K, k = blockIdx.y % K, c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const double s = chunk_sum(partial, g, K, k, C, c, nchunk, red);
+    // grid.y = K: this workgroup walks the G groups in order (accumulating launches); grid.y = G * K: one (group, sum) each
+    const bool walk = (int)gridDim.y == K;
+    const int k = walk ? (int)blockIdx.y : (int)blockIdx.y % K, c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int g0 = walk ? 0 : (int)blockIdx.y / K, g1 = walk ? G : g0 + 1;
+    // optional in-place accumulation of sum 0 / sum 1 (d beta / d gamma of an affine norm): the G groups (BatchNorm over stacked
+    // batches) are added in group order by ONE thread and leave as one add per channel -- reproducible; that add is atomic because
+    // the same parameter's two uses per step may run their backward on different streams (unbatched schedule)
+    double total = 0;
+    for (int g = g0; g < g1; ++g) {
+        const double s = chunk_sum(partial, g, K, k, C, c, nchunk, red);
+        if (threadIdx.x < 32 && c < C) sums[((size_t)g * K + k) * C + c] = (float)s;
+        total += (double)(float)s;
+    }
     if (threadIdx.x < 32 && c < C) {
-        sums[((size_t)g * K + k) * C + c] = (float)s;
-        // optional in-place accumulation of sum 0 / sum 1 (d beta / d gamma of an affine norm with one group)
-        // (atomic: the same parameter's two uses per step run their backward on different streams)
-        if (k == 0 && acc0 != nullptr) atomicAdd(&acc0[c], (float)s);
-        if (k == 1 && acc1 != nullptr) atomicAdd(&acc1[c], (float)s);
+        if (k == 0 && acc0 != nullptr) atomicAdd(&acc0[c], (float)total);
+        if (k == 1 && acc1 != nullptr) atomicAdd(&acc1[c], (float)total);
     }
 }
 
@@ -437,43 +399,25 @@ template <typename T>
 __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
                                                        const T *__restrict__ res, const float *__restrict__ sums,
                                                        T *__restrict__ dx, T *__restrict__ dres, int lddz, int ldx, int ldr,
-                                                       int lddx, int lddr, int frozen, const double *__restrict__ sums64,
-                                                       float *__restrict__ sums_out, float *__restrict__ dbeta_acc,
-                                                       float *__restrict__ dgamma_acc) {
+                                                       int lddx, int lddr, int frozen) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     if (!cx.active) return;
     float ga[VEC], sc[VEC], sh[VEC], mu[VEC], rs[VEC], m1[VEC], m2[VEC];
     const float invP = 1.f / (float)m.P;
-    // one-stage path: the f64 sums of rdfc_norm_bwd_reduce_acc; one thread per (group, channel) rounds them to the f32
-    // `sums` the two-stage path would have produced (sums_out) and adds the affine gradients to their .grad
-    const bool one_stage = sums64 != nullptr;
     float bev[VEC], s1v[VEC], s2v[VEC];
     load_consts<VEC>(a.gamma, cx.c0, 1.f, ga);
     load_consts<VEC>(a.beta, cx.c0, 0.f, bev);
     load_consts<VEC>(a.rstd, cx.g * m.C + cx.c0, 1.f, rs);
     load_consts<VEC>(a.mean, cx.g * m.C + cx.c0, 0.f, mu);
-    load_consts<VEC>(one_stage ? nullptr : sums, (cx.g * 3 + 0) * m.C + cx.c0, 0.f, s1v);
-    load_consts<VEC>(one_stage ? nullptr : sums, (cx.g * 3 + 1) * m.C + cx.c0, 0.f, s2v);
+    load_consts<VEC>(sums, (cx.g * 3 + 0) * m.C + cx.c0, 0.f, s1v);
+    load_consts<VEC>(sums, (cx.g * 3 + 1) * m.C + cx.c0, 0.f, s2v);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-        const int c = cx.c0 + v;
-        const float be = bev[v];
         sc[v] = ga[v] * rs[v];
-        sh[v] = be - mu[v] * ga[v] * rs[v];
-        const float S1 = one_stage ? (float)sums64[((size_t)cx.g * 3 + 0) * m.C + c] : s1v[v];
-        const float S2 = one_stage ? (float)sums64[((size_t)cx.g * 3 + 1) * m.C + c] : s2v[v];
-        m1[v] = frozen ? 0.f : S1 * invP;
-        m2[v] = frozen ? 0.f : S2 * invP;
-        if (one_stage && cx.chunk == 0 && cx.r0 == 0) {
-            if (sums_out != nullptr) {
-                sums_out[(cx.g * 3 + 0) * m.C + c] = S1;
-                sums_out[(cx.g * 3 + 1) * m.C + c] = S2;
-                sums_out[(cx.g * 3 + 2) * m.C + c] = (float)sums64[((size_t)cx.g * 3 + 2) * m.C + c];
-            }
-            if (dbeta_acc != nullptr) atomicAdd(&dbeta_acc[c], S1);
-            if (dgamma_acc != nullptr) atomicAdd(&dgamma_acc[c], S2);
-        }
+        sh[v] = bev[v] - mu[v] * ga[v] * rs[v];
+        m1[v] = frozen ? 0.f : s1v[v] * invP;
+        m2[v] = frozen ? 0.f : s2v[v] * invP;
     }
     const float ns = neg_slope_of(a);
     const size_t gb = (size_t)cx.g * m.P;
@@ -670,7 +614,7 @@ extern "C" int rdfc_norm_nchunk(int pixels_per_group, int C, int dtype) {
 extern "C" int rdfc_norm_stats(const void *x, float *partial, int G, int P, int C, int ld, int dtype, void *stream) {
     if (int e = check_map("rdfc_norm_stats", G, P, C, dtype, {ld})) return e;
     Map m = make_map(G, P, C, rdfc_vec(dtype));
-    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld, partial, (double *)nullptr));
+    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld, partial));
     RDFC_LAUNCH_CHECK("rdfc_norm_stats");
     return 0;
 }
@@ -731,15 +675,16 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
     Map m = make_map(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                       (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr, (double *)nullptr));
+                                       (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr));
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_reduce");
     return 0;
 }
 
 extern "C" int rdfc_norm_bwd_finalize_acc(const float *partial, float *sums, int G, int P, int C, int dtype, float *dbeta_acc,
                                           float *dgamma_acc, void *stream) {
-    // (G > 1 with accumulators: BatchNorm over G stacked batches -- every group's sums are added, atomically)
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), G * 3), dim3(FNT), 0, (hipStream_t)stream, G, C, 3,
+    // (G > 1 with accumulators: BatchNorm over G stacked batches -- the groups' sums are added in group order)
+    const bool acc = dbeta_acc != nullptr || dgamma_acc != nullptr;
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), acc ? 3 : G * 3), dim3(FNT), 0, (hipStream_t)stream, G, C, 3,
                        cdiv(P, chunk_pixels(P, C, rdfc_vec(dtype))), partial, sums, dbeta_acc, dgamma_acc);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_finalize");
     return 0;
@@ -757,8 +702,7 @@ extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *m
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
-                                       lddx, lddr, frozen_stats, (const double *)nullptr, (float *)nullptr, (float *)nullptr,
-                                       (float *)nullptr));
+                                       lddx, lddr, frozen_stats));
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_apply");
     return 0;
 }
@@ -794,72 +738,6 @@ extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *me
     if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, dbeta_acc, dgamma_acc, stream)) return e;
     return rdfc_norm_bwd_apply(dz, x, mean, rstd, gamma, beta, res, sums, dx, dres, G, P, C, lddz, ldx, ldr, lddx, lddr, dtype, act,
                                slope, prelu, frozen_stats, stream);
-}
-
-// ---- one-stage variants: f64 atomics instead of partial buffers + finalize launches ---------------------------------
-extern "C" int rdfc_norm_stats_acc(const void *x, double *sums64, int G, int P, int C, int ld, int dtype, void *stream) {
-    if (int e = check_map("rdfc_norm_stats_acc", G, P, C, dtype, {ld})) return e;
-    RDFC_REQUIRE(sums64 != nullptr, "rdfc_norm_stats_acc: null accumulator");
-    Map m = make_map(G, P, C, rdfc_vec(dtype));
-    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld,
-                                       (float *)nullptr, sums64));
-    RDFC_LAUNCH_CHECK("rdfc_norm_stats_acc");
-    return 0;
-}
-
-extern "C" int rdfc_norm_apply_sums(const void *x, const double *sums64, const float *gamma, const float *beta, const void *res,
-                                    void *z, float *mean_out, float *rstd_out, int G, int P, int C, int ldx, int ldr, int ldz,
-                                    int dtype, float eps, int act, float slope, const float *prelu, float *run_mean,
-                                    float *run_var, float momentum, void *stream) {
-    if (int e = check_map("rdfc_norm_apply_sums", G, P, C, dtype, {ldx, ldz})) return e;
-    RDFC_REQUIRE(sums64 != nullptr, "rdfc_norm_apply_sums: null statistics");
-    RDFC_REQUIRE(act != RDFC_ACT_PRELU || prelu != nullptr, "rdfc_norm_apply_sums: PReLU needs the slope pointer");
-    RDFC_REQUIRE(act != RDFC_ACT_TANH && act != RDFC_ACT_SIGMOID, "rdfc_norm_apply_sums: tanh / sigmoid never follow a norm on this path");
-    RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_apply_sums: running statistics need G == 1 (batch norm)");
-    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
-    ApplyArgs a{nullptr, nullptr, gamma, beta, prelu, act, slope};
-    a.sums64 = sums64;
-    a.eps = eps;
-    a.mean_out = mean_out;
-    a.rstd_out = rstd_out;
-    a.run_mean = run_mean;
-    a.run_var = run_var;
-    a.momentum = momentum;
-    DISPATCH(dtype, hipLaunchKernelGGL(apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                       (const T *)x, (const T *)res, (T *)z, ldx, ldr, ldz));
-    RDFC_LAUNCH_CHECK("rdfc_norm_apply_sums");
-    return 0;
-}
-
-extern "C" int rdfc_norm_bwd_reduce_acc(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
-                                        const float *beta, const void *res, double *sums64, int G, int P, int C, int lddz,
-                                        int ldx, int ldr, int dtype, int act, float slope, const float *prelu, void *stream) {
-    if (int e = check_map("rdfc_norm_bwd_reduce_acc", G, P, C, dtype, {lddz, ldx})) return e;
-    RDFC_REQUIRE(sums64 != nullptr, "rdfc_norm_bwd_reduce_acc: null accumulator");
-    Map m = make_map(G, P, C, rdfc_vec(dtype));
-    ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
-    DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                       (const T *)dz, (const T *)x, (const T *)res, (float *)nullptr, lddz, ldx, ldr, sums64));
-    RDFC_LAUNCH_CHECK("rdfc_norm_bwd_reduce_acc");
-    return 0;
-}
-
-extern "C" int rdfc_norm_bwd_apply_sums(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
-                                        const float *beta, const void *res, const double *sums64, void *dx, void *dres,
-                                        float *sums_out, float *dbeta_acc, float *dgamma_acc, int G, int P, int C, int lddz,
-                                        int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
-                                        const float *prelu, int frozen_stats, void *stream) {
-    if (int e = check_map("rdfc_norm_bwd_apply_sums", G, P, C, dtype, {lddz, ldx, lddx})) return e;
-    RDFC_REQUIRE(sums64 != nullptr, "rdfc_norm_bwd_apply_sums: null sums");
-    RDFC_REQUIRE(G == 1 || (dbeta_acc == nullptr && dgamma_acc == nullptr),
-                 "rdfc_norm_bwd_apply_sums: in-place affine gradients need one statistics group (batch norm)");
-    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
-    ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
-    DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                       (const T *)dz, (const T *)x, (const T *)res, (const float *)nullptr, (T *)dx, (T *)dres, lddz,
-                                       ldx, ldr, lddx, lddr, frozen_stats, sums64, sums_out, dbeta_acc, dgamma_acc));
-    RDFC_LAUNCH_CHECK("rdfc_norm_bwd_apply_sums");
-    return 0;
 }
 
 extern "C" int rdfc_adain_apply(const void *x, const float *mean, const float *rstd, const void *gb, void *out, int N, int P,

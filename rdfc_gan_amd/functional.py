@@ -19,12 +19,10 @@ import torch
 
 from . import hip
 
-# Normalisation reductions: two-stage (per-workgroup partials + a fixed-order f64 finalize launch; bitwise reproducible)
-# by default.  RDFC_NORM_ONESTAGE=1 switches to f64 atomics into one accumulator per (group, channel), which drops the
-# finalize launches but measured SLOWER on MI355X: ~540 workgroups adding to the same address serialise at ~54 ns per
-# add (statistics kernels 1.6 -> 6.4 ms, backward reductions 4.4 -> 9.2 ms per step), far more than the 2.2 ms of
-# finalize launches it saves.
-_DETERMINISTIC = os.environ.get('RDFC_NORM_ONESTAGE', '0') != '1'
+# Normalisation reductions are two-stage (per-workgroup partials + a fixed-order f64 finalize launch): bitwise reproducible.
+# (A one-stage variant -- f64 atomics into one accumulator per (group, channel), no finalize launches -- was built in round 1
+# and measured SLOWER on MI355X: ~540 workgroups adding to the same address serialise at ~54 ns per add, statistics kernels
+# 1.6 -> 6.4 ms and backward reductions 4.4 -> 9.2 ms per step against 2.2 ms of finalize launches saved; removed in round 3.)
 _compute_dtype = torch.bfloat16
 _weights_epoch = 0
 
@@ -331,7 +329,7 @@ class _ConvBlock(torch.autograd.Function):
             d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
                               act=epi_act, slope=spec.slope, out_f32=out_f32)
             G_ = N if spec.norm == 'in' else 1
-            if live_stats and _DETERMINISTIC and hip.conv_stats_nchunk(d, G_) > 0:
+            if live_stats and hip.conv_stats_nchunk(d, G_) > 0:
                 upd = spec.norm == 'bn' and run_mean is not None
                 fused = hip.conv_forward_stats(d, x, wf, bias, y, G_, spec.eps, run_mean if upd else None,
                                                run_var if upd else None, spec.momentum, group_momenta=gm)
@@ -362,12 +360,9 @@ class _ConvBlock(torch.autograd.Function):
             if fused is not None:
                 mean, rstd = fused
                 hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
-            elif _DETERMINISTIC or gm is not None:
+            else:
                 mean, rstd = hip.norm_forward(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
                                               run_mean if upd else None, run_var if upd else None, spec.momentum, group_momenta=gm)
-            else:
-                mean, rstd = hip.norm_forward_onestage(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
-                                                       run_mean if upd else None, run_var if upd else None, spec.momentum)
         ctx.save_for_backward(x, weight, y, mean, rstd, gamma, beta, res, prelu)
         return (z, x_alias.view(x_alias.shape)) if spec.passthrough else z
 
@@ -384,8 +379,7 @@ class _ConvBlock(torch.autograd.Function):
             # affine gradients straight into persistent .grad buffers (FlatAdam's) when there is one statistics group
             direct = (gamma is not None and beta is not None and ctx.needs_input_grad[3]
                       and ctx.needs_input_grad[4] and _accumulable(gamma.grad) and _accumulable(beta.grad))
-            nb = hip.norm_backward if (_DETERMINISTIC or mean.shape[0] > 1) else hip.norm_backward_onestage
-            dy, g_res, sums = nb(dz, y, mean, rstd, gamma, beta, res, spec.act, spec.slope, prelu,
+            dy, g_res, sums = hip.norm_backward(dz, y, mean, rstd, gamma, beta, res, spec.act, spec.slope, prelu,
                               frozen=frozen, want_dres=res is not None and ctx.needs_input_grad[5],
                               acc_beta=beta.grad if direct else None, acc_gamma=gamma.grad if direct else None)
             if gamma is not None and not direct:

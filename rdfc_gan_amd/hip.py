@@ -470,68 +470,6 @@ def norm_stats(x, G, eps, run_mean=None, run_var=None, momentum=0.1):
     return mean, rstd
 
 
-# ---- zeroed f64 scratch for the one-stage reductions: one arena per device, bump-allocated, re-zeroed by reset_sums()
-_ARENA_DOUBLES = 1 << 20          # 8 MB: a train step's ~300 normalisation layers take ~3 MB
-_arenas = {}
-
-
-def reset_sums(device):
-    """zero the arena and rewind it (call once per train step, before the first layer; capturable)"""
-    a = _arenas.get(device)
-    if a is not None:
-        a[0].zero_()
-        a[1] = 0
-
-
-def zeros_f64(n, device):
-    a = _arenas.get(device)
-    if a is None:
-        a = _arenas[device] = [torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=device), 0]
-    n8 = (n + 7) // 8 * 8
-    if a[1] + n8 > _ARENA_DOUBLES:                 # nobody rewound it (layers used outside a train step): fresh memory
-        return torch.zeros(n, dtype=torch.float64, device=device)
-    out = a[0][a[1]:a[1] + n]
-    a[1] += n8
-    return out
-
-
-def norm_forward_onestage(x, G, eps, gamma, beta, res, z, act='none', slope=0.0, prelu=None, run_mean=None, run_var=None,
-                          momentum=0.1, sums=None):
-    """statistics + normalise in two launches (f64 atomics, no finalize); `sums` already filled by the producing conv's
-    epilogue skips the statistics launch.  -> mean[G,C], rstd[G,C] (for the backward)"""
-    N, H, W, Cc = x.shape
-    P = N * H * W // G
-    if sums is None:
-        sums = zeros_f64(G * 2 * Cc, x.device)
-        _chk(lib().rdfc_norm_stats_acc(_p(x), _p(sums), G, P, Cc, ld(x), dt(x), _st()), 'rdfc_norm_stats_acc')
-    mean = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
-    _chk(lib().rdfc_norm_apply_sums(_p(x), _p(sums), _p(gamma), _p(beta), _p(res), _p(z), _p(mean), _p(rstd), G, P, Cc, ld(x),
-                                    ld(res) if res is not None else 0, ld(z), dt(x), _f(eps), ACT[act], _f(slope), _p(prelu),
-                                    _p(run_mean), _p(run_var), _f(momentum), _st()), 'rdfc_norm_apply_sums')
-    return mean, rstd
-
-
-def norm_backward_onestage(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, prelu=None, frozen=False,
-                           want_dres=False, acc_beta=None, acc_gamma=None):
-    """norm_backward without the finalize launch: -> dx, dres (or None), sums[G,3,C] f32"""
-    N, H, W, Cc = x.shape
-    G = mean.shape[0]
-    P = N * H * W // G
-    sums64 = zeros_f64(G * 3 * Cc, x.device)
-    sums = torch.empty(G, 3, Cc, dtype=torch.float32, device=x.device)
-    ldr = ld(res) if res is not None else 0
-    _chk(lib().rdfc_norm_bwd_reduce_acc(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(sums64), G, P, Cc,
-                                        ld(dz), ld(x), ldr, dt(x), ACT[act], _f(slope), _p(prelu), _st()),
-         'rdfc_norm_bwd_reduce_acc')
-    dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
-    dres = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device) if want_dres else None
-    _chk(lib().rdfc_norm_bwd_apply_sums(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(sums64), _p(dx),
-                                        _p(dres), _p(sums), _p(acc_beta), _p(acc_gamma), G, P, Cc, ld(dz), ld(x), ldr, Cc, Cc,
-                                        dt(x), ACT[act], _f(slope), _p(prelu), int(frozen), _st()), 'rdfc_norm_bwd_apply_sums')
-    return dx, dres, sums
-
-
 def norm_apply(x, mean, rstd, gamma, beta, res, z, act='none', slope=0.0, prelu=None):
     N, H, W, Cc = x.shape
     G = mean.shape[0]
@@ -545,7 +483,7 @@ def norm_apply(x, mean, rstd, gamma, beta, res, z, act='none', slope=0.0, prelu=
 def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, prelu=None, frozen=False,
                   want_dres=False, acc_beta=None, acc_gamma=None):
     """-> dx, dres (or None), sums[G,3,C] (sum du, sum du*xhat, sum dz*min(u,0)).
-    acc_beta / acc_gamma: f32[C] buffers that additionally receive += sums[0,0] / sums[0,1] (G == 1 only).
+    acc_beta / acc_gamma: f32[C] buffers that additionally receive += the sums over all groups of sums[g,0] / sums[g,1].
     One call: reduce + finalize + apply (rdfc_norm_backward)."""
     N, H, W, Cc = x.shape
     G = mean.shape[0]

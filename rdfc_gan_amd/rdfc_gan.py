@@ -461,9 +461,8 @@ class RDFCGAN:
         return fake_B if mask is None else _PepperNoise.apply(fake_B, self._mask_to_device(mask))
 
     def forward(self):
-        hip.reset_sums(self.device)
         if self._batched():
-            return self._forward_batched()         # zeroed f64 scratch of the one-stage normalisation reductions: rewound per step
+            return self._forward_batched()
         # The B->A half (G_B2A(real_B)) shares nothing with the A->B half in this method when only the four hot-path networks
         # run: it forks HERE, not behind everything the main stream has enqueued by then.  (G_label / G_normal are used by
         # both halves -- running statistics, packed weights -- so with them the fork stays behind the A->B half.)

@@ -298,38 +298,6 @@ def test_conv_fused_statistics(case, monkeypatch):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
-def test_norm_onestage_matches_twostage(dtype):
-    """rdfc_norm_*_acc / *_sums (f64 atomics, no finalize launch) against the two-stage fixed-order path"""
-    h = hip()
-    N, H, W, C = 3, 21, 17, 40
-    x = to_pm(rnd(N, C, H, W, seed=1), dtype)
-    dz = to_pm(rnd(N, C, H, W, seed=2), dtype)
-    res = to_pm(rnd(N, C, H, W, seed=3), dtype)
-    gamma, beta = (rnd(C, seed=4) + 1.0).to(DEV), rnd(C, seed=5).to(DEV)
-    for G in (1, N):
-        rm1, rv1 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-        rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-        upd = G == 1
-        mean, rstd = h.norm_stats(x, G, 1e-5, rm1 if upd else None, rv1 if upd else None, 0.1)
-        z1 = h.norm_apply(x, mean, rstd, gamma, beta, res, torch.empty_like(x), 'relu', 0.0)
-        z2 = torch.empty_like(x)
-        mean2, rstd2 = h.norm_forward_onestage(x, G, 1e-5, gamma, beta, res, z2, 'relu', 0.0, None, rm2 if upd else None,
-                                               rv2 if upd else None, 0.1)
-        assert rel_err(mean2, mean) < 1e-6 and rel_err(rstd2, rstd) < 1e-6
-        assert rel_err(z2, z1) < 1e-6
-        if upd:
-            assert rel_err(rm2, rm1) < 1e-6 and rel_err(rv2, rv1) < 1e-6
-        gb1, gg1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-        dx1, dr1, s1 = h.norm_backward(dz, x, mean, rstd, gamma, beta, res, 'relu', 0.0, want_dres=True)
-        dx2, dr2, s2 = h.norm_backward_onestage(dz, x, mean, rstd, gamma, beta, res, 'relu', 0.0, want_dres=True,
-                                                acc_beta=gb1 if upd else None, acc_gamma=gg1 if upd else None)
-        assert rel_err(s2, s1) < 1e-5
-        assert rel_err(dx2, dx1) < (1e-5 if dtype == torch.float32 else 1e-2) and rel_err(dr2, dr1) < 1e-6
-        if upd:
-            assert rel_err(gb1, s1[0, 0]) < 1e-5 and rel_err(gg1, s1[0, 1]) < 1e-5
-
-
-@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_adain(dtype):
     h = hip()
     N, H, W, C = 2, 7, 9, 192

@@ -140,11 +140,16 @@ def test_config3_nlspn_18_steps_228x304_against_oracle():
     from rdfc_gan_amd.nlspn import NLPSN
     setup_dtype(torch.float32)
     B, H, W, T = 1, 228, 304, NLSPN_CFG['prop_time']
+    # A well-posed instance: the initial map is a depth map (smooth, with rectangular holes), the guidance conv's weights are
+    # small (offsets up to ~0.2 px, |affinity| sums up to ~1.2).  With weights of 0.02 and more or a white-noise map the 18-step
+    # recursion amplifies rounding differences by orders of magnitude (the oracle evaluated in f32 and in f64 differs by 2e-3
+    # .. 0.7 there); here f32 and f64 oracle agree to 7e-6 while the propagation still moves pixels by up to 0.6.
+    _, raw, _ = gen_inputs('nlspn18', B, H, W)
     guide = det_tensor(61, 'guide', (B, 8, H, W))
-    init = det_tensor(61, 'init', (B, 1, H, W))
+    init = raw.clone()
     conf = torch.sigmoid(det_tensor(61, 'conf', (B, 1, H, W)))
     gout = det_tensor(61, 'gout', (B, 1, H, W))
-    w, b = det_tensor(61, 'w', (24, 8, 3, 3)) * 0.1, det_tensor(61, 'b', (24,)) * 0.1
+    w, b = det_tensor(61, 'w', (24, 8, 3, 3)) * 0.005, det_tensor(61, 'b', (24,)) * 0.005
     ref = NLSPNProp(8, 3, T, 'TGASS', 0.5, conf_prop=True)
     m = NLPSN(8, 1, 3, 3, T, 'TGASS', 0.5, True, False).to(DEV)
     with torch.no_grad():
@@ -171,7 +176,8 @@ def test_config3_nlspn_18_steps_228x304_against_oracle():
     print(f'[nlspn 18 x 228x304] out max|err| {e_out:.2e}; grad rel L2: init {e_i:.2e} conf {e_c:.2e} guidance {e_g:.2e}; aff_scale_const {e_s:.2e}')
     # (the guidance conv runs on the f32 MFMA here and in torch on the host: offsets differ in the last bits, and where a sampling
     #  position sits within that of an integer the OFFSET gradient, which is discontinuous there, takes the other branch)
-    assert e_out < 2e-4 and e_i < 1e-3 and e_c < 1e-3 and e_g < 5e-3 and e_s < 2e-3
+    assert float((y_r.detach() - init).abs().max()) > 0.3, 'the propagation must move the map'
+    assert e_out < 1e-4 and e_i < 1e-3 and e_c < 2e-3 and e_g < 5e-3 and e_s < 2e-3
 
 
 def test_loss_kernel_against_reference_values(golden):
@@ -238,7 +244,7 @@ def test_build_model_with_the_dict_train_py_assembles():
     data['gt_normal'] = nA
     model.set_input(data)
     losses = model.optimize_parameters()
-    assert set(losses) >= {'loss_G', 'loss_D_A', 'loss_D_B', 'loss_G_A2B', 'loss_G_B2A', 'loss_cycle_A2B', 'loss_cycle_B2A', 'loss_A2B_L1'} and len(losses) == 13
+    assert set(losses) >= {'loss_G', 'loss_D_A', 'loss_D_B', 'loss_G_A2B', 'loss_G_B2A', 'loss_cycle_A', 'loss_cycle_B', 'loss_A2B_L1'} and len(losses) == 13
     assert all(isinstance(v, float) and np.isfinite(v) for v in losses.values())
     model.eval()
     out = model(rgb=data['rgb'], raw_depth=data['raw_depth'], gt_normal=data['gt_normal'])

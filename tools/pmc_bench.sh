@@ -26,8 +26,8 @@ for k, d in tot.items():
     if not nf or not nw: continue
     out[k] = dict(launches=nf, fetch_bytes=2.0 * 1024 * d['FETCH_SIZE'] / nf, write_bytes=1024.0 * d['WRITE_SIZE'] / nw)
 sys.path.insert(0, '.')
-from rdfc_gan_amd.build import source_hash
-out['_meta'] = dict(csrc_sha16=source_hash(), command='bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events ' + ' '.join(sys.argv[2:]),
+from rdfc_gan_amd import hip
+out['_meta'] = dict(csrc_sha16=hip.build_hash(),        # compiled into the library the passes above loaded command='bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events ' + ' '.join(sys.argv[2:]),
                     note='bytes per launch; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md); separate --pmc passes')
 json.dump(out, open(f'gpurun_out/{tag}_pmc_traffic.json', 'w'), indent=1, sort_keys=True)
 for k, v in sorted(((k, v) for k, v in out.items() if k != '_meta'), key=lambda kv: -kv[1]['launches'] * (kv[1]['fetch_bytes'] + kv[1]['write_bytes']))[:14]:

@@ -1,0 +1,65 @@
+"""A/B of the ring weight-gradient kernel (conv_wgrad_ring.hip, RDFC_WGRAD_RING=1) against conv_wgrad_glds.hip (=0) on the step's
+3x3 / stride-1 layers: interleaved rounds in ONE process (the switch is read per launch), random operands; the ring kernel's result
+must repeat bit for bit (fixed-order slab reduction) and agree with the other kernel to f32 summation-order accuracy.
+python tools/wgrad_ring_bench.py [rounds] [iters]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from rdfc_gan_amd import hip
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+SHAPES = [  # N, H, W, Ci, Co, pad, reflect
+    (16, 57, 76, 256, 256, 1, 0), (16, 29, 38, 512, 512, 1, 0), (16, 114, 152, 128, 128, 1, 0), (16, 228, 304, 64, 64, 1, 0),
+    (16, 228, 304, 128, 64, 1, 0), (16, 114, 152, 256, 128, 1, 0), (16, 57, 76, 256, 256, 1, 1), (3, 29, 38, 128, 192, 1, 0),
+    (2, 31, 45, 64, 128, 0, 0)]
+dtn = os.environ.get('PP_DTYPE', 'bf16')
+dt = dict(bf16=torch.bfloat16, f16=torch.float16)[dtn]
+
+
+def timed(fn):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+for (N, H, W, Ci, Co, pad, reflect) in SHAPES:
+    g = torch.Generator(device='cuda').manual_seed(1)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    x = torch.randn(N, H, W, Ci, device='cuda', generator=g).to(dt)
+    gy = torch.randn(N, Ho, Wo, Co, device='cuda', generator=g).to(dt)
+    d = hip.conv_desc(x.shape, Co, 3, 1, pad, ldx=Ci, ldy=Co, dtype=hip.dt(x))
+    outs, kern = {}, {}
+    for m in ('0', '1'):
+        os.environ['RDFC_WGRAD_RING'] = m
+        bad = 0
+        for rep in range(4):
+            dw = hip.conv_wgrad(d, x, gy, reflect=bool(reflect))
+            kern[m] = hip.lib().rdfc_last_kernel().decode()
+            if m not in outs:
+                outs[m] = dw
+            elif not torch.equal(outs[m], dw):
+                bad += 1
+        print(f'  RDFC_WGRAD_RING={m} ({kern[m]}): {bad} of 3 repeats differ from the first run')
+    a, b = outs['0'].double(), outs['1'].double()
+    rel = float((a - b).abs().max() / a.abs().max())
+    print(f'wgrad N{N} {H}x{W} {Ci}->{Co} pad{pad} reflect{reflect} [{dtn}]: max|ring - glds| / max|glds| = {rel:.2e} nan={int(torch.isnan(b).sum())}', flush=True)
+    fl = 2.0 * N * Ho * Wo * Co * Ci * 9
+    buf = torch.zeros(Co, 9, Ci, device='cuda')
+    res = {m: [] for m in ('0', '1')}
+    for r in range(rounds):
+        for m in ('0', '1'):
+            os.environ['RDFC_WGRAD_RING'] = m
+            res[m].append(timed(lambda: hip.conv_wgrad(d, x, gy, into=buf, reflect=bool(reflect))))
+    line = '  '
+    for m in ('0', '1'):
+        v = sorted(res[m])
+        med = v[len(v) // 2]
+        line += f'  RING={m}: median {med:7.1f} us (min {v[0]:7.1f}) {fl / med / 1e6:6.0f} TFLOP/s'
+    print(line, flush=True)
