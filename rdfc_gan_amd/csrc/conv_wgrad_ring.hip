@@ -1,7 +1,12 @@
-// conv_wgrad_ring.hip -- weight gradient of 3x3 / stride-1 convolutions (2-byte elements), LDS-DMA staging, flat pixel walk,
-// deterministic split-K (partial slabs + a fixed-order reduction instead of float atomics).
+// conv_wgrad_ring.hip -- weight gradient of 3x3 / 4x4 convolutions of stride 1 or 2 (2-byte elements), LDS-DMA staging, flat pixel
+// walk, deterministic split-K (partial slabs + a fixed-order reduction instead of float atomics).
 //
-//   dW[co][ky][kx][ci] += sum over output pixels m of dY[m][co] * X'[m + (ky, kx)][ci]        X' = X zero-padded by `pad`
+//   dW[co][ky][kx][ci] += sum over output pixels m of dY[m][co] * X'[m + (ky, kx)][ci]        X' = X zero-padded by `pad`   (stride 1)
+//
+// Stride 2 (the encoders' down-sampling 3x3 convs, the transposed decoder convs seen from their output, PatchGAN's 4x4 layers):
+// input column 2 x + kx - 1 = 2 (x + sx) + px, so tap kx reads column x + sx of the PARITY PLANE px of its input row -- within a
+// plane the taps are shifts of one flat sequence again.  A kernel row needs both planes: two X rings, each filled with a lane
+// stride of two pixels; taps (plane, shift): 3x3: (1,0) (0,1) (1,1); 4x4: (1,0) (0,1) (1,1) (0,2).
 //
 // GEMM view as conv_wgrad_glds.hip: M = co, N = (kx, ci), K = pixels; a workgroup (4 waves) owns one kernel row ky, a 128 | 64 co x
 // 64 ci tile and a slice of K.  What is different:
@@ -30,6 +35,7 @@ struct RParams {
     int total_steps, steps_per_slice, nslices;
     int tiles, tiles_ci, xcd_group;
     int reflect;
+    int xoff;                    // input column of flat column 0 of plane 0: -pad (stride 1), -2 (stride 2, pad 1: column 2 (j - 1))
 };
 
 constexpr int SEG = 32, NT = 256;
@@ -64,16 +70,21 @@ template <int ROWB, int MASK> __device__ inline bf16x8 tr_frag(const unsigned ch
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int TCO, int DT>
+// tap kx of a kernel row -> (parity plane, shift within the plane's flat sequence)
+template <int S> __device__ constexpr int tap_plane(int kx) { return S == 1 ? 0 : ((kx & 1) ^ 1); }
+template <int S> __device__ constexpr int tap_shift(int kx) { return S == 1 ? kx : (kx + 1) / 2; }
+
+template <int TCO, int DT, int S = 1, int K = 3>
 __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                                           float *__restrict__ slab, const bf16_t *__restrict__ zero) {
-    constexpr int TCI = 64, LOOK = 3, RY = LOOK + 1, XR = 8;
+    constexpr int TCI = 64, NPL = S;                            // X planes per kernel row
+    constexpr int LOOK = S == 1 ? 3 : 2, RY = LOOK + 1, XR = S == 1 ? 8 : 4;
     constexpr int YROW = TCO * 2, XROW = TCI * 2;               // bytes per pixel row of the two images
     constexpr int YB = SEG * YROW, XBLK = SEG * XROW;           // 8 | 4 KB per dY slot, 4 KB per X block
-    constexpr int NY = YB / (NT * 16), NX = XBLK / (NT * 16);   // DMAs per thread and k-step: dY 2 | 1, X 1
-    constexpr int PER_STEP = NY + NX;
+    constexpr int NY = YB / (NT * 16), NX = XBLK / (NT * 16);   // DMAs per thread and k-step: dY 2 | 1, X 1 per plane
+    constexpr int PER_STEP = NY + NPL * NX;
     constexpr int CPY = TCO / 8, CPX = TCI / 8;                 // 16-byte chunks per pixel
-    constexpr int OFF_X = RY * YB, XMASK = XR * SEG - 1;
+    constexpr int OFF_X = RY * YB, XRING = XR * XBLK, XMASK = XR * SEG - 1;
     constexpr int WCO = TCO / 64, WCI = 4 / WCO;                // waves along co / ci
     constexpr int WTCO = TCO / WCO, WTCI = TCI / WCI;           // wave tile: 64 co x (32 | 16) ci
     constexpr int MT = WTCO / 16, NTF = WTCI / 16;
@@ -89,8 +100,8 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
         slice = (k / p.tiles) * 8 + (blockIdx.x & 7);
     }
     if (slice >= p.nslices) return;
-    const int ky = tile % 3;
-    tile /= 3;
+    const int ky = tile % K;
+    tile /= K;
     const int ci0 = (tile % p.tiles_ci) * TCI, co0 = (tile / p.tiles_ci) * TCO;
     const int seg0 = slice * p.steps_per_slice;
     int nseg = p.total_steps - seg0;
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
         xgrp[k] = (k * NT + wave * 64) / CPX;
         const int px = xgrp[k] + xlp, slot = lane % CPX;
         xcol[k] = ci0 + ((slot ^ (2 * pair_swz<XROW>(px))) << 3);
-        xlane[k] = xlp * p.ldx + xcol[k];
+        xlane[k] = xlp * S * p.ldx + xcol[k];                   // (plane 1 adds one pixel: + ldx)
     }
 
     // ---- wave-uniform cursors of the next dY / X' block to issue, advanced incrementally (no multiply in the loop) ---------------
@@ -128,10 +139,10 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
         yx = y;
         imgx = img;
         ybase = dy + ((long)row * p.Wo + j) * p.ldy;
-        xbase = x + (((long)img * p.Hi + y + ky - p.pad) * p.Wi + (j - p.pad)) * p.ldx;
+        xbase = x + (((long)img * p.Hi + S * y + ky - p.pad) * p.Wi + (S * j + p.xoff)) * p.ldx;
     }
     const int ywrap = (p.Wo - p.L) * p.ldy;                       // element offsets added when a column wraps into the next row ...
-    const int xwrap = (p.Wi - p.L) * p.ldx, ximg = (p.Hi - p.Ho) * p.Wi * p.ldx;      // ... / the next image
+    const int xwrap = S * (p.Wi - p.L) * p.ldx, ximg = (p.Hi - S * p.Ho) * p.Wi * p.ldx;      // ... / the next image
     int ny_issued = 0, nx_issued = 0;                          // block indices of the next issues
     auto issue_y = [&]() {                                     // dY block ny_issued -> slot ny_issued % RY
         const bool live = ny_issued < nseg;
@@ -150,32 +161,34 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
         }
         ++ny_issued;
     };
-    auto issue_x = [&]() {                                     // X' block nx_issued -> ring block nx_issued % XR
-        const bool live = nx_issued <= nseg;                   // (one block beyond the last dY block: its first two positions are read)
+    auto issue_x = [&]() {                                     // X' block nx_issued (every plane) -> ring block nx_issued % XR
+        const bool live = nx_issued <= nseg;                   // (one block beyond the last dY block: its first positions are read)
         const unsigned blk = lds0 + OFF_X + (nx_issued % XR) * XBLK;
 #pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            int j = jx + xgrp[k], yy = yx, img = imgx, off = xgrp[k] * p.ldx;
-            if (j >= p.L) {
-                j -= p.L;
-                off += xwrap;
-                if (++yy == p.Ho) { yy = 0; ++img; off += ximg; }
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                int j = jx + xgrp[k], yy = yx, img = imgx, off = xgrp[k] * S * p.ldx + pl * p.ldx;
+                if (j >= p.L) {
+                    j -= p.L;
+                    off += xwrap;
+                    if (++yy == p.Ho) { yy = 0; ++img; off += ximg; }
+                }
+                int yin = S * yy + ky - p.pad;
+                int xin = S * (j + xlp) + p.xoff + pl;               // per lane
+                const bf16_t *src;
+                if (S == 1 && p.reflect) {                         // mirrored halo: row and column of the source follow the reflection
+                    yin = yin < 0 ? -yin : (yin >= p.Hi ? 2 * p.Hi - 2 - yin : yin);
+                    xin = xin < 0 ? -xin : (xin >= p.Wi ? 2 * p.Wi - 2 - xin : xin);
+                    src = x + (((long)img * p.Hi + yin) * p.Wi + xin) * p.ldx + xcol[k];
+                } else
+                    src = xbase + off + xlane[k];
+                const bool rowok = live && img < p.N && (unsigned)yin < (unsigned)p.Hi;
+                glds16(rowok && (unsigned)xin < (unsigned)p.Wi ? src : zero, blk + pl * XRING + (k * NT + wave * 64) * 16);
             }
-            int yin = yy + ky - p.pad;
-            int xin = j + xlp - p.pad;                             // per lane
-            const bf16_t *src;
-            if (p.reflect) {                                       // mirrored halo: row and column of the source follow the reflection
-                yin = yin < 0 ? -yin : (yin >= p.Hi ? 2 * p.Hi - 2 - yin : yin);
-                xin = xin < 0 ? -xin : (xin >= p.Wi ? 2 * p.Wi - 2 - xin : xin);
-                src = x + (((long)img * p.Hi + yin) * p.Wi + xin) * p.ldx + xcol[k];
-            } else
-                src = xbase + off + xlane[k];
-            const bool rowok = live && img < p.N && (unsigned)yin < (unsigned)p.Hi;
-            glds16(rowok && (unsigned)xin < (unsigned)p.Wi ? src : zero, blk + (k * NT + wave * 64) * 16);
-        }
         if (live) {
             jx += SEG;
-            xbase += SEG * p.ldx;
+            xbase += SEG * S * p.ldx;
             if (jx >= p.L) {
                 jx -= p.L;
                 xbase += xwrap;
@@ -186,9 +199,9 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
     };
 
     const int wr = wave / WCI, wc = wave % WCI;
-    f32x4 acc[3][MT][NTF];
+    f32x4 acc[K][MT][NTF];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < K; ++t)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -212,10 +225,11 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
             for (int i = 0; i < MT; ++i) a[i] = tr_frag<YROW, SEG - 1>(Ys, 0, wr * WTCO + 16 * i, lane);
             const int xrow0 = (s % XR) * SEG;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < K; ++t) {
                 bf16x8 b[NTF];
 #pragma unroll
-                for (int j = 0; j < NTF; ++j) b[j] = tr_frag<XROW, XMASK>(Xs, xrow0 + t, wc * WTCI + 16 * j, lane);
+                for (int j = 0; j < NTF; ++j)
+                    b[j] = tr_frag<XROW, XMASK>(Xs + tap_plane<S>(t) * XRING, xrow0 + tap_shift<S>(t), wc * WTCI + 16 * j, lane);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -226,9 +240,9 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
     }
 
     // ---- this slice's partial tile -> slab[slice][co][ky * 3 + t][ci] (row co = 4 * (lane >> 4) + r, column ci = lane & 15) -------------
-    float *out = slab + (size_t)slice * p.Co * 9 * p.Ci;
+    float *out = slab + (size_t)slice * p.Co * (K * K) * p.Ci;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < K; ++t)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + wr * WTCO + 16 * i + 4 * (lane >> 4) + r;
-                    if (co < p.Co && ci < p.Ci) out[((size_t)co * 9 + ky * 3 + t) * p.Ci + ci] = acc[t][i][j][r];
+                    if (co < p.Co && ci < p.Ci) out[((size_t)co * (K * K) + ky * K + t) * p.Ci + ci] = acc[t][i][j][r];
                 }
             }
 }
@@ -331,23 +345,24 @@ float *slab_for(hipStream_t st, size_t bytes) {
     return (float *)e->ptr;
 }
 
-template <int TCO, int DT>
+template <int TCO, int DT, int S, int K>
 int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
-    constexpr int SMEM = 4 * (SEG * TCO * 2) + 8 * (SEG * 64 * 2);
+    constexpr int RY = (S == 1 ? 3 : 2) + 1, XR = S == 1 ? 8 : 4;
+    constexpr int SMEM = RY * (SEG * TCO * 2) + S * XR * (SEG * 64 * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wgrad_ring_kernel<TCO, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)wgrad_ring_kernel<TCO, DT, S, K>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     p.tiles_ci = cdiv(p.Ci, 64);
-    const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * 3;
+    const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * K;
     // one round of the chip's workgroup slots (2 per CU with the 128-co tile, 3 with the 64-co one) within a slab budget: every
     // workgroup writes its tile once (plain stores) and the reduction reads it once
     static const int slots_env = getenv("RDFC_WGRAD_SLOTS") ? atoi(getenv("RDFC_WGRAD_SLOTS")) : 0;
     static const double cap_mb = getenv("RDFC_WGRAD_SLAB_MB") ? atof(getenv("RDFC_WGRAD_SLAB_MB")) : 64.0;
     const int slots = slots_env ? slots_env : (TCO == 64 ? 768 : 512);
     int slices = slots / tiles;
-    const size_t dw_bytes = (size_t)4 * p.Co * p.Ci * 9;
+    const size_t dw_bytes = (size_t)4 * p.Co * p.Ci * K * K;
     const int cap = (int)(cap_mb * 1.0e6 / (double)dw_bytes);
     if (slices > cap) slices = cap;
     if (slices > cdiv(p.total_steps, 8)) slices = cdiv(p.total_steps, 8);
@@ -359,13 +374,21 @@ int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *ze
     float *slab = slab_for(st, dw_bytes * slices);
     if (slab == nullptr) return 0;
     static const bool xcd_group = !(getenv("RDFC_WGRAD_XCD") && atoi(getenv("RDFC_WGRAD_XCD")) == 0);
-    p.xcd_group = xcd_group && tiles <= 3 && slices >= 8;
+    p.xcd_group = xcd_group && tiles <= 4 && slices >= 8;
     const dim3 grid = p.xcd_group ? dim3(cdiv(slices, 8) * 8 * tiles, 1) : dim3(slices, tiles);
-    rdfc_note_kernel("wgrad_ring_kernel<%d, %d>", TCO, DT);
-    hipLaunchKernelGGL((wgrad_ring_kernel<TCO, DT>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab, zero);
+    rdfc_note_kernel("wgrad_ring_kernel<%d, %d, %d, %d>", TCO, DT, S, K);
+    hipLaunchKernelGGL((wgrad_ring_kernel<TCO, DT, S, K>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab, zero);
     const size_t n4 = dw_bytes / 16;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float *)slab, dw, n4, slices);
     return 1;
+}
+
+template <int S, int K>
+int launch_sk(const rdfc_conv_desc *d, const RParams &p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
+    // 128-co tiles from 256 output channels up (as conv_wgrad_glds.hip: below that the 64-co tile's larger grid wins)
+    if (d->Co % 128 == 0 && d->Co >= 256)
+        return d->dtype == RDFC_F16 ? launch<128, RDFC_F16, S, K>(p, x, dy, dw, zero, st) : launch<128, RDFC_BF16, S, K>(p, x, dy, dw, zero, st);
+    return d->dtype == RDFC_F16 ? launch<64, RDFC_F16, S, K>(p, x, dy, dw, zero, st) : launch<64, RDFC_BF16, S, K>(p, x, dy, dw, zero, st);
 }
 
 }  // namespace
@@ -374,21 +397,30 @@ int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *ze
 // RDFC_WGRAD_RING=0 switches it off (A/B against the segment walk + float atomics).
 int rdfc_try_wgrad_ring(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st, int reflect) {
     const char *env_ = getenv("RDFC_WGRAD_RING");               // (read per call: tools/wgrad_ring_bench.py switches it between launches)
-    if (env_ != nullptr && atoi(env_) == 0) return 0;
-    if (!rdfc_is16(d->dtype)) return 0;
-    if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return 0;
-    if (d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return 0;
+    const int mode = env_ != nullptr ? atoi(env_) : 2;          // 0: off; 1: 3x3 / stride 1 only; 2 (default): also stride 2 and 4x4; 3: 2 without the size exceptions (tests)
+    if (mode == 0 || !rdfc_is16(d->dtype)) return 0;
+    const int S = d->sh, K = d->KH;
+    if (!(d->KH == d->KW && (K == 3 || K == 4) && d->sh == d->sw && (S == 1 || S == 2) && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return 0;
+    if ((S != 1 || K != 3) && (mode < 2 || d->ph != 1 || reflect)) return 0;
+    if (d->Ho != (d->Hi + 2 * d->ph - K) / S + 1 || d->Wo != (d->Wi + 2 * d->pw - K) / S + 1) return 0;
     if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8 || d->Wo < 24) return 0;
     if (((uintptr_t)dw & 15) != 0) return 0;
     if (reflect && (d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return 0;
-    const int L = (d->Wo + 2 + 7) / 8 * 8;
+    const int omax = S == 1 ? K - 1 : K / 2;                   // largest tap shift within a plane's flat sequence
+    int L = (d->Wo + omax + 7) / 8 * 8;
+    if (L < 32) L = 32;
     if ((double)d->N * d->Ho * L >= 2.0e9) return 0;
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
-    RParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, L < 32 ? 32 : L, d->N * d->Ho, 0, 0, 0, 0, 0, 0, reflect};
+    RParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, L, d->N * d->Ho, 0, 0, 0, 0, 0, 0, reflect, S == 1 ? -d->ph : -2};
     p.total_steps = cdiv((long)p.nrows * p.L, SEG);
-    // 128-co tiles from 256 output channels up (as conv_wgrad_glds.hip: below that the 64-co tile's larger grid wins)
-    if (d->Co % 128 == 0 && d->Co >= 256)
-        return d->dtype == RDFC_F16 ? launch<128, RDFC_F16>(p, x, dy, dw, zero, st) : launch<128, RDFC_BF16>(p, x, dy, dw, zero, st);
-    return d->dtype == RDFC_F16 ? launch<64, RDFC_F16>(p, x, dy, dw, zero, st) : launch<64, RDFC_BF16>(p, x, dy, dw, zero, st);
+    // Measured exceptions (profiles/r03_wgrad_ring_ab.txt): the 64-channel full-resolution inputs of the stride-2 layers (64 -> 128 / 192 from
+    // 16 x 228 x 304: every kernel row and co tile streams both parity planes of the 142 MB input again; the tap-gather kernel is
+    // 12-35 % faster there), and launches too small to pay for the second (reduction) launch.
+    if (mode < 3 && S == 2 && d->Ci < 128 && (double)d->N * d->Hi * d->Wi > 6.0e5) return 0;
+    if (mode < 3 && p.total_steps < 256) return 0;
+    if (S == 1 && K == 3) return launch_sk<1, 3>(d, p, x, dy, dw, zero, st);
+    if (S == 2 && K == 3) return launch_sk<2, 3>(d, p, x, dy, dw, zero, st);
+    if (S == 2 && K == 4) return launch_sk<2, 4>(d, p, x, dy, dw, zero, st);
+    return launch_sk<1, 4>(d, p, x, dy, dw, zero, st);
 }

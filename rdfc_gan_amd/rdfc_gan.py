@@ -436,6 +436,8 @@ class RDFCGAN:
         fB_cyc, self._fB_D, self._fB_L1 = Fh.fanout_flat(self.fake_B, 3)
         # G_B2A is InstanceNorm only: nothing in it couples the samples of a batch
         # (the marker's backward runs when G_B2A's backward has been enqueued: its gradient bucket starts its all-reduce then)
+        # (Round 3 tried the two passes un-stacked, G_B2A(real_B) enqueued first on the B->A stream beside G_A2B's forward:
+        #  210.9 / 211.5 pairs/s against 218.4 / 213.6 stacked -- more overlap does not buy time here)
         out = self.G_B2A(Fh.backward_marker(_stack2(self.real_B, fB_cyc), self._start_G_B2A_bucket))
         self.fake_A, self.rec_A = _SplitBatch.apply(out, B)
         self._fA_D, self._fA_L1 = Fh.fanout_flat(self.fake_A, 2)

@@ -63,22 +63,29 @@ def test_config5_480x640_batch4_f16_step_and_eval_forward():
     assert m.scaler is not None and m.scaler.skipped() == [0, 0] and m.scaler.scale() == 1024.0
     for o in m.optimizers.values():
         assert bool(torch.isfinite(o.flat).all())
-    # eval forward at 480x640 against the oracle: f16 storage, outputs in [-1, 1]
+    # eval forward at 480x640 against the oracle (outputs in [-1, 1]): the f32 parity mode pins the kernels at this size, f16 is
+    # the configuration's storage type (CPU simulation of f16 storage, tools/lowp_sim.py at this size: 5.7e-3 max, 7.4e-4 rms)
+    from rdfc_gan_amd import functional as Fh
+    from rdfc_gan_amd.generator import RDFGenerator
     ref = on.RDFGenerator()
     ref.load_state_dict(det_state_dict(ref.state_dict(), 0))
     ref.eval()
-    net = m.G_A2B
-    net.load_state_dict(det_state_dict(net.state_dict(), 0))
-    from rdfc_gan_amd import functional as Fh
-    Fh.invalidate_packed_weights()
-    net.eval()
     rgb, raw, normal = gen_inputs('cfg5', 1, 480, 640)
     with torch.no_grad():
         exp = ref(rgb, raw, normal)
-        got = net(rgb.to(DEV), raw.to(DEV), normal.to(DEV))
-    for k in ('pred_depth', 'depth_map_1', 'depth_map_2', 'confidence_map_1', 'confidence_map_2'):
-        e = (got[k].float().cpu() - exp[k]).abs()
-        assert float(e.max()) < 2e-2 and float(e.pow(2).mean().sqrt()) < 2e-3, (k, float(e.max()))      # (228x304, f16: 9.5e-3 max)
+    del m
+    torch.cuda.empty_cache()
+    for dtype, lim_max, lim_rms in ((torch.float32, 1e-4, 1e-5), (torch.float16, 2e-2, 2e-3)):
+        setup_dtype(dtype)
+        net = RDFGenerator(pretrained_on_imagenet=False)
+        net.load_state_dict(det_state_dict(net.state_dict(), 0))
+        net.to(DEV).eval()
+        with torch.no_grad():
+            got = net(rgb.to(DEV), raw.to(DEV), normal.to(DEV))
+        for k in ('pred_depth', 'depth_map_1', 'depth_map_2', 'confidence_map_1', 'confidence_map_2'):
+            e = (got[k].float().cpu() - exp[k]).abs()
+            print(f'[480x640 eval] {dtype} {k}: max {float(e.max()):.2e} rms {float(e.pow(2).mean().sqrt()):.2e}')
+            assert float(e.max()) < lim_max and float(e.pow(2).mean().sqrt()) < lim_rms, (dtype, k, float(e.max()))
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [
     ('RDFC_GLDS', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and bf16'),   # register-staged predecessors of the LDS-DMA 3x3 kernel
     ('RDFC_WGRAD_RING', '0', '(test_conv_fwd_dgrad_wgrad and not f32) or reflection_pad_folded'),   # segment walk + float atomics instead of the ring kernel
+    ('RDFC_WGRAD_RING', '3', '((test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32) or reflection_pad_folded'),   # the ring kernel also on launches the default leaves to the older kernels (small maps)
     ('RDFC_FUSED_STATS', '1', 'fused_statistics or stacked_batches'),               # conv-epilogue statistics (also under stacked-batch BatchNorm)
 ]
 

@@ -10,10 +10,16 @@ from rdfc_gan_amd import hip
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-SHAPES = [  # N, H, W, Ci, Co, pad, reflect
-    (16, 57, 76, 256, 256, 1, 0), (16, 29, 38, 512, 512, 1, 0), (16, 114, 152, 128, 128, 1, 0), (16, 228, 304, 64, 64, 1, 0),
-    (16, 228, 304, 128, 64, 1, 0), (16, 114, 152, 256, 128, 1, 0), (16, 57, 76, 256, 256, 1, 1), (3, 29, 38, 128, 192, 1, 0),
-    (2, 31, 45, 64, 128, 0, 0)]
+SHAPES = [  # N, H, W, Ci, Co, pad, reflect, kernel, stride
+    (16, 57, 76, 256, 256, 1, 0, 3, 1), (16, 29, 38, 512, 512, 1, 0, 3, 1), (16, 114, 152, 128, 128, 1, 0, 3, 1), (16, 228, 304, 64, 64, 1, 0, 3, 1),
+    (16, 228, 304, 128, 64, 1, 0, 3, 1), (16, 114, 152, 256, 128, 1, 0, 3, 1), (16, 57, 76, 256, 256, 1, 1, 3, 1), (3, 29, 38, 128, 192, 1, 0, 3, 1),
+    (2, 31, 45, 64, 128, 0, 0, 3, 1),
+    # stride 2 / 4x4 (the encoders' down-sampling convs, the transposed decoder convs seen from their output, PatchGAN)
+    (16, 114, 152, 128, 256, 1, 0, 3, 2), (16, 228, 304, 64, 128, 1, 0, 3, 2), (16, 228, 304, 64, 192, 1, 0, 3, 2), (16, 57, 76, 256, 512, 1, 0, 3, 2),
+    (16, 58, 76, 128, 768, 1, 0, 3, 2), (16, 114, 152, 64, 384, 1, 0, 3, 2), (16, 114, 152, 64, 128, 1, 0, 4, 2), (16, 57, 76, 128, 256, 1, 0, 4, 2),
+    (16, 28, 38, 256, 512, 1, 0, 4, 1), (3, 31, 61, 64, 128, 1, 0, 4, 2), (2, 33, 59, 128, 64, 1, 0, 3, 2)]
+if len(sys.argv) > 3:
+    SHAPES = [sh for sh in SHAPES if (sh[7], sh[8]) == tuple(int(v) for v in sys.argv[3].split(','))]
 dtn = os.environ.get('PP_DTYPE', 'bf16')
 dt = dict(bf16=torch.bfloat16, f16=torch.float16)[dtn]
 
@@ -29,14 +35,14 @@ def timed(fn):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-for (N, H, W, Ci, Co, pad, reflect) in SHAPES:
+for (N, H, W, Ci, Co, pad, reflect, ksz, st) in SHAPES:
     g = torch.Generator(device='cuda').manual_seed(1)
-    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    Ho, Wo = (H + 2 * pad - ksz) // st + 1, (W + 2 * pad - ksz) // st + 1
     x = torch.randn(N, H, W, Ci, device='cuda', generator=g).to(dt)
     gy = torch.randn(N, Ho, Wo, Co, device='cuda', generator=g).to(dt)
-    d = hip.conv_desc(x.shape, Co, 3, 1, pad, ldx=Ci, ldy=Co, dtype=hip.dt(x))
+    d = hip.conv_desc(x.shape, Co, ksz, st, pad, ldx=Ci, ldy=Co, dtype=hip.dt(x))
     outs, kern = {}, {}
-    for m in ('0', '1'):
+    for m in ('0', '3'):
         os.environ['RDFC_WGRAD_RING'] = m
         bad = 0
         for rep in range(4):
@@ -47,18 +53,18 @@ for (N, H, W, Ci, Co, pad, reflect) in SHAPES:
             elif not torch.equal(outs[m], dw):
                 bad += 1
         print(f'  RDFC_WGRAD_RING={m} ({kern[m]}): {bad} of 3 repeats differ from the first run')
-    a, b = outs['0'].double(), outs['1'].double()
+    a, b = outs['0'].double(), outs['3'].double()
     rel = float((a - b).abs().max() / a.abs().max())
-    print(f'wgrad N{N} {H}x{W} {Ci}->{Co} pad{pad} reflect{reflect} [{dtn}]: max|ring - glds| / max|glds| = {rel:.2e} nan={int(torch.isnan(b).sum())}', flush=True)
-    fl = 2.0 * N * Ho * Wo * Co * Ci * 9
-    buf = torch.zeros(Co, 9, Ci, device='cuda')
-    res = {m: [] for m in ('0', '1')}
+    print(f'wgrad N{N} {H}x{W} {Ci}->{Co} k{ksz}s{st} pad{pad} reflect{reflect} [{dtn}]: max|ring - glds| / max|glds| = {rel:.2e} nan={int(torch.isnan(b).sum())}', flush=True)
+    fl = 2.0 * N * Ho * Wo * Co * Ci * ksz * ksz
+    buf = torch.zeros(Co, ksz * ksz, Ci, device='cuda')
+    res = {m: [] for m in ('0', '3')}
     for r in range(rounds):
-        for m in ('0', '1'):
+        for m in ('0', '3'):
             os.environ['RDFC_WGRAD_RING'] = m
             res[m].append(timed(lambda: hip.conv_wgrad(d, x, gy, into=buf, reflect=bool(reflect))))
     line = '  '
-    for m in ('0', '1'):
+    for m in ('0', '3'):
         v = sorted(res[m])
         med = v[len(v) // 2]
         line += f'  RING={m}: median {med:7.1f} us (min {v[0]:7.1f}) {fl / med / 1e6:6.0f} TFLOP/s'
