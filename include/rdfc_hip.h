@@ -184,8 +184,9 @@ int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *mean, const
                          void *stream);
 /* sums[G][3][C] from the partials (fixed order => deterministic). */
 int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, int P, int C, int dtype, void *stream);
-/* Same; additionally dbeta_acc[C] += sum du and dgamma_acc[C] += sum du*xhat over every group (either may be NULL):
- * the affine gradients of a BatchNorm land in the parameters' persistent .grad without an autograd add each. */
+/* Same; additionally dbeta_acc[C] += sum du and dgamma_acc[C] += sum du*xhat (either may be NULL; G == 1 only): the affine
+ * gradients of a BatchNorm land in the parameters' persistent .grad without an autograd add each.  With several statistics groups
+ * (BatchNorm over stacked batches) use rdfc_norm_backward: its apply pass adds the groups' sums in group order (reproducible). */
 int rdfc_norm_bwd_finalize_acc(const float *partial, float *sums, int G, int P, int C, int dtype, float *dbeta_acc,
                                float *dgamma_acc, void *stream);
 /* backward pass 2: dx = gamma*rstd*(du - S1/P - xhat*S2/P) (training) or gamma*rstd*du (frozen stats);

@@ -404,7 +404,6 @@ int rdfc_try_wgrad_ring(const rdfc_conv_desc *d, const void *x, const void *dy, 
     if ((S != 1 || K != 3) && (mode < 2 || d->ph != 1 || reflect)) return 0;
     if (d->Ho != (d->Hi + 2 * d->ph - K) / S + 1 || d->Wo != (d->Wi + 2 * d->pw - K) / S + 1) return 0;
     if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8 || d->Wo < 24) return 0;
-    if (((uintptr_t)dw & 15) != 0) return 0;
     if (reflect && (d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return 0;
     const int omax = S == 1 ? K - 1 : K / 2;                   // largest tap shift within a plane's flat sequence
     int L = (d->Wo + omax + 7) / 8 * 8;

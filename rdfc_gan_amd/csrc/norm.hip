@@ -376,22 +376,14 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
 __global__ __launch_bounds__(FNT) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
                                                           float *__restrict__ sums, float *__restrict__ acc0, float *__restrict__ acc1) {
     __shared__ double red[FL * 32];
-    // grid.y = K: this workgroup walks the G groups in order (accumulating launches); grid.y = G * K: one (group, sum) each
-    const bool walk = (int)gridDim.y == K;
-    const int k = walk ? (int)blockIdx.y : (int)blockIdx.y % K, c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int g0 = walk ? 0 : (int)blockIdx.y / K, g1 = walk ? G : g0 + 1;
-    // optional in-place accumulation of sum 0 / sum 1 (d beta / d gamma of an affine norm): the G groups (BatchNorm over stacked
-    // batches) are added in group order by ONE thread and leave as one add per channel -- reproducible; that add is atomic because
-    // the same parameter's two uses per step may run their backward on different streams (unbatched schedule)
-    double total = 0;
-    for (int g = g0; g < g1; ++g) {
-        const double s = chunk_sum(partial, g, K, k, C, c, nchunk, red);
-        if (threadIdx.x < 32 && c < C) sums[((size_t)g * K + k) * C + c] = (float)s;
-        total += (double)(float)s;
-    }
+    const int g = blockIdx.y / K, k = blockIdx.y % K, c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const double s = chunk_sum(partial, g, K, k, C, c, nchunk, red);
     if (threadIdx.x < 32 && c < C) {
-        if (k == 0 && acc0 != nullptr) atomicAdd(&acc0[c], (float)total);
-        if (k == 1 && acc1 != nullptr) atomicAdd(&acc1[c], (float)total);
+        sums[((size_t)g * K + k) * C + c] = (float)s;
+        // optional in-place accumulation of sum 0 / sum 1 (a bias gradient: ONE group, so one add per channel and launch; atomic
+        // because the same parameter's two uses per step may run their backward on different streams)
+        if (k == 0 && acc0 != nullptr) atomicAdd(&acc0[c], (float)s);
+        if (k == 1 && acc1 != nullptr) atomicAdd(&acc1[c], (float)s);
     }
 }
 
@@ -399,10 +391,27 @@ template <typename T>
 __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
                                                        const T *__restrict__ res, const float *__restrict__ sums,
                                                        T *__restrict__ dx, T *__restrict__ dres, int lddz, int ldx, int ldr,
-                                                       int lddx, int lddr, int frozen) {
+                                                       int lddx, int lddr, int frozen, float *__restrict__ dbeta_acc,
+                                                       float *__restrict__ dgamma_acc) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     if (!cx.active) return;
+    // d beta / d gamma of an affine norm straight into their .grad: ONE thread per channel adds the groups' sums (BatchNorm over
+    // stacked batches has one set per group) in group order and issues one add -- reproducible whatever the launch order of the
+    // workgroups; the add is atomic because a parameter's two uses per step may run their backward on different streams
+    if (dbeta_acc != nullptr && cx.chunk == 0 && cx.r0 == 0 && cx.g == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int c = cx.c0 + v;
+            float tb = 0.f, tg = 0.f;
+            for (int g = 0; g < m.G; ++g) {
+                tb += sums[(g * 3 + 0) * m.C + c];
+                tg += sums[(g * 3 + 1) * m.C + c];
+            }
+            atomicAdd(&dbeta_acc[c], tb);
+            if (dgamma_acc != nullptr) atomicAdd(&dgamma_acc[c], tg);
+        }
+    }
     float ga[VEC], sc[VEC], sh[VEC], mu[VEC], rs[VEC], m1[VEC], m2[VEC];
     const float invP = 1.f / (float)m.P;
     float bev[VEC], s1v[VEC], s2v[VEC];
@@ -682,9 +691,9 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
 
 extern "C" int rdfc_norm_bwd_finalize_acc(const float *partial, float *sums, int G, int P, int C, int dtype, float *dbeta_acc,
                                           float *dgamma_acc, void *stream) {
-    // (G > 1 with accumulators: BatchNorm over G stacked batches -- the groups' sums are added in group order)
-    const bool acc = dbeta_acc != nullptr || dgamma_acc != nullptr;
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), acc ? 3 : G * 3), dim3(FNT), 0, (hipStream_t)stream, G, C, 3,
+    // in-place accumulation from here: one statistics group only (several groups: rdfc_norm_backward adds them in group order)
+    RDFC_REQUIRE(G == 1 || (dbeta_acc == nullptr && dgamma_acc == nullptr), "rdfc_norm_bwd_finalize_acc: accumulators need G == 1");
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), G * 3), dim3(FNT), 0, (hipStream_t)stream, G, C, 3,
                        cdiv(P, chunk_pixels(P, C, rdfc_vec(dtype))), partial, sums, dbeta_acc, dgamma_acc);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_finalize");
     return 0;
@@ -702,7 +711,7 @@ extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *m
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
-                                       lddx, lddr, frozen_stats));
+                                       lddx, lddr, frozen_stats, (float *)nullptr, (float *)nullptr));
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_apply");
     return 0;
 }
@@ -735,9 +744,18 @@ extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *me
     if (int e = rdfc_norm_bwd_reduce(dz, x, mean, rstd, gamma, beta, res, scratch, G, P, C, lddz, ldx, ldr, dtype, act, slope, prelu,
                                      stream))
         return e;
-    if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, dbeta_acc, dgamma_acc, stream)) return e;
-    return rdfc_norm_bwd_apply(dz, x, mean, rstd, gamma, beta, res, sums, dx, dres, G, P, C, lddz, ldx, ldr, lddx, lddr, dtype, act,
-                               slope, prelu, frozen_stats, stream);
+    if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, nullptr, nullptr, stream)) return e;
+    // (the affine gradients are accumulated by the apply pass, which reads the sums anyway: the groups in group order, no extra
+    //  launch, and the finalize stays one small workgroup per (group, sum, 32 channels))
+    if (int e = check_map("rdfc_norm_backward", G, P, C, dtype, {lddz, ldx, lddx})) return e;
+    RDFC_REQUIRE(dbeta_acc != nullptr || dgamma_acc == nullptr, "rdfc_norm_backward: d gamma accumulates together with d beta");
+    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
+    ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
+    DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
+                                       (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
+                                       lddx, lddr, frozen_stats, dbeta_acc, dgamma_acc));
+    RDFC_LAUNCH_CHECK("rdfc_norm_backward");
+    return 0;
 }
 
 extern "C" int rdfc_adain_apply(const void *x, const float *mean, const float *rstd, const void *gb, void *out, int N, int P,

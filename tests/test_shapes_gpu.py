@@ -73,7 +73,15 @@ def test_config5_480x640_batch4_f16_step_and_eval_forward():
     rgb, raw, normal = gen_inputs('cfg5', 1, 480, 640)
     with torch.no_grad():
         exp = ref(rgb, raw, normal)
-    del m
+    # ... first through the modules that have just trained (upstream's validation flow: load weights, eval(), forward)
+    m.G_A2B.load_state_dict(det_state_dict(m.G_A2B.state_dict(), 0))
+    Fh.invalidate_packed_weights()
+    m.eval()
+    got = m(rgb=rgb, raw_depth=raw, gt_normal=normal)
+    e = (got['pred_depth'].float().cpu() - exp['pred_depth']).abs()
+    print(f'[480x640 eval] f16, trained modules reloaded: pred_depth max {float(e.max()):.2e} rms {float(e.pow(2).mean().sqrt()):.2e}')
+    assert float(e.max()) < 2e-2 and float(e.pow(2).mean().sqrt()) < 2e-3
+    del m, got
     torch.cuda.empty_cache()
     for dtype, lim_max, lim_rms in ((torch.float32, 1e-4, 1e-5), (torch.float16, 2e-2, 2e-3)):
         setup_dtype(dtype)
@@ -258,3 +266,38 @@ def test_build_model_with_the_dict_train_py_assembles():
     assert tuple(out['pred_depth'].shape) == (2, 1, 60, 76)
     with pytest.raises(KeyError):
         build_model(dict(model_cfg, type='NoSuchModel'))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+def test_eval_forward_after_training_steps_and_checkpoint_load(dtype):
+    """train.py's flow: optimise (parameters live in FlatAdam's flat buffers, conv weights channels-last, packed operands rebuilt
+    in one launch per step), then load a checkpoint's state_dict into the SAME modules, switch to eval() and run the validation
+    forward.  The eval outputs must be those of the oracle on the loaded weights -- nothing of the training steps (packed
+    operands, BatchNorm bookkeeping, stacked-batch settings) may leak into it."""
+    from oracle import nets as on
+    from rdfc_gan_amd import functional as Fh
+    from rdfc_gan_amd.rdfc_gan import RDFCGAN
+    setup_dtype(dtype)
+    m = RDFCGAN(torch.device(DEV), False, _cfg(), is_train=True)
+    m.train()
+    for it in range(2):
+        losses = _one_step(m, 2, 60, 76, seed=it)
+        assert all(np.isfinite(v) for v in losses.values())
+    sd = det_state_dict(m.G_A2B.state_dict(), 3)
+    m.G_A2B.load_state_dict(sd)
+    Fh.invalidate_packed_weights()
+    m.eval()
+    ref = on.RDFGenerator()
+    ref.load_state_dict(sd)
+    ref.eval()
+    rgb, raw, normal = gen_inputs('after_train', 2, 60, 76)
+    with torch.no_grad():
+        exp = ref(rgb, raw, normal)['pred_depth']
+    got = m(rgb=rgb, raw_depth=raw, gt_normal=normal)['pred_depth'].float().cpu()
+    e = float((got - exp).abs().max())
+    print(f'[eval after training] {dtype}: max|err| {e:.2e}')
+    assert e < (5e-5 if dtype == torch.float32 else 2e-2), e
+    # and training goes on from the loaded weights
+    m.train()
+    losses = _one_step(m, 2, 60, 76, seed=5)
+    assert all(np.isfinite(v) for v in losses.values())

@@ -14,7 +14,7 @@ rows = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Na
                 int(r.get('Workgroup_Size_X', r.get('Workgroup_Size', 1)) or 1) * int(r.get('Workgroup_Size_Y', 1) or 1) * int(r.get('Workgroup_Size_Z', 1) or 1))
                for r in R), key=lambda r: r[0])
 # steady state: find adam_kernel launches -> step boundaries
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[2]]
+adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[2] or 'adam_scaled_kernel' in r[2]]
 # two adam launches per step (G, D): take the steps between the 4th-last pair and the last pair
 ends = adam[1::2]
 a, b = ends[-4], ends[-1]
@@ -54,6 +54,12 @@ for k, v in alone.most_common(30):
 per = collections.Counter()
 for s, e, k, st, *_ in rows: per[st] += e - s
 print('kernel time per stream (ms/step):', {k: round(v/nsteps/1e6, 1) for k, v in per.most_common()})
+fam = collections.defaultdict(collections.Counter)
+for s, e, k, st, *_ in rows: fam[st][short(k)[:44]] += e - s
+for st, _v in per.most_common():
+    print(f'stream {st}: kernel time by kernel (ms/step)')
+    for k, v in fam[st].most_common(14):
+        print(f'   {v/nsteps/1e6:7.3f}  {k}')
 # per-millisecond picture of the LAST step: busy fraction of every stream and the kernel with the most time in the bin
 a2, b2 = ends[-2], ends[-1]
 last_rows = [r for r in rows if r[0] >= rows[0][0]][-(b2 - a2):]
