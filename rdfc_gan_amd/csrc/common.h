@@ -177,3 +177,13 @@ __device__ inline float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
+
+// The wait in front of the raw barrier of an LDS-DMA pipeline step: all but this wave's N youngest vector-memory operations are done
+// (its share of the DMAs the coming step reads has landed) AND every LDS read it has issued has RETURNED.  The second half is the
+// write-after-read side of a ring: the slot (or patch buffer) read in step s is refilled by DMAs any wave issues as soon as it is past
+// the barrier of step s + 1, so arriving at that barrier must mean "my reads of step s are complete", not "issued".  hipcc sinks
+// the last fragment reads of a step and their MFMAs below the next barrier when that saves registers (its own lgkmcnt wait then
+// lands after the barrier); with a CU's LDS queue full -- three workgroups of the kernel beside another stream's kernel, 480x640
+// maps -- such a read returned bytes of a later step: rare wrong half-tiles that came and went run to run (found by
+// tools/rerun_check.py in round 3; every LDS-DMA kernel of this library had the same one-step distance).
+template <int N> __device__ inline void wait_vm_and_reads() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     {                                                                                                          \
         constexpr int ALLOW = (WLOOK - 1) * NWP + (WLOOK >= 3 && ((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0); \
         RDFC_STAMP(TAP, 0)                                                                                     \
-        wait_vm<ALLOW>();                                                                                      \
+        wait_vm_and_reads<ALLOW>();                                                                            \
         RDFC_STAMP(TAP, 1)                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                          \
         RDFC_STAMP(TAP, 2)                                                                                     \

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
         const unsigned a_off = (unsigned)((arow << 6) | (kg << 4)) ^ (unsigned)((arow & 4) << 3);     // rows + 16 i share bit 2
         const unsigned b_off = AB + ((unsigned)((brow << 6) | (kg << 4)) ^ (unsigned)((brow & 4) << 3));
         for (int g = 0; g < G; ++g) {
-            wait_vm<(LOOK - 1) * (NA + NB)>();                  // the K-steps after g that are already issued may stay in flight
+            wait_vm_and_reads<(LOOK - 1) * (NA + NB)>();                  // the K-steps after g that are already issued may stay in flight
             __builtin_amdgcn_s_barrier();
             issue(g + LOOK);                                    // its slot was last read in step g - 1: every wave is past the barrier
             const unsigned char *S = smem + (g % RING) * SLOT;

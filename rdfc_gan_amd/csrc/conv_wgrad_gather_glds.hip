@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gather_glds_kernel(WGParams p, co
 #pragma unroll
     for (int h = 0; h < LOOK; ++h) issue(h);
     for (int s = 0; s < nseg; ++s) {
-        wait_vm<(LOOK - 1) * PER_STEP>();
+        wait_vm_and_reads<(LOOK - 1) * PER_STEP>();
         __builtin_amdgcn_s_barrier();
         issue(s + LOOK);
         const unsigned char *Ys = smem + (s % RING) * SLOT, *Xs = Ys + YB;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParam
 #pragma unroll
     for (int h = 0; h < WG_RING - 1; ++h) issue(h);
     for (int s = 0; s < nseg; ++s) {
-        wait_vm<(WG_RING - 2) * PER_STEP>();                    // the k-steps after s that are already issued may stay in flight
+        wait_vm_and_reads<(WG_RING - 2) * PER_STEP>();                    // the k-steps after s that are already issued may stay in flight
         __builtin_amdgcn_s_barrier();
         issue(s + WG_RING - 1);                                 // the slot of k-step s-1: every wave is past its reads (barrier)
         const unsigned char *Ys = smem + (s % WG_RING) * SLOT, *Xs = Ys + YB;

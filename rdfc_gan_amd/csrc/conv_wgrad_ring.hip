@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
             issue_x();
         }
         for (int s = 0; s < nseg; ++s) {
-            wait_vm<(LOOK - 1) * PER_STEP>();                    // everything issued up to step s - LOOK has landed: dY(s), X'(s), X'(s+1)
+            wait_vm_and_reads<(LOOK - 1) * PER_STEP>();                    // everything issued up to step s - LOOK has landed: dY(s), X'(s), X'(s+1)
             __builtin_amdgcn_s_barrier();
             issue_y();                                           // dY(s + LOOK) -> the slot of step s - 1; X'(s + LOOK + 1) -> block s + LOOK + 1 - XR <= s - 1
             issue_x();

@@ -96,6 +96,30 @@ def test_config5_480x640_batch4_f16_step_and_eval_forward():
             assert float(e.max()) < lim_max and float(e.pow(2).mean().sqrt()) < lim_rms, (dtype, k, float(e.max()))
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['f16', 'bf16'])
+def test_eval_forward_480x640_is_reproducible_run_to_run(dtype):
+    """Regression (round 3): with the two branches of G_A2B on two streams and 480x640 maps (more workgroups than the chip holds,
+    two kernels sharing every CU's LDS queue) the LDS-DMA kernels returned rare wrong half-tiles, different from run to run: a ring
+    slot was refilled while a late fragment read of the previous step was still queued (common.h: wait_vm_and_reads).  The forward
+    has no atomics: ten runs on the same weights and inputs must agree bit for bit."""
+    from rdfc_gan_amd.generator import RDFGenerator
+    setup_dtype(dtype)
+    net = RDFGenerator(pretrained_on_imagenet=False)
+    net.load_state_dict(det_state_dict(net.state_dict(), 0))
+    net.to(DEV).eval()
+    inputs = [t.to(DEV) for t in gen_inputs('cfg5', 1, 480, 640)]
+    first = None
+    for r in range(10):
+        with torch.no_grad():
+            out = {k: v.clone() for k, v in net(*inputs).items()}
+        torch.cuda.synchronize()
+        if first is None:
+            first = out
+            continue
+        for k in out:
+            assert torch.equal(out[k], first[k]), (r, k, float((out[k].float() - first[k].float()).abs().max()))
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
 def test_config2_batch8_step_is_finite(dtype):
     """the benchmark's launch sizes (16 stacked samples per pass at 228x304) in both 16-bit modes: two steps, finite losses and weights"""
