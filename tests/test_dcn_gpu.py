@@ -21,7 +21,7 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
 
 def rel_err(got, ref):
     got, ref = got.double().cpu(), ref.double().cpu()
-    return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+    return float((got.detach() - ref.detach()).abs().max() / (ref.detach().abs().max() + 1e-12))
 
 
 # B, C, H, W, Co, k, stride, pad, dil, groups, deformable groups

@@ -120,22 +120,42 @@ def test_eval_forward_480x640_is_reproducible_run_to_run(dtype):
             assert torch.equal(out[k], first[k]), (r, k, float((out[k].float() - first[k].float()).abs().max()))
 
 
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
-def test_config2_batch8_step_is_finite(dtype):
-    """the benchmark's launch sizes (16 stacked samples per pass at 228x304) in both 16-bit modes: two steps, finite losses and weights"""
+_F32_STEPS = {}
+
+
+def _two_steps(dtype):
+    """losses of two optimisation steps at the benchmark's launch sizes (batch 8 at 228x304, fixed weights and batches)"""
     from rdfc_gan_amd.rdfc_gan import RDFCGAN
     setup_dtype(dtype)
     m = RDFCGAN(torch.device(DEV), False, _cfg(), is_train=True)
     _load_det(m)
     m.train()
     assert m._batched()
-    for it in range(2):
-        losses = _one_step(m, 8, 228, 304, seed=it)
-        assert all(np.isfinite(v) for v in losses.values()), (it, losses)
+    out = [_one_step(m, 8, 228, 304, seed=it) for it in range(2)]
     for o in m.optimizers.values():
         assert bool(torch.isfinite(o.flat).all())
     if m.scaler is not None:
         assert m.scaler.skipped() == [0, 0]
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_config2_batch8_steps_follow_the_f32_mode(dtype):
+    """the benchmark's launch sizes (16 stacked samples per pass at 228x304) in both 16-bit modes: two steps with finite losses
+    and weights, no skipped update -- and every loss within the storage format's reach of the f32 parity mode's on the same
+    weights and batches (step 1: the forward at this size; step 2: after one backward + Adam update at this size)."""
+    if 'f32' not in _F32_STEPS:
+        _F32_STEPS['f32'] = _two_steps(torch.float32)
+    ref, got = _F32_STEPS['f32'], _two_steps(dtype)
+    rtol = {torch.float16: (1e-3, 1.5e-2), torch.bfloat16: (1e-2, 4e-2)}[dtype]          # measured: 1.3e-4, 3.0e-3 | 2.2e-3, 1.0e-2
+    for it in range(2):
+        assert all(np.isfinite(v) for v in got[it].values()), (it, got[it])
+        dev = {k: abs(got[it][k] - ref[it][k]) / max(abs(ref[it][k]), 1e-2) for k in ref[it]}
+        worst = max(dev, key=dev.get)
+        print(f'[batch 8, {dtype}] step {it + 1}: worst loss deviation from the f32 mode {dev[worst]:.2e} ({worst}: {got[it][worst]:.5f} vs {ref[it][worst]:.5f})')
+        assert dev[worst] <= rtol[it], (it, worst, got[it][worst], ref[it][worst])
 
 
 def test_config2_batch8_batched_schedule_equals_unbatched_f32():
