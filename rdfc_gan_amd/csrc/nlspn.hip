@@ -93,6 +93,22 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(Geo g, const float *__rest
     const size_t HW = (size_t)H * W;
     const int wy0 = y0 - 1 - R, wx0 = x0 - 1 - R;
     const float *im = in + (size_t)b * HW;
+    // the pixel's 27 coefficients first, the window of the map after them: both fetches are in flight together (with the window
+    // load and its barrier in front, a step was two memory latencies back to back)
+    float hi[PPT][NTAP], wi[PPT][NTAP], cf[PPT][NTAP];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int pix = threadIdx.x + q * NT, h = y0 + pix / TW, w = x0 + pix % TW;
+        const bool live = h < H && w < W;
+        const size_t p = live ? (size_t)h * W + w : 0;
+        const float *o = off + (size_t)b * 2 * NTAP * HW + p, *m = aff + (size_t)b * NTAP * HW + p;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            hi[q][t] = h - 1 + t / 3 + o[(size_t)(2 * t) * HW];
+            wi[q][t] = w - 1 + t % 3 + o[(size_t)(2 * t + 1) * HW];
+            cf[q][t] = wt[t] * m[(size_t)t * HW];
+        }
+    }
     load_window(win, im, wy0, wx0, H, W);
     __syncthreads();
     const float b0 = bias ? bias[0] : 0.f;
@@ -100,21 +116,17 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(Geo g, const float *__rest
     for (int q = 0; q < PPT; ++q) {
         const int pix = threadIdx.x + q * NT, h = y0 + pix / TW, w = x0 + pix % TW;
         if (h >= H || w >= W) continue;
-        const size_t p = (size_t)h * W + w;
-        const float *o = off + (size_t)b * 2 * NTAP * HW + p, *m = aff + (size_t)b * NTAP * HW + p;
         float acc = b0;
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
-            const float hi = h - 1 + t / 3 + o[(size_t)(2 * t) * HW], wi = w - 1 + t % 3 + o[(size_t)(2 * t + 1) * HW];
-            const float a_t = m[(size_t)t * HW];
-            if (inside(hi, wi, H, W)) {
-                const Smp c = sample(hi, wi, H, W);
+            if (inside(hi[q][t], wi[q][t], H, W)) {
+                const Smp c = sample(hi[q][t], wi[q][t], H, W);
                 float a, bb, d, e;
                 corners(c, win, wy0, wx0, im, W, a, bb, d, e);
-                acc += wt[t] * a_t * bilin(c, a, bb, d, e);
+                acc += cf[q][t] * bilin(c, a, bb, d, e);
             }
         }
-        out[(size_t)b * HW + p] = acc;
+        out[(size_t)b * HW + (size_t)h * W + w] = acc;
     }
 }
 
@@ -207,70 +219,88 @@ __global__ __launch_bounds__(NT) void prop_bwd_feat_kernel(Geo g, const float *_
 // ---- gradients of offsets / affinities, summed over the T steps --------------------------------------------------------
 // feats[i] = input map of step i + 1 (i = 0 .. T-1), gouts[i] = cotangent of that step's output; both [T][B][H][W]
 // (feats may have a larger stride between steps: the buffer also holds the final map).
-// (512 threads, one pixel each: 54 live values per pixel -- two pixels per thread needed 498 registers, one wave per SIMD)
-constexpr int CNT = TH * TW;
+// One pixel per thread, THREE TAPS per workgroup (blockIdx.y = tap group): the sampling geometry of a tap is the same for every
+// step, so a thread keeps it (position, bilinear weights, window address: ~10 values per tap) beside the tap's three sums; with
+// all nine taps in one thread that was 256 registers and spills at two waves per SIMD (606 us in the step for a pass over
+// 250 MB).  The T saved maps stream through a double-buffered LDS window: the next step's window is fetched into registers before
+// the current step's arithmetic and deposited after it, one barrier per step.
+constexpr int CNT = TH * TW, TG = 3, NGRP = NTAP / TG;
+constexpr int NS = (WN + CNT - 1) / CNT;              // window cells staged per thread (3)
 __global__ __launch_bounds__(CNT) void prop_bwd_coeff_kernel(Geo g, int T, const float *__restrict__ feats, size_t feat_stride,
                                                             const float *__restrict__ gouts, size_t gout_stride,
                                                             const float *__restrict__ off, const float *__restrict__ aff,
                                                             const float *__restrict__ wt, float *__restrict__ goff,
                                                             float *__restrict__ gaff) {
-    __shared__ float win[WN];
+    __shared__ float win[2][WN];
     int b, y0, x0;
     tile_of(g, b, y0, x0);
-    const int H = g.H, W = g.W;
+    const int H = g.H, W = g.W, t0 = (int)blockIdx.y * TG;
     const size_t HW = (size_t)H * W;
     const int wy0 = y0 - 1 - R, wx0 = x0 - 1 - R;
-    // per pixel: the sampling geometry is the same for every step -- keep it, and the 27 sums, in registers
-    float hi[1][NTAP], wi[1][NTAP], am[1][NTAP], s_h[1][NTAP], s_w[1][NTAP], s_m[1][NTAP];
-    bool live[1];
-    size_t pp[1];
+    const int pix = threadIdx.x, h = y0 + pix / TW, w = x0 + pix % TW;
+    const bool live = h < H && w < W;
+    const size_t pp = live ? (size_t)h * W + w : 0;
+    float hi[TG], wi[TG], cw[TG], am[TG], s_h[TG], s_w[TG], s_m[TG];
+    {
+        const float *o = off + (size_t)b * 2 * NTAP * HW + pp, *m = aff + (size_t)b * NTAP * HW + pp;
 #pragma unroll
-    for (int q = 0; q < 1; ++q) {
-        const int pix = threadIdx.x + q * CNT, h = y0 + pix / TW, w = x0 + pix % TW;
-        live[q] = h < H && w < W;
-        pp[q] = live[q] ? (size_t)h * W + w : 0;
-        const float *o = off + (size_t)b * 2 * NTAP * HW + pp[q], *m = aff + (size_t)b * NTAP * HW + pp[q];
-#pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-            hi[q][t] = h - 1 + t / 3 + (live[q] ? o[(size_t)(2 * t) * HW] : 0.f);
-            wi[q][t] = w - 1 + t % 3 + (live[q] ? o[(size_t)(2 * t + 1) * HW] : 0.f);
-            am[q][t] = live[q] ? m[(size_t)t * HW] : 0.f;
-            s_h[q][t] = s_w[q][t] = s_m[q][t] = 0.f;
+        for (int k = 0; k < TG; ++k) {
+            const int t = t0 + k;
+            hi[k] = h - 1 + t / 3 + (live ? o[(size_t)(2 * t) * HW] : 0.f);
+            wi[k] = w - 1 + t % 3 + (live ? o[(size_t)(2 * t + 1) * HW] : 0.f);
+            am[k] = live ? m[(size_t)t * HW] : 0.f;
+            cw[k] = wt[t];
+            s_h[k] = s_w[k] = s_m[k] = 0.f;
         }
     }
+    // this thread's share of the window: image offsets of its cells (-1: outside the image -> 0), the same for every step
+    int cell[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int e = threadIdx.x + k * CNT, r = e / WW, c = e - r * WW, iy = wy0 + r, ix = wx0 + c;
+        cell[k] = (e < WN && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? iy * W + ix : -1;
+    }
+    float stage[NS];
+    auto fetch = [&](const float *im) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) stage[k] = cell[k] >= 0 ? im[cell[k]] : 0.f;
+    };
+    auto deposit = [&](float *wn) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (threadIdx.x + k * CNT < WN) wn[threadIdx.x + k * CNT] = stage[k];
+    };
+    fetch(feats + (size_t)b * HW);
+    deposit(win[0]);
     for (int i = 0; i < T; ++i) {
         const float *im = feats + (size_t)i * feat_stride + (size_t)b * HW;
-        __syncthreads();                                  // the previous step's reads of the window are done
-        load_window<CNT>(win, im, wy0, wx0, H, W);
-        __syncthreads();
+        __syncthreads();                                  // window i is complete; every thread is done with window i - 1
+        if (i + 1 < T) fetch(im + feat_stride);           // (in flight during the arithmetic below)
+        if (live) {
+            const float go = gouts[(size_t)i * gout_stride + (size_t)b * HW + pp];
 #pragma unroll
-        for (int q = 0; q < 1; ++q) {
-            if (!live[q]) continue;
-            const float go = gouts[(size_t)i * gout_stride + (size_t)b * HW + pp[q]];
-#pragma unroll
-            for (int t = 0; t < NTAP; ++t) {
-                const float h_ = hi[q][t], w_ = wi[q][t];
+            for (int k = 0; k < TG; ++k) {
+                const float h_ = hi[k], w_ = wi[k];
                 if (h_ <= -1.f || w_ <= -1.f || h_ >= H || w_ >= W) continue;
                 const Smp c = sample(h_, w_, H, W);
                 float a, bb, d, e;
-                corners(c, win, wy0, wx0, im, W, a, bb, d, e);
-                const float hh = 1.f - c.lh, hw = 1.f - c.lw, cg = wt[t] * go;
-                s_m[q][t] += cg * (hh * hw * a + hh * c.lw * bb + c.lh * hw * d + c.lh * c.lw * e);
-                s_h[q][t] += cg * am[q][t] * (-hw * a - c.lw * bb + hw * d + c.lw * e);
-                s_w[q][t] += cg * am[q][t] * (-hh * a + hh * bb - c.lh * d + c.lh * e);
+                corners(c, win[i & 1], wy0, wx0, im, W, a, bb, d, e);
+                const float hh = 1.f - c.lh, hw = 1.f - c.lw, cg = cw[k] * go;
+                s_m[k] += cg * (hh * hw * a + hh * c.lw * bb + c.lh * hw * d + c.lh * c.lw * e);
+                s_h[k] += cg * am[k] * (-hw * a - c.lw * bb + hw * d + c.lw * e);
+                s_w[k] += cg * am[k] * (-hh * a + hh * bb - c.lh * d + c.lh * e);
             }
         }
+        if (i + 1 < T) deposit(win[(i + 1) & 1]);         // last read in step i - 1: every thread is past this step's barrier
     }
+    if (!live) return;
+    float *go_ = goff + (size_t)b * 2 * NTAP * HW + pp, *gm_ = gaff + (size_t)b * NTAP * HW + pp;
 #pragma unroll
-    for (int q = 0; q < 1; ++q) {
-        if (!live[q]) continue;
-        float *go_ = goff + (size_t)b * 2 * NTAP * HW + pp[q], *gm_ = gaff + (size_t)b * NTAP * HW + pp[q];
-#pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-            go_[(size_t)(2 * t) * HW] = s_h[q][t];
-            go_[(size_t)(2 * t + 1) * HW] = s_w[q][t];
-            gm_[(size_t)t * HW] = s_m[q][t];
-        }
+    for (int k = 0; k < TG; ++k) {
+        const int t = t0 + k;
+        go_[(size_t)(2 * t) * HW] = s_h[k];
+        go_[(size_t)(2 * t + 1) * HW] = s_w[k];
+        gm_[(size_t)t * HW] = s_m[k];
     }
 }
 
@@ -341,33 +371,78 @@ __global__ __launch_bounds__(NT) void affinity_fwd_kernel(Geo g, AffMode md, con
     }
 }
 
+// the 24 channels of one pixel <-> floats: three (16-bit) or six (f32) 16-byte accesses when the rows are 16-byte aligned
+template <typename T> __device__ __forceinline__ void load24(const T *__restrict__ src, bool vec, float (&v)[3 * NB]) {
+    constexpr int VEC = Elem<T>::VEC;
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < 3 * NB / VEC; ++q) {
+            Vec16<T> t;
+            t.load(src + q * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[q * VEC + e] = t.get(e);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3 * NB; ++c) v[c] = Elem<T>::ld(src + c);
+    }
+}
+template <typename T> __device__ __forceinline__ void store24(T *__restrict__ dst, bool vec, const float (&v)[3 * NB]) {
+    constexpr int VEC = Elem<T>::VEC;
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < 3 * NB / VEC; ++q) {
+            Vec16<T> t;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t.set(e, v[q * VEC + e]);
+            t.store(dst + q * VEC);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3 * NB; ++c) Elem<T>::st(dst + c, v[c]);
+    }
+}
+
 // backward: g_oa (pixel-major, dtype of the guidance conv's output gradient), g_conf (scatter, zero-filled), g_scale (one
-// atomic per workgroup into a zero-filled f32)
+// atomic per workgroup into a zero-filled f32).  Pixel tiles like the propagation kernels; the confidence cotangents (eight
+// bilinear scatters per pixel) go through the 64-bit fixed-point LDS window of prop_bwd_feat_kernel and leave the workgroup as
+// one global atomic per touched cell (they were 32 global float atomics per pixel: 365 us in the step); the pixel's 24 input and
+// 24 output channels move as 16-byte vectors.
 template <typename T>
 __global__ __launch_bounds__(NT) void affinity_bwd_kernel(Geo g, AffMode md, const T *__restrict__ oa, int ld, const float *__restrict__ conf_s,
                                                           const float *__restrict__ scale, const float *__restrict__ wconf,
                                                           const float *__restrict__ goff,
                                                           const float *__restrict__ gaff, T *__restrict__ goa, int ldg,
-                                                          float *__restrict__ gconf, float *__restrict__ gscale) {
+                                                          float *__restrict__ gconf, float *__restrict__ gscale, int vec_in, int vec_out) {
+    __shared__ long long gacc[WN];
+    __shared__ float wmax[NT / 64], red[NT / 64];
+    int b, y0, x0;
+    tile_of(g, b, y0, x0);
     const int H = g.H, W = g.W;
-    const size_t HW = (size_t)H * W, total = (size_t)g.B * HW;
+    const size_t HW = (size_t)H * W;
+    const int wy0 = y0 - 1 - R, wx0 = x0 - 1 - R;
     const float inv_scale = md.use_tanh ? 1.f / (scale[0] + md.scale_eps) : 1.f;
     const float wc = wconf ? wconf[0] : 1.f;
-    float gs_local = 0.f;
-    for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
-        const int b = (int)(idx / HW);
-        const size_t p = idx - (size_t)b * HW;
-        const int h = (int)(p / W), w = (int)(p - (size_t)h * W);
-        const T *src = oa + idx * ld;
-        float v[3 * NB];
+    const bool scatter = gconf != nullptr && conf_s != nullptr;
+    if (scatter)
+        for (int e = threadIdx.x; e < WN; e += NT) gacc[e] = 0;
+    float gc[PPT][NB], sy[PPT][NB], sx[PPT][NB];          // confidence cotangents of this thread's pixels and where they land
+    float gs_local = 0.f, big = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3 * NB; ++c) v[c] = Elem<T>::ld(src + c);
+    for (int q = 0; q < PPT; ++q) {
+        const int pix = threadIdx.x + q * NT, h = y0 + pix / TW, w = x0 + pix % TW;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) gc[q][k] = sy[q][k] = sx[q][k] = 0.f;
+        if (h >= H || w >= W) continue;
+        const size_t p = (size_t)h * W + w, idx = (size_t)b * HW + p;
+        float v[3 * NB];
+        load24(oa + idx * ld, vec_in != 0, v);
         const float *go = goff ? goff + (size_t)b * 2 * NTAP * HW + p : nullptr, *gm = gaff + (size_t)b * NTAP * HW + p;
         // recompute the forward up to the normalisation
         float th[NB], cs[NB], bk[NB], s = 0.f;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            float x = v[2 * NB + k];
+            const float x = v[2 * NB + k];
             th[k] = md.use_tanh ? tanhf(x) : x;
             cs[k] = conf_s ? conf_s[((size_t)b * NB + k) * HW + p] : 1.f;
             bk[k] = (md.use_tanh ? th[k] * inv_scale : th[k]) * cs[k];
@@ -402,26 +477,64 @@ __global__ __launch_bounds__(NT) void affinity_bwd_kernel(Geo g, AffMode md, con
             const int t = k < REF ? k : k + 1;
             out[2 * k] = go ? go[(size_t)(2 * t) * HW] : 0.f;                 // (the confidence gathers use detached offsets)
             out[2 * k + 1] = go ? go[(size_t)(2 * t + 1) * HW] : 0.f;
-            if (gconf != nullptr && conf_s != nullptr && g_c != 0.f) {
-                const float hi = h + v[2 * k], wi = w + v[2 * k + 1];
-                if (!(hi <= -1.f || wi <= -1.f || hi >= H || wi >= W)) {
-                    const Smp c = sample(hi, wi, H, W);
+            if (scatter) {
+                gc[q][k] = g_c;
+                sy[q][k] = h + v[2 * k];
+                sx[q][k] = w + v[2 * k + 1];
+                big = fabsf(g_c) <= 3.0e38f ? fmaxf(big, fabsf(g_c)) : __builtin_inff();      // NaN / inf: flagged, not dropped
+            }
+        }
+        store24(goa + idx * ldg, vec_out != 0, out);
+    }
+    if (scatter) {
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) big = fmaxf(big, __shfl_xor(big, o_, 64));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = big;
+        __syncthreads();                                    // (also: the window is zeroed)
+        big = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (big != 0.f) {                                   // uniform over the workgroup
+            int ex = 0;
+            if (big <= 3.0e38f) frexpf(big, &ex);
+            const bool fixed = big <= 3.0e38f && 46 - ex <= 126;            // see prop_bwd_feat_kernel
+            const float up = fixed ? ldexpf(1.f, 46 - ex) : 0.f;
+            const double down = fixed ? 1.0 / (double)up : 0.0;
+            float *gi = gconf + (size_t)b * HW;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const float h_ = sy[q][k], w_ = sx[q][k], vv = gc[q][k];
+                    if (h_ <= -1.f || w_ <= -1.f || h_ >= H || w_ >= W || vv == 0.f) continue;
+                    const Smp c = sample(h_, w_, H, W);
                     const float hh = 1.f - c.lh, hw = 1.f - c.lw;
-                    float *gi = gconf + (size_t)b * HW;
-                    if (c.v00) atomicAdd(gi + (size_t)c.h0 * W + c.w0, hh * hw * g_c);
-                    if (c.v01) atomicAdd(gi + (size_t)c.h0 * W + c.w0 + 1, hh * c.lw * g_c);
-                    if (c.v10) atomicAdd(gi + (size_t)(c.h0 + 1) * W + c.w0, c.lh * hw * g_c);
-                    if (c.v11) atomicAdd(gi + (size_t)(c.h0 + 1) * W + c.w0 + 1, c.lh * c.lw * g_c);
+                    const int r0 = c.h0 - wy0, c0 = c.w0 - wx0;
+                    if (__builtin_expect(fixed && r0 >= 0 && c0 >= 0 && r0 + 1 < WH && c0 + 1 < WW, 1)) {
+                        long long *ga_ = gacc + r0 * WW + c0;
+                        const float s_ = vv * up;
+                        atomicAdd(reinterpret_cast<unsigned long long *>(ga_), (unsigned long long)(long long)(hh * hw * s_));
+                        atomicAdd(reinterpret_cast<unsigned long long *>(ga_ + 1), (unsigned long long)(long long)(hh * c.lw * s_));
+                        atomicAdd(reinterpret_cast<unsigned long long *>(ga_ + WW), (unsigned long long)(long long)(c.lh * hw * s_));
+                        atomicAdd(reinterpret_cast<unsigned long long *>(ga_ + WW + 1), (unsigned long long)(long long)(c.lh * c.lw * s_));
+                    } else {
+                        if (c.v00) atomicAdd(gi + (size_t)c.h0 * W + c.w0, hh * hw * vv);
+                        if (c.v01) atomicAdd(gi + (size_t)c.h0 * W + c.w0 + 1, hh * c.lw * vv);
+                        if (c.v10) atomicAdd(gi + (size_t)(c.h0 + 1) * W + c.w0, c.lh * hw * vv);
+                        if (c.v11) atomicAdd(gi + (size_t)(c.h0 + 1) * W + c.w0 + 1, c.lh * c.lw * vv);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < WN; e += NT) {
+                const long long a = gacc[e];
+                if (a != 0) {
+                    const int r = e / WW, c = e - r * WW, iy = wy0 + r, ix = wx0 + c;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) atomicAdd(gi + (size_t)iy * W + ix, (float)((double)a * down));
                 }
             }
         }
-        T *dst = goa + idx * ldg;
-#pragma unroll
-        for (int c = 0; c < 3 * NB; ++c) Elem<T>::st(dst + c, out[c]);
     }
     if (gscale != nullptr && md.use_tanh) {
         gs_local = wave_sum(gs_local);
-        __shared__ float red[NT / 64];
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gs_local;
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(gscale, red[0] + red[1] + red[2] + red[3]);
@@ -487,9 +600,11 @@ extern "C" int rdfc_nlspn_affinity_backward(const void *offset_aff, int ld, int 
         return 2;
     }
     const Geo g = make_geo(B, H, W);
-    const int nb = (int)min((size_t)4096, (total + NT - 1) / NT);
-    DISPATCH(dtype, hipLaunchKernelGGL(affinity_bwd_kernel<T>, dim3(nb), dim3(NT), 0, st, g, md, (const T *)offset_aff, ld, conf_samples, scale, w_conf,
-                                       grad_offset, grad_aff, (T *)grad_offset_aff, ldg, grad_confidence, grad_scale));
+    const size_t esz = dtype == RDFC_F32 ? 4 : 2;
+    const int vec_in = (ld * esz) % 16 == 0 && (size_t)offset_aff % 16 == 0, vec_out = (ldg * esz) % 16 == 0 && (size_t)grad_offset_aff % 16 == 0;
+    DISPATCH(dtype, hipLaunchKernelGGL(affinity_bwd_kernel<T>, dim3(g.tiles_x * g.tiles_y * B), dim3(NT), 0, st, g, md, (const T *)offset_aff, ld,
+                                       conf_samples, scale, w_conf, grad_offset, grad_aff, (T *)grad_offset_aff, ldg, grad_confidence, grad_scale,
+                                       vec_in, vec_out));
     RDFC_LAUNCH_CHECK("rdfc_nlspn_affinity_backward");
     return 0;
 }
@@ -529,7 +644,7 @@ extern "C" int rdfc_nlspn_propagate_backward(const float *feats, const float *of
         hipLaunchKernelGGL(prop_bwd_feat_kernel, grid, dim3(NT), 0, st, g, offset, aff, weight, grads + (size_t)i * n, grads + (size_t)(i - 1) * n);
     if (grad_offset != nullptr || grad_aff != nullptr) {
         RDFC_REQUIRE(grad_offset != nullptr && grad_aff != nullptr, "rdfc_nlspn_propagate_backward: offset and affinity gradients come together");
-        hipLaunchKernelGGL(prop_bwd_coeff_kernel, grid, dim3(CNT), 0, st, g, T, feats, n, grads + n, n, offset, aff, weight, grad_offset, grad_aff);
+        hipLaunchKernelGGL(prop_bwd_coeff_kernel, dim3(grid.x, NGRP), dim3(CNT), 0, st, g, T, feats, n, grads + n, n, offset, aff, weight, grad_offset, grad_aff);
     }
     RDFC_LAUNCH_CHECK("rdfc_nlspn_propagate_backward");
     return 0;
