@@ -105,6 +105,12 @@ int rdfc_unpack_wgrad(const float *dw_packed, float *grad_oihw, int O, int I, in
 int rdfc_conv2d_reflect_supported(const rdfc_conv_desc *d);
 int rdfc_conv2d_forward_reflect(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, void *stream);
 int rdfc_conv2d_wgrad_reflect(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream);
+/* 1 when rdfc_conv2d_wgrad (reflect = 0) / rdfc_conv2d_wgrad_reflect (reflect = 1) of this layer adds its split-K partial sums in a
+ * fixed order -- bitwise reproducible weight gradients (the 3x3 / 4x4, stride 1 / 2 layers with >= 64 channels on both sides:
+ * conv_wgrad_ring.hip) -- and 0 when the launch goes to a kernel that accumulates partials with f32 atomics (same values up to
+ * the order of the adds).  torch.nn.grad.conv2d_weight in upstream's autograd (torch.nn.Conv2d, common.py:11-17) has no such
+ * guarantee either; a caller that needs run-to-run identical training asks here. */
+int rdfc_conv2d_wgrad_deterministic(const rdfc_conv_desc *d, int reflect);
 
 /* y = act(conv(x, w_fwd) + bias).  bias: f32[Co] or NULL. */
 int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias,

@@ -186,4 +186,10 @@ __device__ inline float wave_sum(float v) {
 // lands after the barrier); with a CU's LDS queue full -- three workgroups of the kernel beside another stream's kernel, 480x640
 // maps -- such a read returned bytes of a later step: rare wrong half-tiles that came and went run to run (found by
 // tools/rerun_check.py in round 3; every LDS-DMA kernel of this library had the same one-step distance).
+// (-DRDFC_TEST_NO_READ_WAIT builds the kernels as they were, to show that tests/test_fullsize_gpu.py and the 480x640 reproducibility
+// test catch the hazard; never in a shipped library.)
+#ifdef RDFC_TEST_NO_READ_WAIT
+template <int N> __device__ inline void wait_vm_and_reads() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#else
 template <int N> __device__ inline void wait_vm_and_reads() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+#endif

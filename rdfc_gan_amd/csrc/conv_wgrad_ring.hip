@@ -393,31 +393,46 @@ int launch_sk(const rdfc_conv_desc *d, const RParams &p, const void *x, const vo
 
 }  // namespace
 
+// whether this kernel takes the launch (shape rules + the measured exceptions); L = padded row length of the flat pixel walk
+static bool ring_takes(const rdfc_conv_desc *d, int reflect, int &L) {
+    const char *env_ = getenv("RDFC_WGRAD_RING");               // (read per call: tools/wgrad_ring_bench.py switches it between launches)
+    const int mode = env_ != nullptr ? atoi(env_) : 2;          // 0: off; 1: 3x3 / stride 1 only; 2 (default): also stride 2 and 4x4; 3: 2 without the size exceptions (tests)
+    if (mode == 0 || !rdfc_is16(d->dtype)) return false;
+    const int S = d->sh, K = d->KH;
+    if (!(d->KH == d->KW && (K == 3 || K == 4) && d->sh == d->sw && (S == 1 || S == 2) && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return false;
+    if ((S != 1 || K != 3) && (mode < 2 || d->ph != 1 || reflect)) return false;
+    if (d->Ho != (d->Hi + 2 * d->ph - K) / S + 1 || d->Wo != (d->Wi + 2 * d->pw - K) / S + 1) return false;
+    if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8 || d->Wo < 24) return false;
+    if (reflect && (d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return false;
+    const int omax = S == 1 ? K - 1 : K / 2;                   // largest tap shift within a plane's flat sequence
+    L = (d->Wo + omax + 7) / 8 * 8;
+    if (L < 32) L = 32;
+    if ((double)d->N * d->Ho * L >= 2.0e9) return false;
+    // Measured exceptions (profiles/r03_wgrad_ring_ab.txt): the 64-channel full-resolution inputs of the stride-2 layers (64 -> 128 / 192 from
+    // 16 x 228 x 304: every kernel row and co tile streams both parity planes of the 142 MB input again; the tap-gather kernel is
+    // 12-35 % faster there), and launches too small to pay for the second (reduction) launch.
+    if (mode < 3 && S == 2 && d->Ci < 128 && (double)d->N * d->Hi * d->Wi > 6.0e5) return false;
+    if (mode < 3 && cdiv((long)d->N * d->Ho * L, SEG) < 256) return false;
+    return true;
+}
+
+// include/rdfc_hip.h: 1 when rdfc_conv2d_wgrad[_reflect] of this layer adds its split-K partials in a fixed order (bitwise
+// reproducible results), 0 when the launch goes to a kernel that accumulates with float atomics
+extern "C" int rdfc_conv2d_wgrad_deterministic(const rdfc_conv_desc *d, int reflect) {
+    int L = 0;
+    return d != nullptr && ring_takes(d, reflect, L) ? 1 : 0;
+}
+
 // Called by rdfc_try_wgrad_glds (conv_wgrad_glds.hip) ahead of its own kernels; returns 1 if it took the launch.
 // RDFC_WGRAD_RING=0 switches it off (A/B against the segment walk + float atomics).
 int rdfc_try_wgrad_ring(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st, int reflect) {
-    const char *env_ = getenv("RDFC_WGRAD_RING");               // (read per call: tools/wgrad_ring_bench.py switches it between launches)
-    const int mode = env_ != nullptr ? atoi(env_) : 2;          // 0: off; 1: 3x3 / stride 1 only; 2 (default): also stride 2 and 4x4; 3: 2 without the size exceptions (tests)
-    if (mode == 0 || !rdfc_is16(d->dtype)) return 0;
+    int L = 0;
+    if (!ring_takes(d, reflect, L)) return 0;
     const int S = d->sh, K = d->KH;
-    if (!(d->KH == d->KW && (K == 3 || K == 4) && d->sh == d->sw && (S == 1 || S == 2) && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return 0;
-    if ((S != 1 || K != 3) && (mode < 2 || d->ph != 1 || reflect)) return 0;
-    if (d->Ho != (d->Hi + 2 * d->ph - K) / S + 1 || d->Wo != (d->Wi + 2 * d->pw - K) / S + 1) return 0;
-    if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8 || d->Wo < 24) return 0;
-    if (reflect && (d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return 0;
-    const int omax = S == 1 ? K - 1 : K / 2;                   // largest tap shift within a plane's flat sequence
-    int L = (d->Wo + omax + 7) / 8 * 8;
-    if (L < 32) L = 32;
-    if ((double)d->N * d->Ho * L >= 2.0e9) return 0;
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
     RParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, L, d->N * d->Ho, 0, 0, 0, 0, 0, 0, reflect, S == 1 ? -d->ph : -2};
     p.total_steps = cdiv((long)p.nrows * p.L, SEG);
-    // Measured exceptions (profiles/r03_wgrad_ring_ab.txt): the 64-channel full-resolution inputs of the stride-2 layers (64 -> 128 / 192 from
-    // 16 x 228 x 304: every kernel row and co tile streams both parity planes of the 142 MB input again; the tap-gather kernel is
-    // 12-35 % faster there), and launches too small to pay for the second (reduction) launch.
-    if (mode < 3 && S == 2 && d->Ci < 128 && (double)d->N * d->Hi * d->Wi > 6.0e5) return 0;
-    if (mode < 3 && p.total_steps < 256) return 0;
     if (S == 1 && K == 3) return launch_sk<1, 3>(d, p, x, dy, dw, zero, st);
     if (S == 2 && K == 3) return launch_sk<2, 3>(d, p, x, dy, dw, zero, st);
     if (S == 2 && K == 4) return launch_sk<2, 4>(d, p, x, dy, dw, zero, st);

@@ -350,6 +350,11 @@ def conv_wgrad(d, x, dy, into=None, stream=None, reflect=False):
     return dw
 
 
+def wgrad_is_deterministic(d, reflect=False):
+    """whether conv_wgrad(d, ...) sums its split-K partials in a fixed order (bitwise reproducible) or with float atomics"""
+    return bool(lib().rdfc_conv2d_wgrad_deterministic(C.byref(d), int(reflect)))
+
+
 def zero_(t):
     """hipMemsetAsync on the current stream (a contiguous tensor or a contiguous slice of one)"""
     assert t.is_contiguous()

@@ -1,0 +1,105 @@
+"""GPU: the conv kernels at the benchmark's OWN launch sizes (16 stacked samples of BASELINE configs[1]: 228x304 ... 29x38 maps), through
+properties that need no oracle run of that size (the oracle comparisons run at 60x76):
+  * adjointness: <conv_w(x), g> = <x, dgrad_w(g)> = <w, wgrad(x, g)> -- the three kernels of a layer are each other's transposes, so a
+    tile that is skipped, doubled or mis-addressed anywhere in a 1 000-workgroup grid shows up in one scalar;
+  * linearity in the exactly representable case: conv(2 x) == 2 conv(x) bit for bit (a power of two commutes with every rounding);
+  * reproducibility under load: the same launch repeated while another stream keeps every CU busy returns the same bits.  (The
+    write-after-read hazard of the LDS-DMA rings found in round 3 -- common.h: wait_vm_and_reads -- is guarded by
+    test_shapes_gpu.py's 480x640 run-to-run test, which fails on a -DRDFC_TEST_NO_READ_WAIT build; this synthetic pairing of
+    launches did not provoke it on that build and stays as the cheap first line.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+# N, H, W, Ci, Co, k, stride, pad: the step's big layers (rdfc_gan_amd/DESIGN.md section 7's per-layer table)
+LAYERS = [(16, 228, 304, 64, 64, 3, 1, 1), (16, 114, 152, 128, 128, 3, 1, 1), (16, 57, 76, 256, 256, 3, 1, 1), (16, 29, 38, 512, 512, 3, 1, 1),
+          (16, 228, 304, 128, 64, 3, 1, 1), (16, 228, 304, 64, 128, 3, 2, 1), (16, 114, 152, 128, 256, 3, 2, 1), (16, 28, 38, 256, 512, 4, 1, 1),
+          (16, 57, 76, 128, 256, 4, 2, 1), (16, 57, 76, 384, 768, 1, 1, 0)]
+IDS = ['x'.join(str(v) for v in c) for c in LAYERS]
+DT = [torch.float16, torch.bfloat16]
+
+
+def _layer(case, dtype, seed=0):
+    from rdfc_gan_amd import hip
+    N, H, W, Ci, Co, k, s, p = case
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(N, H, W, Ci, device=DEV, generator=g).to(dtype)
+    w = torch.randn(Co, Ci, k, k, device=DEV, generator=g) * (0.7 / (Ci * k * k) ** 0.5)
+    w = w.to(dtype).float()                                  # the packed operand holds these values exactly
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    gy = torch.randn(N, Ho, Wo, Co, device=DEV, generator=g).to(dtype)
+    wf, wb = hip.pack_weight(w.contiguous(), dtype)
+    d = hip.conv_desc(x.shape, Co, k, s, p, ldx=Ci, ldy=Co, dtype=hip.dt(x))
+    return hip, d, x, w, wf, wb, gy, (N, Ho, Wo, Co)
+
+
+@pytest.mark.parametrize('dtype', DT, ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', LAYERS, ids=IDS)
+def test_forward_dgrad_wgrad_are_adjoint(case, dtype):
+    hip, d, x, w, wf, wb, gy, oshape = _layer(case, dtype)
+    y = hip.conv_forward(d, x, wf, None, torch.empty(oshape, dtype=dtype, device=DEV))
+    dx = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x))
+    dw = hip.conv_wgrad(d, x, gy)                                                   # f32 [Co][k*k][Ci]
+    a = (y.double() * gy.double()).sum()
+    b = (x.double() * dx.double()).sum()
+    c = (dw.double() * w.permute(0, 2, 3, 1).reshape(dw.shape).double()).sum()
+    # y and dx are stored in 16 bits (relative rounding 2^-9 bf16 / 2^-11 f16 per element, independent signs): the scale of what
+    # that does to the sums is the root-sum-square of their terms
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10
+    sa = float((y.double() * gy.double()).pow(2).sum().sqrt())
+    sb = float((x.double() * dx.double()).pow(2).sum().sqrt())
+    assert abs(float(a - c)) <= 6 * eps * sa + 1e-6 * abs(float(c)), (float(a), float(c), sa)
+    assert abs(float(b - c)) <= 6 * eps * sb + 1e-6 * abs(float(c)), (float(b), float(c), sb)
+
+
+@pytest.mark.parametrize('dtype', DT, ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', LAYERS, ids=IDS)
+def test_scaling_by_two_is_exact(case, dtype):
+    hip, d, x, w, wf, wb, gy, oshape = _layer(case, dtype, seed=1)
+    def same(two, one):
+        # (f16 results below 2^-13 are subnormal after the doubling or before it: fixed absolute spacing, 2 round(a) != round(2a))
+        ok = one.abs() >= 2.0 ** -13 if dtype == torch.float16 else torch.ones_like(one, dtype=torch.bool)
+        assert float(ok.float().mean()) > 0.99
+        return torch.equal(two[ok], (one * 2)[ok])
+    y1 = hip.conv_forward(d, x, wf, None, torch.empty(oshape, dtype=dtype, device=DEV))
+    y2 = hip.conv_forward(d, x * 2, wf, None, torch.empty(oshape, dtype=dtype, device=DEV))
+    assert same(y2, y1)
+    dx1 = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x))
+    dx2 = hip.conv_dgrad(d, gy * 2, wb, None, torch.empty_like(x))
+    assert same(dx2, dx1)
+    dw1 = hip.conv_wgrad(d, x, gy)
+    dw2 = hip.conv_wgrad(d, x * 2, gy)
+    if hip.wgrad_is_deterministic(d):
+        assert torch.equal(dw2, dw1 * 2)
+    else:                                                    # split-K float atomics: the order of the adds varies
+        assert float((dw2 - dw1 * 2).abs().max()) <= 1e-5 * float(dw1.abs().max())
+
+
+@pytest.mark.parametrize('dtype', DT, ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', LAYERS[:6], ids=IDS[:6])
+def test_results_do_not_change_under_load(case, dtype):
+    """forward, input gradient and weight gradient launched on one stream while a second stream runs other LDS-DMA convolutions
+    back to back (every CU's LDS queue shared by two kernels): twelve rounds, the same bits as alone"""
+    hip, d, x, w, wf, wb, gy, oshape = _layer(case, dtype, seed=2)
+    _, d2, x2, _w2, wf2, wb2, gy2, oshape2 = _layer(LAYERS[0] if case != LAYERS[0] else LAYERS[2], dtype, seed=3)
+    y_ref = hip.conv_forward(d, x, wf, None, torch.empty(oshape, dtype=dtype, device=DEV)).clone()
+    dx_ref = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x)).clone()
+    dw_ref = hip.conv_wgrad(d, x, gy).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    y2, dx2 = torch.empty(oshape2, dtype=dtype, device=DEV), torch.empty_like(x2)
+    for r in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                hip.conv_forward(d2, x2, wf2, None, y2)
+                hip.conv_dgrad(d2, gy2, wb2, None, dx2)
+        y = hip.conv_forward(d, x, wf, None, torch.full(oshape, 7.0, dtype=dtype, device=DEV))
+        dx = hip.conv_dgrad(d, gy, wb, None, torch.full_like(x, 7.0))
+        dw = hip.conv_wgrad(d, x, gy)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref), (r, 'forward', float((y.float() - y_ref.float()).abs().max()))
+        assert torch.equal(dx, dx_ref), (r, 'dgrad', float((dx.float() - dx_ref.float()).abs().max()))
+        if hip.wgrad_is_deterministic(d):
+            assert torch.equal(dw, dw_ref), (r, 'wgrad', float((dw - dw_ref).abs().max()))
