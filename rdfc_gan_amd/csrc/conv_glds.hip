@@ -32,6 +32,7 @@ struct GParams {
     float slope;
     int out_f32;
     int tiles_x, tiles_y;
+    int vstride;                 // > 0: the batch is tiled as ONE tall map, image n at virtual rows [n * vstride, n * vstride + H) (stack_rows below)
     int stats_groups;            // fused statistics: 0 = off, 1 = one group (batch norm), N = one group per image (instance norm)
     const void *addend;          // optional map (2-byte elements, pixel stride ld_add) added to the result before the store: the
     int ld_add;                  // input gradient of a residual junction in one pass (rdfc_conv2d_dgrad_add)
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     const int t_all = t;                                        // tile index after the renumbering (unique)
     const int tx = t % p.tiles_x;
     t /= p.tiles_x;
-    const int ty = t % p.tiles_y, n = t / p.tiles_y;
+    // stacked batch (p.vstride > 0): ty counts tile rows of the tall virtual map and y0 is a virtual row; else a tile belongs to image n
+    const int ty = p.vstride ? t : t % p.tiles_y, n = p.vstride ? 0 : t / p.tiles_y;
     const int y0 = ty * TR, x0 = tx * TC;
     const int ncc = p.Cin / BK;
 
@@ -130,13 +132,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
             psrc[v][r] = zero;
             if (q < NPATCH) {
                 const int py = q / PW, px = q - py * PW;
-                int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px;
+                int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px, ni = n;
+                if (p.vstride) {           // virtual row -> (image, row); the rows between two images read zeros (iy >= Hin below)
+                    ni = iy >= 0 ? iy / p.vstride : p.N;
+                    iy -= ni * p.vstride;
+                }
                 if (p.reflect) {           // LDS-DMA sources are per lane: the halo of a reflection-padded map is just another address
                     iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);
                     ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
                 }                          // (what is still outside belongs to output pixels beyond the map: zero page)
-                if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
-                    psrc[v][r] = x + ((size_t)(n * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
+                if (ni < p.N && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
+                    psrc[v][r] = x + ((size_t)(ni * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
                     plive[v] |= 1u << r;
                 }
             }
@@ -262,6 +268,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     // (the activation is selected once, outside the 64-value loop: a per-element switch costs more than the stores)
     const int q4 = (lane >> 4) * 4;
     const bool vec_ok = (p.ld_out & 3) == 0;
+    int on[JR], oyr[JR];                                        // image and row of this wave's JR output rows (-1: none)
+#pragma unroll
+    for (int j = 0; j < JR; ++j) {
+        int v = y0 + JR * wc + j, ni = n;
+        if (p.vstride) {
+            ni = v / p.vstride;
+            v -= ni * p.vstride;
+        }
+        on[j] = ni;
+        oyr[j] = (ni < p.N && v < p.H) ? v : -1;
+    }
     float bv[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                               // four consecutive channels per lane: one 16-byte load, not four scalar ones
@@ -284,8 +301,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
             for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < JR; ++j) {
-            const int oy = y0 + JR * wc + j, ox = x0 + (lane & 15);
-            if (oy < p.H && ox < p.W) {
+            const int oy = oyr[j], ox = x0 + (lane & 15);
+            if (oy >= 0 && ox < p.W) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -339,9 +356,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     auto store_all = [&](auto actf) {
 #pragma unroll
         for (int j = 0; j < JR; ++j) {
-            const int oy = y0 + JR * wc + j, ox = x0 + (lane & 15);
-            if (oy >= p.H || ox >= p.W) continue;
-            const size_t po = ((size_t)n * p.H + oy) * p.W + ox;
+            const int oy = oyr[j], ox = x0 + (lane & 15);
+            if (oy < 0 || ox >= p.W) continue;
+            const size_t po = ((size_t)on[j] * p.H + oy) * p.W + ox;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int co = co0 + wr * 64 + 16 * i + q4;
@@ -410,7 +427,7 @@ int launch(const GParams &p, const void *x, const void *w, const float *bias, vo
         if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
-    dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
+    dim3 grid(p.tiles_x * p.tiles_y * (p.vstride ? 1 : p.N), cdiv(p.Cout, TCO));
     rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, DT);         // the symbol as rocprofv3 prints it
     hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, DT>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
     return 1;
@@ -430,10 +447,29 @@ static bool glds_shape_ok(const rdfc_conv_desc *d, int transposed) {
 
 // Number of per-tile statistics rows the fused epilogue writes per group for this shape (G = 1 or N), 0 if the shape does
 // not run on this kernel (the caller then uses rdfc_norm_stats).
+// Row tiles of 8 / 16 rows waste the last tile row of every image (57 rows: 8 tiles for 7.1, 29 rows: 4 for 3.6).  With N > 1 the
+// batch is tiled as ONE tall map instead: image n at virtual rows [n * S, n * S + H), the S - H rows between two images read zeros
+// and store nothing (they ARE the zero padding both neighbours need, which is what fixes S), and only the last tile row of the whole
+// batch is partial: 128 -> 116 row tiles for 16 x 57, 64 -> 60 for 16 x 29.  Not with the reflection fold (a mirrored halo row differs
+// per image) and not with per-image fused statistics (a tile may straddle two images).  -> S, 0 if the launch keeps per-image tiles.
+static int stack_rows(int N, int H, int Hin, int oy0, int TR, bool allowed, int &tiles_y) {
+    static const int on = getenv("RDFC_GLDS_STACK") ? atoi(getenv("RDFC_GLDS_STACK")) : 1;
+    tiles_y = cdiv(H, TR);
+    if (!on || !allowed || N < 2) return 0;
+    int S = H > Hin - oy0 ? H : Hin - oy0;                      // a row above an image's first must be a zero row of its predecessor
+    if (H + 1 + oy0 >= Hin && S < H + 2 + oy0) S = H + 2 + oy0; // rows below an image's last must not be its successor's first
+    const int stacked = cdiv((N - 1) * S + H, TR);
+    if (stacked >= N * tiles_y) return 0;
+    tiles_y = stacked;
+    return S;
+}
+
 int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G) {
     if (!glds_shape_ok(d, 0) || (G != 1 && G != d->N)) return 0;
-    const int tiles = cdiv(d->Wo, TC) * cdiv(d->Ho, d->Co > 64 ? 8 : 16);
-    return G == 1 ? tiles * d->N : tiles;
+    int tiles_y;
+    const int S = stack_rows(d->N, d->Ho, d->Hi, -d->ph, d->Co > 64 ? 8 : 16, G == 1, tiles_y);
+    const int tiles = cdiv(d->Wo, TC) * tiles_y;
+    return G == 1 && !S ? tiles * d->N : tiles;
 }
 
 // Called by conv_igemm.hip's entry points before the register-staged 3x3 kernels. Returns 1 if it took the launch.
@@ -451,9 +487,9 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     const int pad = d->ph;
     GParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo,
               Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
-              d->act, d->slope, d->out_f32, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect};
-    p.tiles_x = cdiv(p.W, TC);
-    p.tiles_y = cdiv(p.H, Cout > 64 ? 8 : 16);                 // 128 co x (8 x 16) px or 64 co x (16 x 16) px per workgroup
+              d->act, d->slope, d->out_f32, 0, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect};
+    p.tiles_x = cdiv(p.W, TC);                                 // 128 co x (8 x 16) px or 64 co x (16 x 16) px per workgroup
+    p.vstride = stack_rows(p.N, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, !reflect && (stats == nullptr || G == 1), p.tiles_y);
     if (d->dtype == RDFC_F16)
         return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, stats, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, stats, st);
     return Cout > 64 ? launch<128>(p, in, w, bias, out, zero, stats, st) : launch<64>(p, in, w, bias, out, zero, stats, st);
