@@ -451,7 +451,8 @@ static bool glds_shape_ok(const rdfc_conv_desc *d, int transposed) {
 // batch is tiled as ONE tall map instead: image n at virtual rows [n * S, n * S + H), the S - H rows between two images read zeros
 // and store nothing (they ARE the zero padding both neighbours need, which is what fixes S), and only the last tile row of the whole
 // batch is partial: 128 -> 116 row tiles for 16 x 57, 64 -> 60 for 16 x 29.  Not with the reflection fold (a mirrored halo row differs
-// per image) and not with per-image fused statistics (a tile may straddle two images).  -> S, 0 if the launch keeps per-image tiles.
+// per image) and not with fused statistics (their per-tile rows are consumed per image / per stacked batch, and a tile may straddle
+// two images).  -> S, 0 if the launch keeps per-image tiles.
 static int stack_rows(int N, int H, int Hin, int oy0, int TR, bool allowed, int &tiles_y) {
     static const int on = getenv("RDFC_GLDS_STACK") ? atoi(getenv("RDFC_GLDS_STACK")) : 1;
     tiles_y = cdiv(H, TR);
@@ -466,10 +467,8 @@ static int stack_rows(int N, int H, int Hin, int oy0, int TR, bool allowed, int 
 
 int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G) {
     if (!glds_shape_ok(d, 0) || (G != 1 && G != d->N)) return 0;
-    int tiles_y;
-    const int S = stack_rows(d->N, d->Ho, d->Hi, -d->ph, d->Co > 64 ? 8 : 16, G == 1, tiles_y);
-    const int tiles = cdiv(d->Wo, TC) * tiles_y;
-    return G == 1 && !S ? tiles * d->N : tiles;
+    const int tiles = cdiv(d->Wo, TC) * cdiv(d->Ho, d->Co > 64 ? 8 : 16);        // (launches with fused statistics keep per-image tiles)
+    return G == 1 ? tiles * d->N : tiles;
 }
 
 // Called by conv_igemm.hip's entry points before the register-staged 3x3 kernels. Returns 1 if it took the launch.
@@ -489,7 +488,7 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
               Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
               d->act, d->slope, d->out_f32, 0, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect};
     p.tiles_x = cdiv(p.W, TC);                                 // 128 co x (8 x 16) px or 64 co x (16 x 16) px per workgroup
-    p.vstride = stack_rows(p.N, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, !reflect && (stats == nullptr || G == 1), p.tiles_y);
+    p.vstride = stack_rows(p.N, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, !reflect && stats == nullptr, p.tiles_y);
     if (d->dtype == RDFC_F16)
         return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, stats, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, stats, st);
     return Cout > 64 ? launch<128>(p, in, w, bias, out, zero, stats, st) : launch<64>(p, in, w, bias, out, zero, stats, st);
