@@ -368,6 +368,8 @@ int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G);
 int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                         hipStream_t st, const void *addend = nullptr, int ld_add = 0);       // conv_igemm_glds.hip
 int rdfc_try_head_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const float *bias, void *dx, hipStream_t st);   // conv_head_dgrad.hip
+int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const void *w_bwd, const float *bias, void *res, hipStream_t st,
+                             const void *addend = nullptr, int ld_add = 0);                                                    // conv_t3x3s2_glds.hip
 int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st);               // conv_thin_in.hip
 static bool patch_enabled() {
@@ -447,6 +449,7 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
     } else if (rdfc_try_conv_thin(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_conv_thin_in(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_conv3x3_glds(d, 1, dy, w_bwd, bias, dx, st)) {
+    } else if (rdfc_try_convt3x3s2_glds(d, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_igemm_glds(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (d->dtype == RDFC_BF16) launch_T<bf16_t>(p, dy, w_bwd, bias, dx, st);
@@ -467,6 +470,7 @@ extern "C" int rdfc_conv2d_dgrad_add(const rdfc_conv_desc *d, const void *dy, co
     RDFC_REQUIRE(d->act == RDFC_ACT_NONE && !d->out_f32, "rdfc_conv2d_dgrad_add: plain input gradient only");
     hipStream_t st = (hipStream_t)stream;
     if (rdfc_is16(d->dtype) && (rdfc_try_conv3x3_glds(d, 1, dy, w_bwd, nullptr, dx, st, nullptr, 0, addend, ld_add) ||
+                                rdfc_try_convt3x3s2_glds(d, dy, w_bwd, nullptr, dx, st, addend, ld_add) ||
                                 rdfc_try_igemm_glds(d, 1, dy, w_bwd, nullptr, dx, st, addend, ld_add))) {
         RDFC_LAUNCH_CHECK("rdfc_conv2d_dgrad_add");
         return 0;

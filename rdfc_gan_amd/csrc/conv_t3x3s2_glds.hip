@@ -1,0 +1,264 @@
+// conv_t3x3s2_glds.hip -- the TRANSPOSED 3x3 / stride-2 / pad-1 convolution, staged by LDS-DMA with the source patch reused by all
+// nine taps: the input gradient of the encoders' stride-2 convs (encoder_decoder.py:40-61 via common.py:29-44, resnet_generator.py:8-51)
+// and the forward of the decoders' ConvTranspose2d(3, 2, 1, output_padding) (common.py:46-61).
+//
+//     r(y, x) = sum_{kh, kw} s((y + 1 - kh) / 2, (x + 1 - kw) / 2) . w[kh, kw]      over the taps that make both quotients integers
+//
+// igemm_glds_kernel walks the result per stride-parity class (even/even: one tap, ..., odd/odd: four) and gathers the source pixels of
+// every tap again: 16 KB of pixel DMA per 64-MFMA step on top of the weights, four passes over the source map, K loops of 4-16 steps
+// behind a 3-step prologue -- 190-200 us (0.09-0.12 of the peak) on the 64-channel full-resolution results.  Here a workgroup owns
+// 8 x 16 SOURCE pixels and 64 result channels, i.e. all FOUR classes of the 16 x 32 result pixels above them:
+//   * the 9 x 17 source patch of a 32-channel slab is staged once (10 KB) and every tap reads it at a shift of 0 or 1 pixel:
+//     kh = 1 -> even result rows from source row q; kh = 0 -> odd rows from q + 1; kh = 2 -> odd rows from q (columns alike);
+//   * a wave owns 64 co x 32 source px and keeps the four classes' accumulators (4 x 32 f32x4 = 128 registers); a phase is one
+//     kernel row = three taps = 24 MFMAs per wave behind one barrier, weights (12 KB per phase) in a ring of two phases;
+//   * per phase 12 KB of weights + a third of the patch = 15.4 KB for 96 MFMAs (160 B per MFMA; igemm_glds<64>: 320), the source is
+//     read once (+ a 13 % halo) instead of four times.
+// Pipeline rules as in conv_glds.hip (counted vmcnt + lgkmcnt(0) in front of a raw barrier, zero page for out-of-range pieces so
+// that every wave issues the same number of DMAs).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+struct TParams {
+    int N, Hs, Ws, Hr, Wr;       // source map (the smaller one), result map
+    int Cin, Cout;               // source channels (K), result channels
+    int ld_in, ld_out;
+    int act;
+    float slope;
+    int out_f32;
+    int tiles_x, tiles_y;
+    const void *addend;          // optional map added to the result before the store (rdfc_conv2d_dgrad_add)
+    int ld_add;
+};
+
+constexpr int BK = 32, NT = 256, TCO = 64;
+constexpr int TC = 16, TRS = 8, PW = TC + 1, PH = TRS + 1, NPATCH = PH * PW;     // source tile, patch (one halo row / column on the high side)
+constexpr int NPIECE = NPATCH * 4, PATCH_BYTES = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;   // 612 pieces, 10 KB, 3 rounds
+constexpr int WPH = 3 * TCO * BK * 2, NWP = WPH / 16 / NT;                        // weights of one phase (kernel row): 12 KB, 3 DMAs per thread
+constexpr int RING = 2;
+constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + RING * WPH, SMEM = OFF_JUNK + 1024;
+constexpr int JR = 2;                                                             // source rows per wave
+static_assert(NR == 3, "one patch round per phase of the previous slab");
+
+__device__ inline void glds16(const void *gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
+
+template <int DT>
+__global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
+                                                                const float *__restrict__ bias, void *__restrict__ yout,
+                                                                const bf16_t *__restrict__ zero) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = (int)threadIdx.x;
+    const int co0 = blockIdx.y * TCO;
+    int t = blockIdx.x;
+    {   // contiguous runs of tiles per XCD (conv_glds.hip)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = t & 7, k = t >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y, n = t / p.tiles_y;
+    const int y0 = ty * TRS, x0 = tx * TC;                       // source coordinates of the tile
+    const int ncc = p.Cin / BK;
+
+    // ---- per-thread DMA sources (computed once) --------------------------------------------------------------------------------
+    const bf16_t *psrc[NR];
+    unsigned plive = 0, pdst[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = r * NT + tid, q = e >> 2, slot = e & 3;
+        psrc[r] = zero;
+        if (q < NPATCH) {
+            const int py = q / PW, px = q - py * PW, iy = y0 + py, ix = x0 + px;
+            if (iy < p.Hs && ix < p.Ws) {
+                psrc[r] = x + ((size_t)(n * p.Hs + iy) * p.Ws + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
+                plive |= 1u << r;
+            }
+        }
+        const int wbase = (r * NT + wave * 64) * 16;
+        pdst[r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
+    }
+    const bf16_t *wsrc[NWP];                                     // DMA k of a phase = tap kw = k, row co = tid >> 2
+    {
+        const int row = tid >> 2, slot = tid & 3;
+#pragma unroll
+        for (int k = 0; k < NWP; ++k)
+            wsrc[k] = co0 + row < p.Cout ? w + (size_t)(co0 + row) * 9 * p.Cin + k * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3) : nullptr;
+    }
+    auto issue_w = [&](int it) {                                 // weights of global phase it = cc * 3 + kh -> ring slot it % RING
+        const int cc = it / 3, kh = it - cc * 3;
+        const int off = kh * 3 * p.Cin + cc * BK;
+#pragma unroll
+        for (int k = 0; k < NWP; ++k)
+            glds16(cc < ncc && wsrc[k] != nullptr ? wsrc[k] + off : zero, lds0 + OFF_W + (it % RING) * WPH + (k * NT + wave * 64) * 16);
+    };
+    auto issue_p = [&](int r, int cc) {                          // round r of slab cc -> patch buffer cc & 1
+        const unsigned dst = pdst[r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[r];
+        glds16(cc < ncc ? psrc[r] + ((plive >> r) & 1 ? cc * BK : 0) : zero, dst);
+    };
+
+    // ---- fragment coordinates -----------------------------------------------------------------------------------------------------
+    int bpp[JR];
+#pragma unroll
+    for (int j = 0; j < JR; ++j) bpp[j] = (JR * wave + j) * PW + (lane & 15);
+    const int arow = lane & 15, kg = lane >> 4;
+    const unsigned a_off = (unsigned)((arow << 6) | (kg << 4)) ^ (unsigned)((arow & 4) << 3);      // + 1024 per 16 rows (they share bit 2)
+
+    f32x4 acc[4][4][JR];                                          // [class ry * 2 + rx][16-channel block][source row]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < JR; ++j) acc[c][i][j] = f32x4{0, 0, 0, 0};
+
+    // ---- prologue: slab 0's patch, the first phase's weights --------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < NR; ++r) issue_p(r, 0);
+    issue_w(0);
+
+    // phase (cc, KH): kernel row KH feeds result rows of parity RY from source rows q + SY
+#define RDFC_T3S2_PHASE(KH)                                                                                     \
+    {                                                                                                           \
+        constexpr int RY = KH == 1 ? 0 : 1, SY = KH == 0 ? 1 : 0;                                                \
+        if (KH == 0) wait_vm_and_reads<0>(); else wait_vm_and_reads<1>();   /* phase 0 reads a patch whose last round was the youngest DMA */ \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        issue_w(it0 + KH + 1);                                                                                  \
+        issue_p(KH, cc + 1);                                                                                    \
+        const unsigned char *Wt = smem + OFF_W + ((it0 + KH) % RING) * WPH + a_off;                              \
+        const unsigned char *Pt = smem + (cc & 1) * PATCH_BYTES;                                                \
+        bf16x8 b_[2][JR];                                                                                       \
+        _Pragma("unroll") for (int sx = 0; sx < 2; ++sx)                                                        \
+            _Pragma("unroll") for (int j = 0; j < JR; ++j) {                                                    \
+                const int row = bpp[j] + SY * PW + sx;                                                          \
+                b_[sx][j] = *reinterpret_cast<const bf16x8 *>(Pt + (((row << 6) | (kg << 4)) ^ ((row & 4) << 3))); \
+            }                                                                                                   \
+        _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                      \
+            const int rx = kw == 1 ? 0 : 1, sx = kw == 0 ? 1 : 0;                                               \
+            bf16x8 a_[4];                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) a_[i] = *reinterpret_cast<const bf16x8 *>(Wt + (kw * 4 + i) * 1024); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < JR; ++j) acc[RY * 2 + rx][i][j] = mma16<DT>(a_[i], b_[sx][j], acc[RY * 2 + rx][i][j]); \
+        }                                                                                                       \
+    }
+    for (int cc = 0; cc < ncc; ++cc) {
+        const int it0 = cc * 3;
+        RDFC_T3S2_PHASE(0)
+        RDFC_T3S2_PHASE(1)
+        RDFC_T3S2_PHASE(2)
+    }
+#undef RDFC_T3S2_PHASE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: bias + activation (+ addend) + store, four consecutive result channels per lane --------------------------------
+    const int q4 = (lane >> 4) * 4;
+    const bool vec_ok = (p.ld_out & 3) == 0;
+    float bv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 16 * i + q4 + r;
+            bv[i][r] = (bias != nullptr && co < p.Cout) ? bias[co] : 0.f;
+        }
+    auto store_all = [&](auto actf) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ry = c >> 1, rx = c & 1;
+#pragma unroll
+            for (int j = 0; j < JR; ++j) {
+                const int oy = 2 * (y0 + JR * wave + j) + ry, ox = 2 * (x0 + (lane & 15)) + rx;
+                if (oy >= p.Hr || ox >= p.Wr) continue;
+                const size_t po = ((size_t)n * p.Hr + oy) * p.Wr + ox;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + 16 * i + q4;
+                    if (co >= p.Cout) continue;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = actf(acc[c][i][j][r] + bv[i][r]);
+                    if (p.addend != nullptr) {
+                        const bf16_t *ad = reinterpret_cast<const bf16_t *>(p.addend) + po * p.ld_add + co;
+                        if ((p.ld_add & 3) == 0 && co + 3 < p.Cout) {
+                            const bf16x4 t4 = *reinterpret_cast<const bf16x4 *>(ad);
+                            for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t4[r]);
+                        } else
+                            for (int r = 0; r < 4; ++r)
+                                if (co + r < p.Cout) v[r] += f32of<DT>(ad[r]);
+                    }
+                    const size_t off = po * p.ld_out + co;
+                    if (p.out_f32) {
+                        float *y = reinterpret_cast<float *>(yout) + off;
+                        if (vec_ok && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                        else
+                            for (int r = 0; r < 4; ++r)
+                                if (co + r < p.Cout) y[r] = v[r];
+                    } else {
+                        bf16_t *y = reinterpret_cast<bf16_t *>(yout) + off;
+                        if (vec_ok && co + 3 < p.Cout) {
+                            bf16x4 o;
+                            for (int r = 0; r < 4; ++r) o[r] = cvt16<DT>(v[r]);
+                            *reinterpret_cast<bf16x4 *>(y) = o;
+                        } else
+                            for (int r = 0; r < 4; ++r)
+                                if (co + r < p.Cout) y[r] = cvt16<DT>(v[r]);
+                    }
+                }
+            }
+        }
+    };
+    with_act(p.act, p.slope, store_all);
+}
+
+const bf16_t *zero_page() {
+    static void *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (pages[dev] == nullptr) {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
+        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = ptr;
+    }
+    return (const bf16_t *)pages[dev];
+}
+
+template <int DT>
+int launch(const TParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)convt3x3s2_glds_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
+    rdfc_note_kernel("convt3x3s2_glds_kernel<%d>", DT);
+    hipLaunchKernelGGL((convt3x3s2_glds_kernel<DT>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero);
+    return 1;
+}
+
+}  // namespace
+
+// Called by conv_igemm.hip's input-gradient entry points ahead of igemm_glds_kernel.  d describes the FORWARD stride-2 conv (result of
+// this kernel = d's input map, source = d's output map); returns 1 if it took the launch.  RDFC_T3S2=0 switches it off (A/B).
+int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const void *w_bwd, const float *bias, void *res, hipStream_t st,
+                             const void *addend = nullptr, int ld_add = 0) {
+    static const int on = getenv("RDFC_T3S2") ? atoi(getenv("RDFC_T3S2")) : 1;
+    if (!on || !rdfc_is16(d->dtype)) return 0;
+    if (!(d->KH == 3 && d->KW == 3 && d->sh == 2 && d->sw == 2 && d->ph == 1 && d->pw == 1 && d->dh == 1 && d->dw == 1)) return 0;
+    if (d->Ho != (d->Hi - 1) / 2 + 1 || d->Wo != (d->Wi - 1) / 2 + 1) return 0;
+    if (d->Co % BK != 0 || d->Ci % 64 != 0 || d->ldy % 8 != 0) return 0;
+    const bf16_t *zero = zero_page();
+    if (zero == nullptr) return 0;
+    TParams p{d->N, d->Ho, d->Wo, d->Hi, d->Wi, d->Co, d->Ci, d->ldy, d->ldx, d->act, d->slope, d->out_f32, cdiv(d->Wo, TC), cdiv(d->Ho, TRS),
+              addend, ld_add};
+    return d->dtype == RDFC_F16 ? launch<RDFC_F16>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16>(p, src, w_bwd, bias, res, zero, st);
+}

@@ -4,11 +4,12 @@
 //   affinity_fwd    conv_offset_aff's 24-channel output -> offsets [B,18,H,W] + affinities [B,9,H,W]: offset packing with
 //                   the zero reference tap, tanh / TGASS scaling, the eight 1x1 confidence gathers, abs-sum normalisation
 //                   and the reference weight -- upstream: ~15 elementwise launches + 8 deformable-conv launches
-//   affinity_bwd    its backward (gradient of the 24 channels, of the confidence map, of aff_scale_const)
+//   affinity_bwd    its backward (gradient of the 24 channels, of the confidence map -- scattered through a fixed-point LDS window --
+//                   and of aff_scale_const)
 //   prop_fwd        one propagation step: out[p] = b + sum_t w_t aff_t(p) bilinear(in, p + D_t + off_t(p))
 //   prop_bwd_feat   gradient of one step w.r.t. its input map only (the scatter)
-//   prop_bwd_coeff  gradients of offsets and affinities SUMMED OVER ALL STEPS in one pass: every pixel keeps its 27
-//                   accumulators in registers while the T saved input maps and cotangents stream through LDS
+//   prop_bwd_coeff  gradients of offsets and affinities SUMMED OVER ALL STEPS in one pass: a thread keeps the sums of one pixel's
+//                   three taps (blockIdx.y = tap group) in registers while the T saved input maps stream through LDS
 //
 // Why this split: offsets and affinities are shared by the T = 18 steps, so their gradients are sums over the steps.
 // Step by step (what autograd does with upstream's loop) that is 18 x (27 gradient planes written + 27 added by an
