@@ -172,8 +172,8 @@ def _self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=8, help='untimed steps (a cold first process on a fresh box needs a few: page cache, clocks)')
     ap.add_argument('--batch', type=int, default=8, help='pairs per GPU')
     ap.add_argument('--height', type=int, default=228)
     ap.add_argument('--width', type=int, default=304)
