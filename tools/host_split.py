@@ -32,10 +32,12 @@ def step(i):
 for i in range(4): step(i)
 torch.cuda.synchronize(); acc.clear()
 N = 8
-t0 = time.perf_counter()
-for i in range(N): step(i)
-host = time.perf_counter() - t0
-torch.cuda.synchronize(); wall = time.perf_counter() - t0
+host = wall = 0.0
+for i in range(N):          # one step at a time into an IDLE queue: with several steps in flight the launch queue fills up and the
+    t0 = time.perf_counter()  # enqueuing thread blocks inside whichever call comes next
+    step(i)
+    host += time.perf_counter() - t0
+    torch.cuda.synchronize(); wall += time.perf_counter() - t0
 print(f'per step: host enqueue {1e3*host/N:.2f} ms, wall {1e3*wall/N:.2f} ms')
 tot = 0
 for k, (s, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
