@@ -1,5 +1,5 @@
-// conv_t3x3s2_glds.hip -- the TRANSPOSED 3x3 / stride-2 / pad-1 convolution, staged by LDS-DMA with the source patch reused by all
-// nine taps: the input gradient of the encoders' stride-2 convs (encoder_decoder.py:40-61 via common.py:29-44, resnet_generator.py:8-51)
+// conv_t3x3s2_glds.hip -- the TRANSPOSED 3x3 (and 4x4) / stride-2 / pad-1 convolution, staged by LDS-DMA with the source patch reused by all
+// taps: the input gradient of the encoders' stride-2 convs (encoder_decoder.py:40-61 via common.py:29-44, resnet_generator.py:8-51)
 // and the forward of the decoders' ConvTranspose2d(3, 2, 1, output_padding) (common.py:46-61).
 //
 //     r(y, x) = sum_{kh, kw} s((y + 1 - kh) / 2, (x + 1 - kw) / 2) . w[kh, kw]      over the taps that make both quotients integers
@@ -35,13 +35,18 @@ struct TParams {
 };
 
 constexpr int BK = 32, NT = 256, TCO = 64;
-constexpr int TC = 16, TRS = 8, PW = TC + 1, PH = TRS + 1, NPATCH = PH * PW;     // source tile, patch (one halo row / column on the high side)
-constexpr int NPIECE = NPATCH * 4, PATCH_BYTES = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;   // 612 pieces, 10 KB, 3 rounds
-constexpr int WPH = 3 * TCO * BK * 2, NWP = WPH / 16 / NT;                        // weights of one phase (kernel row): 12 KB, 3 DMAs per thread
-constexpr int RING = 2;
-constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + RING * WPH, SMEM = OFF_JUNK + 1024;
-constexpr int JR = 2;                                                             // source rows per wave
-static_assert(NR == 3, "one patch round per phase of the previous slab");
+constexpr int TC = 16, TRS = 8, JR = 2, RING = 2;                                 // source tile; source rows per wave; weight ring (phases)
+// KS = 3: taps kh = 0, 1, 2 feed result rows of parity 1, 0, 1 from source rows q + 1, q, q (halo: one row / column on the high side).
+// KS = 4 (PatchGAN's 4x4 / stride-2 layers, patch_gan_discriminator.py:11-37): kh = 0 .. 3 -> parity 1, 0, 1, 0 from q + 1, q, q, q - 1
+// (halo on both sides).  A phase is one kernel row = KS taps.
+template <int KS> struct Geo {
+    static constexpr int ORG = KS == 4 ? 1 : 0;                                   // patch origin = tile origin - ORG
+    static constexpr int PW = TC + 1 + ORG, PH = TRS + 1 + ORG, NPATCH = PH * PW;
+    static constexpr int NPIECE = NPATCH * 4, PATCH_BYTES = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;   // 612 | 720 pieces, 10 | 12 KB, 3 rounds
+    static constexpr int WPH = KS * TCO * BK * 2, NWP = KS;                       // weights of one phase: 12 | 16 KB, one DMA per thread and tap
+    static constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + RING * WPH, SMEM = OFF_JUNK + 1024;
+    static_assert(NR == 3 && NR <= KS, "one patch round per phase of the previous slab");
+};
 
 __device__ inline void glds16(const void *gsrc, unsigned lds_base) {
     unsigned keep;
@@ -51,10 +56,13 @@ __device__ inline void glds16(const void *gsrc, unsigned lds_base) {
                  : "memory");
 }
 
-template <int DT>
+template <int DT, int KS>
 __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
                                                                 const float *__restrict__ bias, void *__restrict__ yout,
                                                                 const bf16_t *__restrict__ zero) {
+    using G = Geo<KS>;
+    constexpr int ORG = G::ORG, PW = G::PW, NPATCH = G::NPATCH, PATCH_BYTES = G::PATCH_BYTES, NR = G::NR, WPH = G::WPH, NWP = G::NWP;
+    constexpr int OFF_W = G::OFF_W, OFF_JUNK = G::OFF_JUNK;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = (int)threadIdx.x;
@@ -78,8 +86,8 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
         const int e = r * NT + tid, q = e >> 2, slot = e & 3;
         psrc[r] = zero;
         if (q < NPATCH) {
-            const int py = q / PW, px = q - py * PW, iy = y0 + py, ix = x0 + px;
-            if (iy < p.Hs && ix < p.Ws) {
+            const int py = q / PW, px = q - py * PW, iy = y0 - ORG + py, ix = x0 - ORG + px;
+            if ((unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws) {
                 psrc[r] = x + ((size_t)(n * p.Hs + iy) * p.Ws + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
                 plive |= 1u << r;
             }
@@ -92,11 +100,11 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
         const int row = tid >> 2, slot = tid & 3;
 #pragma unroll
         for (int k = 0; k < NWP; ++k)
-            wsrc[k] = co0 + row < p.Cout ? w + (size_t)(co0 + row) * 9 * p.Cin + k * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3) : nullptr;
+            wsrc[k] = co0 + row < p.Cout ? w + (size_t)(co0 + row) * KS * KS * p.Cin + k * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3) : nullptr;
     }
-    auto issue_w = [&](int it) {                                 // weights of global phase it = cc * 3 + kh -> ring slot it % RING
-        const int cc = it / 3, kh = it - cc * 3;
-        const int off = kh * 3 * p.Cin + cc * BK;
+    auto issue_w = [&](int it) {                                 // weights of global phase it = cc * KS + kh -> ring slot it % RING
+        const int cc = it / KS, kh = it - cc * KS;
+        const int off = kh * KS * p.Cin + cc * BK;
 #pragma unroll
         for (int k = 0; k < NWP; ++k)
             glds16(cc < ncc && wsrc[k] != nullptr ? wsrc[k] + off : zero, lds0 + OFF_W + (it % RING) * WPH + (k * NT + wave * 64) * 16);
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
     // ---- fragment coordinates -----------------------------------------------------------------------------------------------------
     int bpp[JR];
 #pragma unroll
-    for (int j = 0; j < JR; ++j) bpp[j] = (JR * wave + j) * PW + (lane & 15);
+    for (int j = 0; j < JR; ++j) bpp[j] = (JR * wave + j + ORG) * PW + (lane & 15) + ORG;
     const int arow = lane & 15, kg = lane >> 4;
     const unsigned a_off = (unsigned)((arow << 6) | (kg << 4)) ^ (unsigned)((arow & 4) << 3);      // + 1024 per 16 rows (they share bit 2)
 
@@ -126,35 +134,37 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
     for (int r = 0; r < NR; ++r) issue_p(r, 0);
     issue_w(0);
 
-    // phase (cc, KH): kernel row KH feeds result rows of parity RY from source rows q + SY
+    // phase (cc, KH): kernel row KH feeds result rows of parity RY = (KH + 1) & 1 from source rows q + SY, SY = (RY + 1 - KH) / 2; columns alike
 #define RDFC_T3S2_PHASE(KH)                                                                                     \
-    {                                                                                                           \
-        constexpr int RY = KH == 1 ? 0 : 1, SY = KH == 0 ? 1 : 0;                                                \
+    if (KH < KS) {                                                                                              \
+        constexpr int RY = (KH + 1) & 1, SY = (RY + 1 - KH) / 2;                                                 \
         if (KH == 0) wait_vm_and_reads<0>(); else wait_vm_and_reads<1>();   /* phase 0 reads a patch whose last round was the youngest DMA */ \
         __builtin_amdgcn_s_barrier();                                                                           \
         issue_w(it0 + KH + 1);                                                                                  \
-        issue_p(KH, cc + 1);                                                                                    \
+        if (KH < NR) issue_p(KH < NR ? KH : 0, cc + 1);                                                         \
+        else glds16(zero, lds0 + OFF_JUNK);                   /* (a fourth phase issues a dummy piece: the vmcnt arithmetic stays the same) */ \
         const unsigned char *Wt = smem + OFF_W + ((it0 + KH) % RING) * WPH + a_off;                              \
         const unsigned char *Pt = smem + (cc & 1) * PATCH_BYTES;                                                \
-        bf16x8 b_[2][JR];                                                                                       \
-        _Pragma("unroll") for (int sx = 0; sx < 2; ++sx)                                                        \
+        bf16x8 b_[3][JR];                                      /* column shifts -1 (KS = 4 only), 0, +1 */      \
+        _Pragma("unroll") for (int sx = (KS == 4 ? -1 : 0); sx <= 1; ++sx)                                      \
             _Pragma("unroll") for (int j = 0; j < JR; ++j) {                                                    \
                 const int row = bpp[j] + SY * PW + sx;                                                          \
-                b_[sx][j] = *reinterpret_cast<const bf16x8 *>(Pt + (((row << 6) | (kg << 4)) ^ ((row & 4) << 3))); \
+                b_[sx + 1][j] = *reinterpret_cast<const bf16x8 *>(Pt + (((row << 6) | (kg << 4)) ^ ((row & 4) << 3))); \
             }                                                                                                   \
-        _Pragma("unroll") for (int kw = 0; kw < 3; ++kw) {                                                      \
-            const int rx = kw == 1 ? 0 : 1, sx = kw == 0 ? 1 : 0;                                               \
+        _Pragma("unroll") for (int kw = 0; kw < KS; ++kw) {                                                     \
+            const int rx = (kw + 1) & 1, sx = (rx + 1 - kw) / 2;                                                \
             bf16x8 a_[4];                                                                                       \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) a_[i] = *reinterpret_cast<const bf16x8 *>(Wt + (kw * 4 + i) * 1024); \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
-                _Pragma("unroll") for (int j = 0; j < JR; ++j) acc[RY * 2 + rx][i][j] = mma16<DT>(a_[i], b_[sx][j], acc[RY * 2 + rx][i][j]); \
+                _Pragma("unroll") for (int j = 0; j < JR; ++j) acc[RY * 2 + rx][i][j] = mma16<DT>(a_[i], b_[sx + 1][j], acc[RY * 2 + rx][i][j]); \
         }                                                                                                       \
     }
     for (int cc = 0; cc < ncc; ++cc) {
-        const int it0 = cc * 3;
+        const int it0 = cc * KS;
         RDFC_T3S2_PHASE(0)
         RDFC_T3S2_PHASE(1)
         RDFC_T3S2_PHASE(2)
+        RDFC_T3S2_PHASE(3)
     }
 #undef RDFC_T3S2_PHASE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -232,33 +242,41 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int DT>
+template <int DT, int KS>
 int launch(const TParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, hipStream_t st) {
+    constexpr int SMEM = Geo<KS>::SMEM;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)convt3x3s2_glds_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)convt3x3s2_glds_kernel<DT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.N, cdiv(p.Cout, TCO));
-    rdfc_note_kernel("convt3x3s2_glds_kernel<%d>", DT);
-    hipLaunchKernelGGL((convt3x3s2_glds_kernel<DT>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero);
+    rdfc_note_kernel("convt3x3s2_glds_kernel<%d, %d>", DT, KS);
+    hipLaunchKernelGGL((convt3x3s2_glds_kernel<DT, KS>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero);
     return 1;
 }
 
 }  // namespace
 
 // Called by conv_igemm.hip's input-gradient entry points ahead of igemm_glds_kernel.  d describes the FORWARD stride-2 conv (result of
-// this kernel = d's input map, source = d's output map); returns 1 if it took the launch.  RDFC_T3S2=0 switches it off (A/B).
+// this kernel = d's input map, source = d's output map); returns 1 if it took the launch.  RDFC_T3S2=0 switches it off (A/B), 1: 3x3 only,
+// 3: also the launches too small to fill the chip (tests).
 int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const void *w_bwd, const float *bias, void *res, hipStream_t st,
                              const void *addend = nullptr, int ld_add = 0) {
-    static const int on = getenv("RDFC_T3S2") ? atoi(getenv("RDFC_T3S2")) : 1;
+    static const int on = getenv("RDFC_T3S2") ? atoi(getenv("RDFC_T3S2")) : 2;
     if (!on || !rdfc_is16(d->dtype)) return 0;
-    if (!(d->KH == 3 && d->KW == 3 && d->sh == 2 && d->sw == 2 && d->ph == 1 && d->pw == 1 && d->dh == 1 && d->dw == 1)) return 0;
-    if (d->Ho != (d->Hi - 1) / 2 + 1 || d->Wo != (d->Wi - 1) / 2 + 1) return 0;
+    const int KS = d->KH;
+    if (!((KS == 3 || KS == 4) && d->KW == KS && d->sh == 2 && d->sw == 2 && d->ph == 1 && d->pw == 1 && d->dh == 1 && d->dw == 1)) return 0;
+    if (KS == 4 && on < 2) return 0;                           // RDFC_T3S2=1: 3x3 only (A/B)
+    if (d->Hi + 2 < KS || d->Wi + 2 < KS || d->Ho != (d->Hi + 2 - KS) / 2 + 1 || d->Wo != (d->Wi + 2 - KS) / 2 + 1) return 0;
     if (d->Co % BK != 0 || d->Ci % 64 != 0 || d->ldy % 8 != 0) return 0;
+    // (small launches stay on igemm_glds' flat 128-pixel tiles: 8 x 16 source tiles x 64 channels leave most CUs empty there --
+    //  256->512 @ 16x30x38: 46 vs 41 us, the 4x4 128->256 @ 8x57x76: 32 vs 28 us)
+    if (on < 3 && cdiv(d->Wo, TC) * cdiv(d->Ho, TRS) * d->N * cdiv(d->Ci, TCO) < 384) return 0;
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
     TParams p{d->N, d->Ho, d->Wo, d->Hi, d->Wi, d->Co, d->Ci, d->ldy, d->ldx, d->act, d->slope, d->out_f32, cdiv(d->Wo, TC), cdiv(d->Ho, TRS),
               addend, ld_add};
-    return d->dtype == RDFC_F16 ? launch<RDFC_F16>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16>(p, src, w_bwd, bias, res, zero, st);
+    if (KS == 4) return d->dtype == RDFC_F16 ? launch<RDFC_F16, 4>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16, 4>(p, src, w_bwd, bias, res, zero, st);
+    return d->dtype == RDFC_F16 ? launch<RDFC_F16, 3>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16, 3>(p, src, w_bwd, bias, res, zero, st);
 }
