@@ -2,7 +2,9 @@
 
 The forward runs N times on the same weights and inputs with a device synchronisation after every call; run 0's tensors are kept
 (inputs and results of every functional call and of every hip.conv_forward / hip.norm_apply launch) and every later run is compared
-with them element by element.  `python tools/rerun_check.py [f16|bf16|f32] [H W] [runs]`."""
+with them element by element.  `python tools/rerun_check.py [f16|bf16|f32] [H W] [runs]`.  Environment: FINAL=1 -- no instrumentation at all,
+only the five results of every run are compared (the fast yes / no); INNER=0 -- wrap the functional calls only, not the launches inside
+them; LIMIT=n -- differing calls reported per run (default 3)."""
 import os
 import sys
 
