@@ -296,7 +296,7 @@ def _geometry(spec, x, weight):
 
 class _ConvBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var):
+    def forward(ctx, x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with=None):
         dtype = x.dtype
         N, H, W, Cin = x.shape
         Cout, Ho, Wo = _geometry(spec, x, weight)
@@ -345,18 +345,20 @@ class _ConvBlock(torch.autograd.Function):
             x_alias = x
         ctx.has_bias = bias is not None
         ctx.bias = bias                    # (a parameter: kept for its .grad, into which the bias gradient accumulates directly)
+        ctx.cat = False
         if not has_norm:
+            assert cat_with is None, 'cat_with: blocks with a normalisation layer only'
             ctx.save_for_backward(x, weight, y if spec.act != 'none' else None)
             return (y, x_alias.view(x_alias.shape)) if spec.passthrough else y
         G = N if spec.norm == 'in' else (len(gm) if gm is not None else 1)
         if spec.norm == 'bn' and not training:
             mean = run_mean.view(1, -1).float()
             rstd = torch.rsqrt(run_var.view(1, -1).float() + spec.eps)
-            z = torch.empty(N, Ho, Wo, Cout, dtype=dtype, device=x.device)
+            z, buf = _out_for_cat(N, Ho, Wo, Cout, dtype, x.device, cat_with)
             hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
         else:
             upd = spec.norm == 'bn' and run_mean is not None
-            z = torch.empty(N, Ho, Wo, Cout, dtype=dtype, device=x.device)
+            z, buf = _out_for_cat(N, Ho, Wo, Cout, dtype, x.device, cat_with)
             if fused is not None:
                 mean, rstd = fused
                 hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
@@ -364,6 +366,11 @@ class _ConvBlock(torch.autograd.Function):
                 mean, rstd = hip.norm_forward(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
                                               run_mean if upd else None, run_var if upd else None, spec.momentum, group_momenta=gm)
         ctx.save_for_backward(x, weight, y, mean, rstd, gamma, beta, res, prelu)
+        if cat_with is not None:            # [block output | cat_with]: the block wrote its channels of the concatenation itself
+            assert not spec.passthrough
+            hip.copy_window(cat_with, buf[..., Cout:])
+            ctx.cat = True
+            return buf
         return (z, x_alias.view(x_alias.shape)) if spec.passthrough else z
 
     @staticmethod
@@ -371,7 +378,10 @@ class _ConvBlock(torch.autograd.Function):
         spec = ctx.spec
         Cout, Ho, Wo = ctx.shapes
         has_norm = spec.norm != 'none'
-        g_gamma = g_beta = g_res = g_prelu = g_bias = None
+        g_gamma = g_beta = g_res = g_prelu = g_bias = g_cat = None
+        if ctx.cat:                          # cotangent of [block output | cat_with]: two channel slices, read in place
+            g_cat = dz[..., Cout:]
+            dz = dz[..., :Cout]
         if has_norm:
             x, weight, y, mean, rstd, gamma, beta, res, prelu = ctx.saved_tensors
             dz = dz if dz.dtype == x.dtype else dz.to(x.dtype)
@@ -448,12 +458,23 @@ class _ConvBlock(torch.autograd.Function):
                 d = hip.conv_desc((N, Ho, Wo, Cout), Cin, spec.k, spec.stride, spec.pad, ldx=hip.ld(dy), ldy=hip.ld(x),
                                   dtype=hip.dt(x), out_hw=(H, W))
                 g_w = _wgrad(d, dy, x, weight, Cin, Cout, spec.k, spec.wscale)     # [O = Cin][T][I = Cout]
-        return g_x, g_w, g_bias, g_gamma, g_beta, g_res, g_prelu, None, None, None, None
+        return g_x, g_w, g_bias, g_gamma, g_beta, g_res, g_prelu, None, None, None, None, g_cat
 
 
 def conv_block(x, weight, bias=None, gamma=None, beta=None, res=None, prelu=None, *, spec, training=True,
-               run_mean=None, run_var=None):
-    return _ConvBlock.apply(x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var)
+               run_mean=None, run_var=None, cat_with=None):
+    """cat_with (blocks with a normalisation layer): return cat((block output, cat_with), channels) -- the normalise pass writes the
+    block's channels of the concatenation directly (no separate copy of them); same shape [N, Ho, Wo, *] required"""
+    return _ConvBlock.apply(x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with)
+
+
+def _out_for_cat(N, Ho, Wo, Cout, dtype, device, cat_with):
+    """-> (where the block writes its output, the concatenation buffer or None)"""
+    if cat_with is None:
+        return torch.empty(N, Ho, Wo, Cout, dtype=dtype, device=device), None
+    assert cat_with.shape[:3] == (N, Ho, Wo) and cat_with.dtype == dtype, (tuple(cat_with.shape), (N, Ho, Wo), cat_with.dtype, dtype)
+    buf = torch.empty(N, Ho, Wo, Cout + cat_with.shape[3], dtype=dtype, device=device)
+    return buf[..., :Cout], buf
 
 
 class _WAdaIN(torch.autograd.Function):

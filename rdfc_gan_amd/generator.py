@@ -48,9 +48,9 @@ class EncoderDecoder(nn.Module):
         assert layer_idx > 1
         return getattr(self, f'en{layer_idx}')(x)
 
-    def forward_decoder_layer(self, x, skip=None, skip_type='concat', layer_idx=2):
+    def forward_decoder_layer(self, x, skip=None, skip_type='concat', layer_idx=2, cat_with=None):
         assert layer_idx > 1
-        return getattr(self, f'de{layer_idx}')(x)
+        return getattr(self, f'de{layer_idx}')(x, cat_with=cat_with)
 
 
 class _EqualLinearHolder(nn.Module):
@@ -140,6 +140,13 @@ class RDFGenerator(nn.Module):
     def forward(self, rgb, depth, normal):
         R, D = self.rgb_branch_encoder_decoder, self.depth_branch_encoder_decoder
         cat = Fh.crop_cat
+
+        def dec_cat(net, f, lvl, skip_f):
+            """decoder level + skip connection (rdf_generator.py:244-260): when the up-sampled map has the skip's size (228 = 2 x 114,
+            114 = 2 x 57: the two largest levels) the level writes its channels of the concatenation itself"""
+            if (2 * f.shape[1], 2 * f.shape[2]) == tuple(skip_f.shape[1:3]):
+                return net.forward_decoder_layer(f, layer_idx=lvl, cat_with=skip_f)
+            return cat(net.forward_decoder_layer(f, layer_idx=lvl), skip_f)
         nrm = Fh.to_pm(normal)                    # `rgb` is accepted but never read (rdf_generator.py:282)
         dep = Fh.to_pm(depth)
         # The depth branch is independent of the RGB branch (the RGB decoder only READS its features): it runs on a second
@@ -189,7 +196,7 @@ class RDFGenerator(nn.Module):
         fuses = (self.fuse_layer1, self.fuse_layer2, self.fuse_layer3, self.fuse_layer4)
         for k, lvl in enumerate((5, 4, 3, 2)):
             with on_side():                                  # depth decoder level `lvl` (its output feeds the NEXT RGB level) ...
-                nxt = cat(D.forward_decoder_layer(df, layer_idx=lvl), skip[lvl])
+                nxt = dec_cat(D, df, lvl, skip[lvl])
                 if lvl == 2:
                     heads = Fh.fanout(nxt, nh)               # the last decoder feature only feeds the heads
                 else:
@@ -197,19 +204,19 @@ class RDFGenerator(nn.Module):
                     dfs.append(publish(ff))
             if two:
                 main.wait_event(ready[k])                    # ... beside RGB decoder level `lvl`, which trails it by one level
-            rf = cat(R.forward_decoder_layer(fuses[k](rf, dfs[k]), layer_idx=lvl), rskip[lvl])
+            rf = dec_cat(R, fuses[k](rf, dfs[k]), lvl, rskip[lvl])
         with on_side():
-            pred_init = self._head(self.id_dec0, cat(self.id_dec1(heads[0]), d1_heads[0]), 'tanh')
-            confidence = self.cf_dec0(cat(self.cf_dec1(heads[1]), d1_heads[1]))
+            pred_init = self._head(self.id_dec0, self.id_dec1(heads[0], cat_with=d1_heads[0]), 'tanh')
+            confidence = self.cf_dec0(self.cf_dec1(heads[1], cat_with=d1_heads[1]))
             if self.use_nlspn_refine:
-                guide = self.gd_dec0(cat(self.gd_dec1(heads[2]), d1_heads[2]))
+                guide = self.gd_dec0(self.gd_dec1(heads[2], cat_with=d1_heads[2]))
                 confidence, conf_prop = Fh.fanout(confidence, 2)
                 depth_map_2 = self.nlspn_refine_module(pred_init, guide, conf_prop, depth)
             else:
                 depth_map_2 = pred_init
         rfa, rfb = Fh.fanout(rf, 2)
-        depth_map_1 = self._head(self.rgb_pred_dec0, cat(self.rgb_pred_dec1(rfa), r1a), 'tanh')
-        confidence_map_1 = self.rgb_conf_dec0(cat(self.rgb_conf_dec1(rfb), r1b))
+        depth_map_1 = self._head(self.rgb_pred_dec0, self.rgb_pred_dec1(rfa, cat_with=r1a), 'tanh')
+        confidence_map_1 = self.rgb_conf_dec0(self.rgb_conf_dec1(rfb, cat_with=r1b))
         if two:
             for t in (depth_map_2, confidence):
                 t.record_stream(main)

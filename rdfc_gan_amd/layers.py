@@ -6,6 +6,8 @@ parameters / buffers -- their own forward is never called.
 """
 import contextlib
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -65,9 +67,10 @@ def _count_batch(norm, k):
 
 
 _spec_cache = {}
+_CAT_INTO = os.environ.get('RDFC_CAT_INTO', '1') != '0'
 
 
-def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False, passthrough=False, reflect=0):
+def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False, passthrough=False, reflect=0, cat_with=None):
     """conv (nn.Conv2d | nn.ConvTranspose2d) [+ norm (BatchNorm2d | InstanceNorm2d)] [+ res] [+ act module]"""
     # the static description of the block is the same on every call of the same modules: cache it (a train step runs
     # ~180 blocks, each used to rebuild its ConvSpec from a dozen attribute lookups)
@@ -83,7 +86,7 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False, passthrough=
             if training and norm.num_batches_tracked is not None:
                 _count_batch(norm, sum(BN_GROUP_REPEATS) if BN_GROUP_REPEATS else BN_STAT_REPEAT)
         return Fh.conv_block(x, conv.weight, conv.bias, gamma, beta, res, prelu, spec=spec, training=training,
-                             run_mean=rm, run_var=rv)
+                             run_mean=rm, run_var=rv, cat_with=cat_with)
     transposed = isinstance(conv, nn.ConvTranspose2d)
     aname, slope, prelu = _act_of(act)
     if norm is None:
@@ -118,21 +121,25 @@ def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False, passthrough=
             _count_batch(norm, sum(BN_GROUP_REPEATS) if BN_GROUP_REPEATS else BN_STAT_REPEAT)
     _spec_cache[key] = (conv, norm, act, spec, nname, prelu)
     return Fh.conv_block(x, conv.weight, conv.bias, gamma, beta, res, prelu, spec=spec, training=training,
-                         run_mean=rm, run_var=rv)
+                         run_mean=rm, run_var=rv, cat_with=cat_with)
 
 
 class ConvSeq(nn.Sequential):
     """nn.Sequential(conv, [norm], [act]) as built by upstream's conv_bn_relu / convt_bn_relu
     (encoder_decoder/common.py:29-61); forward = one fused block."""
 
-    def forward(self, x, res=None, out_f32=False):
+    def forward(self, x, res=None, out_f32=False, cat_with=None):
+        """cat_with: -> cat((block(x), cat_with), channels) with the block writing its part of the concatenation in place (blocks with a
+        normalisation layer, equal map sizes; RDFC_CAT_INTO=0: a separate concatenation pass, for A/B runs)"""
+        if cat_with is not None and not _CAT_INTO:
+            return Fh.crop_cat(self.forward(x, res, out_f32), cat_with)
         conv, norm, act = self[0], None, None
         for m in list(self)[1:]:
             if isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d)):
                 norm = m
             else:
                 act = m
-        return run_conv(x, conv, norm, act, res, out_f32)
+        return run_conv(x, conv, norm, act, res, out_f32, cat_with=cat_with)
 
 
 def conv_bn_relu(cin, cout, kernel, stride=1, padding=0, bn=True, _in=False, relu=True):
