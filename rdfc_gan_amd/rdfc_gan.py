@@ -423,6 +423,14 @@ class RDFCGAN:
     def _forward_batched(self):
         """forward() of the batched schedule: fake_B | rec_B from one G_A2B pass, fake_A | rec_A from one G_B2A pass"""
         B = self.real_B.shape[0]
+        # The pepper mask of fake_B (helper.py:384-402, a host RNG draw of B x H x W doubles: 1.5 ms) does not depend on fake_B: draw and
+        # upload it BEFORE G_A2B's forward is enqueued, not between that forward and the cycle pass where the host stalls with nothing
+        # queued behind the generator.  Nothing between here and upstream's draw point consumes python / numpy random numbers, so the
+        # stream positions -- and the image pools' draws after it -- are unchanged.
+        self._pepper_pre = None
+        if not getattr(self, '_graph_mode', False) and not self.device_pepper:
+            mask = draw_pepper_mask((B, 1) + tuple(self.real_B.shape[2:]))
+            self._pepper_pre = (None if mask is None else self._mask_to_device(mask),)
         self.fake_normal_realA = self._normal('real_A', self.real_A)
         self.fake_normal_fakeA = self._normal('fake_A', None)
         normal_again = self._normal('fake_A_again', None)
@@ -459,6 +467,9 @@ class RDFCGAN:
                 mask = hip.draw_pepper_mask(b, h, w, self._pepper_seed + 7919 * self.local_rank, self._pepper_calls, 0.98, self.device)
                 return _PepperNoise.apply(fake_B, mask)
             return fake_B
+        pre, self._pepper_pre = getattr(self, '_pepper_pre', None), None
+        if pre is not None:                  # drawn at the top of _forward_batched
+            return fake_B if pre[0] is None else _PepperNoise.apply(fake_B, pre[0])
         mask = draw_pepper_mask(fake_B.shape)
         return fake_B if mask is None else _PepperNoise.apply(fake_B, self._mask_to_device(mask))
 
