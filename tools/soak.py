@@ -6,13 +6,14 @@ import torch, bench
 from rdfc_gan_amd import functional as Fh
 from rdfc_gan_amd.rdfc_gan import RDFCGAN
 dev = torch.device('cuda', 0)
-Fh.set_compute_dtype(torch.bfloat16)
+Fh.set_compute_dtype(dict(bf16=torch.bfloat16, f16=torch.float16)[os.environ.get('SOAK_DTYPE', 'f16')])
 m = RDFCGAN(dev, False, bench.model_cfg(False), is_train=True); m.train()
 batches = [bench.synth_batch(8, 228, 304, 1234 + i, dev) for i in range(2)]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 for i in range(n):
     m.set_input(batches[i % 2]); ls = m.optimize_parameters(sync_losses=(i % 20 == 19))
-    if i % 20 == 19:
+    if i % 20 == 19 and (i + 1) % (100 if n > 400 else 20) == 0:
         torch.cuda.synchronize()
         print(f'step {i+1}: allocated {torch.cuda.memory_allocated()/2**30:.2f} GiB, reserved {torch.cuda.memory_reserved()/2**30:.2f} GiB, '
-              f'peak {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, loss_G {ls["loss_G"]:.3f}')
+              f'peak {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, loss_G {ls["loss_G"]:.3f}'
+              + (f', loss scale {m.scaler.scale():.0f}, skipped {m.scaler.skipped()}' if m.scaler is not None else ''))
