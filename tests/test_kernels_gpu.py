@@ -382,7 +382,7 @@ def test_fusion_head_losses_adam_pepper():
                 ref = (wt * fn(ar, b)).sum()
                 (ref * 3.0).backward()
                 val, grad = h.weighted_loss(a.to(DEV), b.to(DEV), ww.to(DEV) if ww is not None else None, kind, True, 3.0)
-                assert abs(float(val) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+                assert abs(float(val) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
                 assert rel_err(grad, ar.grad) < 1e-5
     p = rnd(2, 1, 26, 36, seed=5)
     val, grad = h.weighted_loss(p.to(DEV), 1.0, None, 2, True, 1.0)
