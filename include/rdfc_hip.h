@@ -201,8 +201,15 @@ int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const 
                         const float *beta, const void *res, const float *sums, void *dx, void *dres,
                         int G, int P, int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype,
                         int act, float slope, const float *prelu, int frozen_stats, void *stream);
-/* One layer's launches behind one call (same kernels, order and stream as the three calls they stand for; the step is partly
- * launch-bound).  scratch: f32 [G * rdfc_norm_nchunk(P, C, dtype) * 2 * C] (forward) / [... * 3 * C] (backward). */
+/* One layer's launches behind one call.  Round 4: the finalize of every two-stage reduction is done by the reduction launch's
+ * LAST-ARRIVING workgroup (csrc/fold.h: write-through partial rows, one agent-scope ticket per workgroup, two levels of fixed-order
+ * f64 sums -- bitwise reproducible like the separate finalize launches these calls used to make, which the three-call sequences
+ * above still do).  scratch: f32 [rdfc_fold_scratch_floats(G, rdfc_norm_nchunk(P, C, dtype), K, C)], K = 2 (forward) / 3 (backward):
+ * the partial rows + the level-2 rows. */
+int rdfc_fold_scratch_floats(int G, int nchunk, int K, int C);
+/* statistics only (W-AdaIN's instance norm of the content map, model_utils.py:86): mean / rstd [G][C] (+ running statistics, G == 1) */
+int rdfc_norm_stats_final(const void *x, float *scratch, float *mean, float *rstd, int G, int P, int C, int ld, int dtype, float eps,
+                          float *run_mean, float *run_var, float momentum, void *stream);
 int rdfc_norm_forward(const void *x, float *scratch, float *mean, float *rstd, const float *gamma, const float *beta,
                       const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
                       float *run_mean, float *run_var, float momentum, int act, float slope, const float *prelu, void *stream);
@@ -211,6 +218,14 @@ int rdfc_norm_forward_seq(const void *x, float *scratch, float *mean, float *rst
                           const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
                           float *run_mean, float *run_var, const float *group_momentum, int act, float slope,
                           const float *prelu, void *stream);
+/* The part of rdfc_norm_forward_seq behind the partial rows (round 4): statistics per group in parallel (one small workgroup per
+ * (group, 32 channels)), then the normalise pass, ONE thread per channel of which also advances the running statistics once per
+ * group in group order -- rdfc_norm_finalize_seq walks the groups inside one workgroup instead.  partial: [G][nchunk][2][C] from
+ * rdfc_norm_stats (nchunk 0: derived from (P, C, dtype)) or rdfc_conv2d_forward_stats; muvar: f64 [G][2][C] scratch. */
+int rdfc_norm_finalize_apply_seq(const float *partial, int nchunk, double *muvar, const void *x, float *mean, float *rstd,
+                                 const float *gamma, const float *beta, const void *res, void *z, int G, int P, int C, int ldx,
+                                 int ldr, int ldz, int dtype, float eps, float *run_mean, float *run_var,
+                                 const float *group_momentum, int act, float slope, const float *prelu, void *stream);
 int rdfc_norm_backward(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
                        const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P, int C,
                        int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope, const float *prelu,
@@ -225,8 +240,14 @@ int rdfc_adain_bwd_apply(const void *dout, const void *x, const float *mean, con
                          const float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx,
                          int ldgb, int lddx, int lddgb, int dtype, void *stream);
 
+/* sums + apply of the W-AdaIN backward in one call; scratch: f32 [rdfc_fold_scratch_floats(N, rdfc_norm_nchunk(P, C, dtype), 3, C)], sums f32 [N][3][C] */
+int rdfc_adain_backward(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb, float *scratch,
+                        float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx, int ldgb, int lddx, int lddgb,
+                        int dtype, void *stream);
+
 /* per-channel sum over all pixels (bias gradient): out[C] = sum_p x[p, c].
- * partial: scratch of min(4096, P) * C floats (upper bound on the chunk count of either code path). */
+ * partial: scratch of rdfc_channel_sum_scratch_floats(P, C, ld, dtype) floats. */
+int rdfc_channel_sum_scratch_floats(int P, int C, int ld, int dtype);
 int rdfc_channel_sum(const void *x, float *partial, float *out, int P, int C, int ld, int dtype, void *stream);
 /* same, and acc[c] += out[c] (f32, may be NULL): the bias gradient lands in the parameter's persistent .grad without a pass of
  * autograd's own (torch accumulates a returned gradient with a stock elementwise add) */

@@ -1,13 +1,19 @@
-// conv_thin_in.hip -- convolutions that READ at most 4 channels and produce a wide map (bf16, MFMA).
+// conv_thin_in.hip -- convolutions that READ at most 4 channels and produce a wide map (2-byte elements, MFMA).
 //
-// The 1- / 3-channel input layers (RDFGenerator's first convs, ResnetGenerator's 7x7 stem, PatchGAN's first 4x4
-// stride-2 conv) and the input-gradients of the 1- / 3-channel output layers (heads, 7x7 output conv):
+// The 1- / 3-channel input layers (RDFGenerator's first convs rdf_generator.py:286-292, ResnetGenerator's 7x7 stem
+// resnet_generator.py:19-22, PatchGAN's first 4x4 stride-2 conv patch_gan_discriminator.py:22-26) and the input-gradients of the
+// 1- / 3-channel output layers (7x7 output conv resnet_generator.py:48-51):
 //     out[p][co] = sum over k = (tap, c) of  T[p*s + r(tap)][c] * w[co][k],      K = taps * ct <= 160.
-// On the generic kernel the K loop gathers every (pixel, k) element with a scalar 2-byte global load.  Here a
-// workgroup stages the thin map's halo patch of a 16x16 output tile (a few KB) and the whole weight matrix
-// [Cout][K] in LDS; B fragments (8 consecutive k of one pixel per lane) are gathered from the patch with 16-bit
-// LDS reads through a per-lane offset table, A fragments are plain ds_read_b128.  Workgroups are persistent
-// (grid-stride over tiles) so the weights are staged once.  The layer is bound by writing its wide output.
+// The arithmetic is nothing (K <= 160 against 2 * Cout bytes written per pixel): the layer is bound by WRITING its wide output, and what
+// has to be avoided is latency -- round 3's kernel staged a 16 x 16 tile's patch with a loop of dependent 2-byte loads between two
+// workgroup barriers and ran the 3 <- 64 7x7 input gradient at 0.46 TB/s (324 us for 142 MB), the stems at 0.8 TB/s.
+//
+// Round 4: every WAVE works alone.  A wave owns tasks of 4 rows x 16 columns of output pixels; it keeps the task's halo patch of the
+// thin map ((3 s + KH) x (15 s + KW) pixels, 0.6-2 KB) in its own slice of LDS, fetches the NEXT task's patch into registers before it
+// computes the current one (so the global latency sits under the gathers / MFMAs / stores), and shares only the weight matrix
+// [Cout][K] (staged once per workgroup) with the other waves -- no barrier after the prologue, 16 waves per CU at different points of
+// their tasks.  B fragments (8 consecutive k of one pixel per lane) are gathered from the patch with 16-bit LDS reads through a
+// per-lane offset table, A fragments are plain ds_read_b128.
 #include "common.h"
 
 #include <stdlib.h>
@@ -20,44 +26,54 @@ struct TIParams {
     int KH, KW, s;                 // taps, stride of the source position per output pixel
     int oy, ox, flip;              // patch origin = tile origin * s + (oy, ox); flip: tap (ky,kx) reads patch (KH-1-ky, KW-1-kx)
     int K, KS;                     // real K = KH*KW*ct, k-steps of 32
-    int PH, PW;                    // patch extent in pixels
-    int tiles_x, tiles_y, ntiles;
+    int PH, PW;                    // patch extent in pixels (per wave task)
+    int tiles_x, tiles_y, ntasks;
     int act, out_f32;
     float slope;
 };
 
+constexpr int TROWS = 4, TCOLS = 16;        // output pixels of a wave task
+constexpr int MAXE = 16;                    // patch elements per lane (64 * 16 = 1024 elements = 2 KB per wave)
+constexpr int MAXKS = 5;
+
 template <int MF, int DT = RDFC_BF16>   // output-channel fragments per wave: Cout <= 16 * MF
-__global__ __launch_bounds__(256) void thin_in_kernel(TIParams p, const bf16_t *__restrict__ t, const bf16_t *__restrict__ w,
+__global__ __launch_bounds__(256, 2) void thin_in_kernel(TIParams p, const bf16_t *__restrict__ t, const bf16_t *__restrict__ w,
                                                       const float *__restrict__ bias, void *__restrict__ yout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int KP = p.KS * 32, WLD = KP + 8;                       // padded weight row (elements)
     bf16_t *Wl = reinterpret_cast<bf16_t *>(smem);                 // [16*MF][WLD]
-    unsigned short *Tl = reinterpret_cast<unsigned short *>(Wl + 16 * MF * WLD);   // [PH*PW*ct] (+8 slack)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned short *Kt = reinterpret_cast<unsigned short *>(Wl + 16 * MF * WLD);                               // [MAXKS][4][8] gather offsets
+    unsigned short *Tl = Kt + MAXKS * 32 + wave * (64 * MAXE + 8);                                            // this wave's patch
 
-    // ---- weights: w[co][K] -> Wl[co][KP], zero padded ---------------------------------------------------------------
+    // ---- weights: w[co][K] -> Wl[co][KP], zero padded (once per workgroup) -------------------------------------------
     for (int e = tid; e < 16 * MF * KP; e += 256) {
         const int co = e / KP, k = e - co * KP;
         bf16_t v = (bf16_t)0.f;
         if (co < p.Cout && k < p.K) v = w[(size_t)co * p.K + k];
         Wl[co * WLD + k] = v;
     }
-    // ---- per-lane gather offsets: element offset of k inside the patch, for k = 32 ks + 8 (lane>>4) + j --------------
-    constexpr int MAXKS = 5;
-    int koff[MAXKS][8];
-#pragma unroll
-    for (int ks = 0; ks < MAXKS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = ks * 32 + 8 * (lane >> 4) + j;
-            int o = 0;
-            if (ks < p.KS && k < p.K) {
-                const int tap = k / p.ct, c = k - tap * p.ct, ky = tap / p.KW, kx = tap - ky * p.KW;
-                const int pr = p.flip ? p.KH - 1 - ky : ky, pc = p.flip ? p.KW - 1 - kx : kx;
-                o = (pr * p.PW + pc) * p.ct + c;
-            }
-            koff[ks][j] = o;                                       // k >= K: any valid element (its weight column is zero)
+    // ---- gather offsets: element offset of k inside the patch, table [ks][k-group of 8][8] (a lane reads its 8 with one ds_read_b128) ---
+    const int prow = p.PW * p.ct;                                  // elements per patch row
+    for (int k = tid; k < MAXKS * 32; k += 256) {
+        int o = 0;
+        if (k < p.K) {
+            const int tap = k / p.ct, c = k - tap * p.ct, ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int pr = p.flip ? p.KH - 1 - ky : ky, pc = p.flip ? p.KW - 1 - kx : kx;
+            o = pr * prow + pc * p.ct + c;
         }
+        Kt[k] = (unsigned short)o;                                 // k >= K: any valid element (its weight column is zero)
+    }
+    __syncthreads();                                               // the only workgroup barrier
+    // ---- per-lane staging geometry: patch element e = lane + 64 i -> (row, column, channel) packed, task independent ---------------
+    const int ne = p.PH * prow;                                    // <= 64 * MAXE (host)
+    int sgeo[MAXE];                                                // row << 16 | col << 2 | c; row = 0x7fff: no element
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int e = lane + 64 * i;
+        const int row = e / prow, rem = e - row * prow, col = rem / p.ct, c = rem - col * p.ct;
+        sgeo[i] = e < ne ? (row << 16 | col << 2 | c) : (0x7fff << 16);
+    }
     const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
     const int q4 = (lane >> 4) * 4;
     float bv[MF][4];
@@ -68,61 +84,62 @@ __global__ __launch_bounds__(256) void thin_in_kernel(TIParams p, const bf16_t *
             const int co = 16 * i + q4 + r;
             bv[i][r] = (bias != nullptr && co < p.Cout) ? bias[co] : 0.f;
         }
-    const int prow = p.PW * p.ct;                                  // elements per patch row
+    const unsigned short *tsrc = reinterpret_cast<const unsigned short *>(t);
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        int tt = tile;
+    const int wstride = gridDim.x * 4;
+    int task = blockIdx.x * 4 + wave;
+    unsigned short pre[MAXE];
+    auto fetch = [&](int tk) {                                     // the patch of task tk -> registers (loads stay in flight)
+        int tt = tk;
         const int tx = tt % p.tiles_x;
         tt /= p.tiles_x;
         const int ty = tt % p.tiles_y, n = tt / p.tiles_y;
-        const int y0 = ty * 16, x0 = tx * 16;
-        __syncthreads();                                           // previous tile's gathers are done (and Wl is written)
-        // ---- stage the patch: rows of PW*ct contiguous elements ---------------------------------------------------
-        for (int row = wave; row < p.PH; row += 4) {
-            const int gy = y0 * p.s + p.oy + row;
-            const bool rok = (unsigned)gy < (unsigned)p.Ht;
-            const int gx0 = x0 * p.s + p.ox;
-            const unsigned short *src = reinterpret_cast<const unsigned short *>(t) + ((size_t)(n * p.Ht + (rok ? gy : 0)) * p.Wt) * p.ldt;
-            for (int e = lane; e < prow; e += 64) {
-                const int col = e / p.ct, c = e - col * p.ct, gx = gx0 + col;
-                unsigned short v = 0;
-                if (rok && (unsigned)gx < (unsigned)p.Wt) v = src[(size_t)gx * p.ldt + c];
-                Tl[row * prow + e] = v;
-            }
+        const int gy0 = ty * TROWS * p.s + p.oy, gx0 = tx * TCOLS * p.s + p.ox;
+        const unsigned short *base = tsrc + ((long)(n * p.Ht + gy0) * p.Wt + gx0) * p.ldt;
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) {
+            const int row = sgeo[i] >> 16, col = (sgeo[i] >> 2) & 0x3fff, c = sgeo[i] & 3;
+            const bool ok = (unsigned)(gy0 + row) < (unsigned)p.Ht && (unsigned)(gx0 + col) < (unsigned)p.Wt;
+            pre[i] = ok ? base[(row * p.Wt + col) * p.ldt + c] : (unsigned short)0;
         }
-        __syncthreads();
-
-        f32x4 acc[MF][4];
+    };
+    if (task < p.ntasks) fetch(task);
+    for (; task < p.ntasks; task += wstride) {
+        int tt = task;
+        const int tx = tt % p.tiles_x;
+        tt /= p.tiles_x;
+        const int ty = tt % p.tiles_y, n = tt / p.tiles_y;
+        const int y0 = ty * TROWS, x0 = tx * TCOLS;
+        // registers -> this wave's LDS patch (the previous task's gathers were issued before these stores: same wave, in order)
 #pragma unroll
-        for (int i = 0; i < MF; ++i)
+        for (int i = 0; i < MAXE; ++i)
+            if (lane + 64 * i < ne) Tl[lane + 64 * i] = pre[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (task + wstride < p.ntasks) fetch(task + wstride);      // next patch: in flight under this task's work
+#pragma unroll 1
+        for (int j = 0; j < TROWS; ++j) {
+            f32x4 acc[MF];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-        int pbase[4];                                              // patch element of this lane's pixel in row-fragment j
+            for (int i = 0; i < MF; ++i) acc[i] = f32x4{0, 0, 0, 0};
+            const int pbase = (j * p.s * p.PW + (lane & 15) * p.s) * p.ct;
+#pragma unroll 1
+            for (int ks = 0; ks < p.KS; ++ks) {
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+                const u16x8 ko = *reinterpret_cast<const u16x8 *>(Kt + ks * 32 + 8 * (lane >> 4));
+                s16x8 bvv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pbase[j] = ((4 * wave + j) * p.s * p.PW + (lane & 15) * p.s) * p.ct;
+                for (int e = 0; e < 8; ++e) bvv[e] = (short)Tl[pbase + ko[e]];
+                const bf16x8 b = __builtin_bit_cast(bf16x8, bvv);
 #pragma unroll
-        for (int ks = 0; ks < MAXKS; ++ks) {
-            if (ks < p.KS) {
-                bf16x8 a[MF];
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-                    a[i] = *reinterpret_cast<const bf16x8 *>(Wl + (16 * i + (lane & 15)) * WLD + ks * 32 + 8 * (lane >> 4));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    s16x8 bvv;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bvv[e] = (short)Tl[pbase[j] + koff[ks][e]];
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, bvv);
-#pragma unroll
-                    for (int i = 0; i < MF; ++i) acc[i][j] = mma16<DT>(a[i], b, acc[i][j]);
+                for (int i = 0; i < MF; ++i) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Wl + (16 * i + (lane & 15)) * WLD + ks * 32 + 8 * (lane >> 4));
+                    acc[i] = mma16<DT>(a, b, acc[i]);
                 }
             }
-        }
-        // ---- epilogue: lane holds channels 16 i + q4 .. +3 of pixel (row 4*wave + j, col lane & 15) ------------------
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int oy = y0 + 4 * wave + j, ox = x0 + (lane & 15);
+            // ---- epilogue: lane holds channels 16 i + q4 .. +3 of pixel (row y0 + j, col x0 + (lane & 15)) ------------------
+            const int oy = y0 + j, ox = x0 + (lane & 15);
             if (oy >= p.Ho || ox >= p.Wo) continue;
             const size_t po = ((size_t)(n * p.Ho + oy) * p.Wo + ox) * p.ld_out;
 #pragma unroll
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(TIParams p, const bf16_t *
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float u = acc[i][j][r] + bv[i][r];
+                    const float u = acc[i][r] + bv[i][r];
                     v[r] = u > 0.f ? u : u * ns;
                 }
                 if (p.out_f32) {
@@ -153,15 +170,17 @@ __global__ __launch_bounds__(256) void thin_in_kernel(TIParams p, const bf16_t *
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();                           // (compiler: the gathers above stay above the next task's patch stores)
     }
 }
 
 template <int MF>
 int launch(const TIParams &p, const void *t, const void *w, const float *bias, void *y, hipStream_t st, int dtype) {
     const int KP = p.KS * 32, WLD = KP + 8;
-    const size_t smem = (size_t)16 * MF * WLD * 2 + ((size_t)p.PH * p.PW * p.ct + 8) * 2;
+    const size_t smem = (size_t)16 * MF * WLD * 2 + (size_t)MAXKS * 32 * 2 + (size_t)4 * (64 * MAXE + 8) * 2;
     if (smem > 64 * 1024) return 0;
-    int blocks = p.ntiles < 1024 ? p.ntiles : 1024;
+    const int wtasks = cdiv(p.ntasks, 4);
+    int blocks = wtasks < 2048 ? wtasks : 2048;                    // 8 workgroups per CU at most; every wave then walks >= 1 task
     rdfc_note_kernel("thin_in_kernel<%d, %d>", MF, dtype);
     if (dtype == RDFC_F16) hipLaunchKernelGGL((thin_in_kernel<MF, RDFC_F16>), dim3(blocks), dim3(256), smem, st, p, (const bf16_t *)t, (const bf16_t *)w, bias, y);
     else hipLaunchKernelGGL((thin_in_kernel<MF, RDFC_BF16>), dim3(blocks), dim3(256), smem, st, p, (const bf16_t *)t, (const bf16_t *)w, bias, y);
@@ -198,18 +217,15 @@ int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *i
     p.flip = transposed;
     p.K = d->KH * d->KW * Cin;
     p.KS = (p.K + 31) / 32;
-    if (p.KS > 5) return 0;
-    p.PH = 15 * p.s + d->KH;
-    p.PW = 15 * p.s + d->KW;
-    p.tiles_x = cdiv(p.Wo, 16);
-    p.tiles_y = cdiv(p.Ho, 16);
-    p.ntiles = p.tiles_x * p.tiles_y * d->N;
-    if (p.ntiles < 64) return 0;
-    // A/B on one device (tools/thin_in_bench.sh): wins on the 7x7 layers (3<-64 input gradient 138 vs 236 us, 1->64 stem
-    // 85 vs 112 us) and on 16-channel outputs (30 vs 35 us); the 3x3 / 4x4 layers with 48-128 output channels are a tie
-    // or slightly behind the generic kernel (per-tile latency: stage, barrier, compute, store do not overlap yet)
-    static const bool all = getenv("RDFC_THIN_IN_ALL") != nullptr;
-    if (!all && d->KH * d->KW <= 16 && Cout > 16) return 0;
+    if (p.KS > MAXKS) return 0;
+    p.PH = (TROWS - 1) * p.s + d->KH;
+    p.PW = (TCOLS - 1) * p.s + d->KW;
+    if (p.PH * p.PW * p.ct > 64 * MAXE) return 0;
+    if ((double)p.N * p.Ht * p.Wt * p.ldt >= 2.0e9) return 0;
+    p.tiles_x = cdiv(p.Wo, TCOLS);
+    p.tiles_y = cdiv(p.Ho, TROWS);
+    p.ntasks = p.tiles_x * p.tiles_y * d->N;
+    if (p.ntasks < 256) return 0;
     p.act = d->act;
     p.out_f32 = d->out_f32;
     p.slope = d->slope;

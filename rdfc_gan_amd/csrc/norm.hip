@@ -9,6 +9,7 @@
 // Reductions are two-stage (per-chunk partials, then a fixed-order finalize in f64):
 // deterministic, no atomics.
 #include "common.h"
+#include "fold.h"
 
 #include <stdlib.h>
 
@@ -144,7 +145,7 @@ __device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K]
         float a = 0.f;
         for (int r = 0; r < RPB; ++r) a += red[(k * NT + r * CVT + cvt) * VEC + v];
         const int c = cbase + cvv;
-        partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + c] = a;
+        fold::st_f32(&partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + c], a);      // write-through: read by the last-arriving workgroup (fold.h)
     }
 }
 
@@ -164,8 +165,63 @@ __device__ __forceinline__ void load_consts(const float *__restrict__ p, int idx
 }
 
 // ------------------------------------------------------------------------------------------
+// BatchNorm over G stacked batches (several calls of the same layer run as one launch, rdfc_gan.py's batched schedule):
+// every group gets its own statistics; the running statistics advance once per group, in group order, each with its own
+// momentum -- exactly what G separate forwards would leave behind.
+constexpr int MAXSEQ = 8;
+struct Moms { float m[MAXSEQ]; };
+
+// what the last-arriving workgroup of a statistics launch does with the totals (fold.h): mean / rstd per (group, channel), and the
+// running statistics -- one group (nn.BatchNorm2d) or `seq` stacked groups advanced in group order by the workgroup that finishes last
+struct FinStats {
+    float *mean, *rstd;
+    float eps;
+    float *run_mean, *run_var;
+    float momentum;
+    int seq;
+    Moms moms;
+    double *muvar;          // seq with running statistics: [G][2][C] (mean, biased variance) handed to the last group's finisher
+    unsigned *cnt_all;      // ... and its arrival counter
+};
+
+__device__ inline void finish_stats(const fold::Args &fa, const FinStats &fs, int G, int P, int C, int g, int chunk, const float *partial) {
+    const bool want_run = fs.run_mean != nullptr;
+    const bool last = fold::arrive<2>(fa, g, chunk, C, partial + (size_t)g * fa.nchunk * 2 * C, [&](int c, const double (&s)[2]) {
+        const double mu = s[0] / P;
+        double var = s[1] / P - mu * mu;
+        if (var < 0) var = 0;
+        fs.mean[g * C + c] = (float)mu;
+        fs.rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)fs.eps));
+        if (!want_run) return;
+        if (!fs.seq) {                 // batch norm, one group: nn.BatchNorm2d running statistics
+            const double unb = P > 1 ? var * P / (P - 1) : var;
+            fs.run_mean[c] = (float)((1.0 - fs.momentum) * fs.run_mean[c] + fs.momentum * mu);
+            fs.run_var[c] = (float)((1.0 - fs.momentum) * fs.run_var[c] + fs.momentum * unb);
+        } else {
+            fold::st_f64(fs.muvar + ((size_t)g * 2 + 0) * C + c, mu);
+            fold::st_f64(fs.muvar + ((size_t)g * 2 + 1) * C + c, var);
+        }
+    });
+    if (!last || !fs.seq || !want_run) return;
+    __shared__ unsigned s_word;
+    if (fold::arrive_ticket(fs.cnt_all, &s_word) != (unsigned)(G - 1)) return;
+    fold::acquire_all();
+    if (threadIdx.x == 0) __hip_atomic_store(fs.cnt_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double rm = fs.run_mean[c], rv = fs.run_var[c];
+        for (int q = 0; q < G; ++q) {
+            const double mu = fold::ld_f64(fs.muvar + ((size_t)q * 2 + 0) * C + c), var = fold::ld_f64(fs.muvar + ((size_t)q * 2 + 1) * C + c);
+            const double unb = P > 1 ? var * P / (P - 1) : var, mom = fs.moms.m[q];
+            rm = (double)(float)((1.0 - mom) * rm + mom * mu);          // rounded to f32 per update, like G separate launches
+            rv = (double)(float)((1.0 - mom) * rv + mom * unb);
+        }
+        fs.run_mean[c] = (float)rm;
+        fs.run_var[c] = (float)rv;
+    }
+}
+
 template <typename T>
-__global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ x, int ld, float *__restrict__ partial) {
+__global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ x, int ld, float *__restrict__ partial, fold::Args fa, FinStats fs) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[2][VEC];
@@ -186,6 +242,7 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
         ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 2>(cx, m, s, partial);
+    if (fa.cnt != nullptr) finish_stats(fa, fs, m.G, m.P, m.C, cx.g, cx.chunk, partial);
 }
 
 // fixed-order sum over the chunk partials of one (group, k, channel): 32 channels x FL lanes per workgroup,
@@ -241,11 +298,6 @@ __global__ __launch_bounds__(FNT) void stats_finalize_kernel(Map m, int nchunk, 
     }
 }
 
-// BatchNorm over G stacked batches (several calls of the same layer run as one launch, rdfc_gan.py's batched schedule):
-// every group gets its own statistics; the running statistics advance once per group, in group order, each with its own
-// momentum -- exactly what G separate forwards would leave behind.
-constexpr int MAXSEQ = 8;
-struct Moms { float m[MAXSEQ]; };
 __global__ __launch_bounds__(FNT) void stats_finalize_seq_kernel(Map m, int nchunk, const float *__restrict__ partial,
                                                                 float *__restrict__ mean, float *__restrict__ rstd, float eps,
                                                                 float *run_mean, float *run_var, Moms moms) {
@@ -276,6 +328,35 @@ __global__ __launch_bounds__(FNT) void stats_finalize_seq_kernel(Map m, int nchu
     }
 }
 
+// Round 4: the same per (group, 32 channels) -- grid (C / 32, G) instead of one workgroup walking the groups -- which leaves the
+// in-order update of the running statistics to ONE thread per channel of the normalise pass that follows (apply_kernel, RunUpd): it
+// reads every group's (mean, biased variance) in f64 from muvar[G][2][C].  13.9 -> ~6 us per launch at two stacked batches.
+__global__ __launch_bounds__(FNT) void stats_finalize_par_kernel(Map m, int nchunk, const float *__restrict__ partial,
+                                                                float *__restrict__ mean, float *__restrict__ rstd, float eps,
+                                                                double *__restrict__ muvar) {
+    __shared__ double red[FL * 32];
+    const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const double s1 = chunk_sum(partial, g, 2, 0, m.C, c, nchunk, red);
+    const double s2 = chunk_sum(partial, g, 2, 1, m.C, c, nchunk, red);
+    if (threadIdx.x >= 32 || c >= m.C) return;
+    const double mu = s1 / m.P;
+    double var = s2 / m.P - mu * mu;
+    if (var < 0) var = 0;
+    mean[g * m.C + c] = (float)mu;
+    rstd[g * m.C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (muvar != nullptr) {
+        muvar[((size_t)g * 2 + 0) * m.C + c] = mu;
+        muvar[((size_t)g * 2 + 1) * m.C + c] = var;
+    }
+}
+
+// running statistics of a BatchNorm over G stacked batches, advanced in group order by the normalise pass (see above)
+struct RunUpd {
+    float *run_mean, *run_var;      // nullptr: nothing to do
+    const double *muvar;            // [G][2][C]
+    Moms moms;
+};
+
 struct ApplyArgs {
     const float *mean, *rstd, *gamma, *beta, *prelu;
     int act;            // none | relu | lrelu | prelu only: all piecewise linear -> act(u) = u > 0 ? u : u * neg_slope
@@ -287,10 +368,25 @@ __device__ inline float neg_slope_of(const ApplyArgs &a) {
 
 template <typename T>
 __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *__restrict__ x, const T *__restrict__ res,
-                                                   T *__restrict__ z, int ldx, int ldr, int ldz) {
+                                                   T *__restrict__ z, int ldx, int ldr, int ldz, RunUpd ru) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     if (!cx.active) return;
+    if (ru.run_mean != nullptr && cx.chunk == 0 && cx.g == 0 && cx.r0 == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int c = cx.c0 + v;
+            double rm = ru.run_mean[c], rv = ru.run_var[c];
+            for (int g = 0; g < m.G; ++g) {
+                const double mu = ru.muvar[((size_t)g * 2 + 0) * m.C + c], var = ru.muvar[((size_t)g * 2 + 1) * m.C + c];
+                const double unb = m.P > 1 ? var * m.P / (m.P - 1) : var, mom = ru.moms.m[g];
+                rm = (double)(float)((1.0 - mom) * rm + mom * mu);          // rounded to f32 per update, like G separate launches
+                rv = (double)(float)((1.0 - mom) * rv + mom * unb);
+            }
+            ru.run_mean[c] = (float)rm;
+            ru.run_var[c] = (float)rv;
+        }
+    }
     float sc[VEC], sh[VEC];
     {                                   // per-channel constants by 16-byte loads
         float gav[VEC], bev[VEC], rsv[VEC], muv[VEC];
@@ -321,11 +417,23 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
         ROW_LOOP(cx, body);
 }
 
+// the last-arriving workgroup of a per-channel sum launch (fold.h): sums[g][k][c] = totals; optionally acc[c] += total of k = 0 (one
+// group: a bias gradient straight into its .grad; atomic because a parameter's two uses per step may run their backward on
+// different streams)
+template <int K>
+__device__ inline void finish_sums(const fold::Args &fa, int C, int g, int chunk, const float *partial, float *sums, float *acc0) {
+    fold::arrive<K>(fa, g, chunk, C, partial + (size_t)g * fa.nchunk * K * C, [&](int c, const double (&s)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sums[((size_t)g * K + k) * C + c] = (float)s[k];
+        if (acc0 != nullptr) atomicAdd(&acc0[c], (float)s[0]);
+    });
+}
+
 // backward pass 1: sums of du, du*xhat, dz*min(u,0)
 template <typename T>
 __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
                                                         const T *__restrict__ res, float *__restrict__ partial, int lddz,
-                                                        int ldx, int ldr) {
+                                                        int ldx, int ldr, fold::Args fa, float *__restrict__ sums) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[3][VEC];
@@ -371,6 +479,7 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
 #endif
     }
     block_reduce_store<T, 3>(cx, m, s, partial);
+    if (fa.cnt != nullptr) finish_sums<3>(fa, m.C, cx.g, cx.chunk, partial, sums, nullptr);
 }
 
 __global__ __launch_bounds__(FNT) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
@@ -480,7 +589,7 @@ template <typename T>
 __global__ __launch_bounds__(NT) void adain_bwd_reduce_kernel(Map m, const float *__restrict__ mean, const float *__restrict__ rstd,
                                                               const T *__restrict__ dout, const T *__restrict__ x,
                                                               const T *__restrict__ gbm, float *__restrict__ partial, int lddo,
-                                                              int ldx, int ldgb) {
+                                                              int ldx, int ldgb, fold::Args fa, float *__restrict__ sums) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[3][VEC];
@@ -507,6 +616,7 @@ __global__ __launch_bounds__(NT) void adain_bwd_reduce_kernel(Map m, const float
         ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 3>(cx, m, s, partial);
+    if (fa.cnt != nullptr) finish_sums<3>(fa, m.C, cx.g, cx.chunk, partial, sums, nullptr);
 }
 
 template <typename T>
@@ -554,7 +664,8 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(Map m, const float 
 // ------------------------------------------------------------------------------------------
 // per-channel sum.  Vector path (C a multiple of the 16-byte vector): the common Ctx mapping, K = 1.
 template <typename T>
-__global__ __launch_bounds__(NT) void chsum_vec_kernel(Map m, int ld, const T *__restrict__ x, float *__restrict__ partial) {
+__global__ __launch_bounds__(NT) void chsum_vec_kernel(Map m, int ld, const T *__restrict__ x, float *__restrict__ partial, fold::Args fa,
+                                                       float *__restrict__ out, float *__restrict__ acc) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[1][VEC];
@@ -571,10 +682,12 @@ __global__ __launch_bounds__(NT) void chsum_vec_kernel(Map m, int ld, const T *_
         ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 1>(cx, m, s, partial);
+    if (fa.cnt != nullptr) finish_sums<1>(fa, m.C, 0, cx.chunk, partial, out, acc);
 }
 // scalar path (C = 1, 3, ...): thread t -> channel t % Cb, rows t / Cb
 template <typename T>
-__global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, int chunk, const T *__restrict__ x, float *__restrict__ partial) {
+__global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, int chunk, const T *__restrict__ x, float *__restrict__ partial,
+                                                   fold::Args fa, float *__restrict__ out, float *__restrict__ acc) {
     const int slab0 = blockIdx.z * NT, Cb = min(C - slab0, NT), RPB = NT / Cb;
     const int t = threadIdx.x, c = slab0 + t % Cb, r0 = t / Cb;
     const bool active = t < RPB * Cb;
@@ -588,8 +701,9 @@ __global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, int chu
     if (active && r0 == 0) {
         float a = 0.f;
         for (int r = 0; r < RPB; ++r) a += red[r * Cb + t];
-        partial[(size_t)blockIdx.x * C + c] = a;
+        fold::st_f32(&partial[(size_t)blockIdx.x * C + c], a);
     }
+    if (fa.cnt != nullptr) finish_sums<1>(fa, C, 0, blockIdx.x, partial, out, acc);
 }
 
 template <typename T>
@@ -616,6 +730,37 @@ int check_map(const char *who, int G, int P, int C, int dtype, std::initializer_
 
 #define DISPATCH(dtype, ...) RDFC_DISPATCH(dtype, __VA_ARGS__)
 
+// ---- folded second stage (fold.h): scratch layout [partials f32: G * nchunk * K * C | pad to 8 bytes | level-2 rows f64 | f64 [G][2][C]]
+namespace {
+const fold::Args NO_FOLD{nullptr, nullptr, 0, 1, 1};
+// Opt-in (RDFC_NORM_FOLD=1).  Measured on MI355X (profiles/r04_fold_experiment.txt): the folded tail is a chain of dependent memory round
+// trips (write-through drain, ticket, row loads; twice for two levels) of ~15 us alone against 5-14 us for the finalize launch it
+// replaces, and the step is no faster with it (36.7 vs 36.3 ms): the separate launches stay the default.
+const bool g_fold_on = getenv("RDFC_NORM_FOLD") != nullptr && atoi(getenv("RDFC_NORM_FOLD")) != 0;
+
+inline size_t part_floats(int G, int nchunk, int K, int C) { return ((size_t)G * nchunk * K * C + 1) & ~(size_t)1; }
+// -> false (and fa.cnt == nullptr) when this launch keeps its finalize launch: more than one channel slab per workgroup row, the switch off
+bool plan_fold(int G, int nchunk, int K, int C, int nslab, float *scratch, int extra_counters, hipStream_t st, fold::Args &fa, double *&tail, unsigned *&extra) {
+    fa = NO_FOLD;
+    tail = nullptr;
+    extra = nullptr;
+    if (!g_fold_on || nslab != 1) return false;
+    int gs, ng;
+    fold::shape(nchunk, gs, ng);
+    unsigned *cnt = rdfc_fold_counters(G * (1 + ng) + extra_counters, st);
+    if (cnt == nullptr) return false;
+    double *l2 = reinterpret_cast<double *>(scratch + part_floats(G, nchunk, K, C));
+    fa = fold::Args{cnt, l2, nchunk, gs, ng};
+    tail = l2 + fold::l2_doubles(G, nchunk, K * C);
+    extra = cnt + G * (1 + ng);
+    return true;
+}
+}  // namespace
+
+extern "C" int rdfc_fold_scratch_floats(int G, int nchunk, int K, int C) {
+    return (int)(part_floats(G, nchunk, K, C) + 2 * (fold::l2_doubles(G, nchunk, K * C) + (size_t)G * 2 * C));
+}
+
 extern "C" int rdfc_norm_nchunk(int pixels_per_group, int C, int dtype) {
     return cdiv(pixels_per_group, chunk_pixels(pixels_per_group, C, rdfc_vec(dtype)));
 }
@@ -623,7 +768,8 @@ extern "C" int rdfc_norm_nchunk(int pixels_per_group, int C, int dtype) {
 extern "C" int rdfc_norm_stats(const void *x, float *partial, int G, int P, int C, int ld, int dtype, void *stream) {
     if (int e = check_map("rdfc_norm_stats", G, P, C, dtype, {ld})) return e;
     Map m = make_map(G, P, C, rdfc_vec(dtype));
-    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld, partial));
+    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld, partial,
+                                       NO_FOLD, FinStats{}));
     RDFC_LAUNCH_CHECK("rdfc_norm_stats");
     return 0;
 }
@@ -672,8 +818,33 @@ extern "C" int rdfc_norm_apply(const void *x, const float *mean, const float *rs
     Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                       (const T *)x, (const T *)res, (T *)z, ldx, ldr, ldz));
+                                       (const T *)x, (const T *)res, (T *)z, ldx, ldr, ldz, RunUpd{}));
     RDFC_LAUNCH_CHECK("rdfc_norm_apply");
+    return 0;
+}
+
+// BatchNorm over G stacked batches, the part behind the partial rows: statistics per group from `partial` ([G][nchunk][2][C]; nchunk 0:
+// derived from (P, C, dtype)), then the normalise pass, which also advances the running statistics once per group, in group order
+// (group_momentum: HOST array of G floats; run_mean NULL: no running statistics).  muvar: f64 [G][2][C] scratch.
+extern "C" int rdfc_norm_finalize_apply_seq(const float *partial, int nchunk, double *muvar, const void *x, float *mean, float *rstd,
+                                            const float *gamma, const float *beta, const void *res, void *z, int G, int P, int C, int ldx,
+                                            int ldr, int ldz, int dtype, float eps, float *run_mean, float *run_var,
+                                            const float *group_momentum, int act, float slope, const float *prelu, void *stream) {
+    if (int e = check_map("rdfc_norm_finalize_apply_seq", G, P, C, dtype, {ldx, ldz})) return e;
+    RDFC_REQUIRE(G <= MAXSEQ, "rdfc_norm_finalize_apply_seq: 1 <= G <= %d groups", MAXSEQ);
+    RDFC_REQUIRE(run_mean == nullptr || (group_momentum != nullptr && muvar != nullptr), "rdfc_norm_finalize_apply_seq: running statistics need the per-group momenta and the f64 scratch");
+    RDFC_REQUIRE(act != RDFC_ACT_PRELU || prelu != nullptr, "rdfc_norm_finalize_apply_seq: PReLU needs the slope pointer");
+    RDFC_REQUIRE(act != RDFC_ACT_TANH && act != RDFC_ACT_SIGMOID, "rdfc_norm_finalize_apply_seq: tanh / sigmoid never follow a norm on this path");
+    Map mr = make_map(G, P, C, rdfc_vec(dtype));
+    hipLaunchKernelGGL(stats_finalize_par_kernel, dim3(cdiv(C, 32), G), dim3(FNT), 0, (hipStream_t)stream, mr, nchunk > 0 ? nchunk : cdiv(P, mr.chunk),
+                       partial, mean, rstd, eps, run_mean != nullptr ? muvar : nullptr);
+    RunUpd ru{run_mean, run_var, muvar, Moms{}};
+    for (int g = 0; g < G && group_momentum != nullptr; ++g) ru.moms.m[g] = group_momentum[g];
+    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
+    ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
+    DISPATCH(dtype, hipLaunchKernelGGL(apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
+                                       (const T *)x, (const T *)res, (T *)z, ldx, ldr, ldz, ru));
+    RDFC_LAUNCH_CHECK("rdfc_norm_finalize_apply_seq");
     return 0;
 }
 
@@ -684,7 +855,7 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
     Map m = make_map(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                       (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr));
+                                       (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr, NO_FOLD, (float *)nullptr));
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_reduce");
     return 0;
 }
@@ -719,12 +890,40 @@ extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *m
 // ---- composites: the launches of one layer's forward / backward behind ONE call (the step makes ~360 of them and is partly
 //      launch-bound; a ctypes call costs the host ~4-5 us).  Same kernels, same order, same stream.
 //      scratch (f32): forward [G * nchunk * 2 * C] partials; backward [G * nchunk * 3 * C] partials.
+// statistics with the finalize folded into the launch (fold.h) -> mean / rstd (+ running statistics); scratch: rdfc_fold_scratch_floats(G, nchunk, 2, C)
+static int stats_folded(const void *x, float *scratch, float *mean, float *rstd, int G, int P, int C, int ldx, int dtype, float eps, float *run_mean,
+                        float *run_var, float momentum, const float *group_momentum, void *stream) {
+    if (int e = check_map("rdfc_norm_forward", G, P, C, dtype, {ldx})) return e;
+    const bool seq = group_momentum != nullptr;
+    RDFC_REQUIRE(!seq || G <= MAXSEQ, "rdfc_norm_forward_seq: 1 <= G <= %d groups", MAXSEQ);
+    RDFC_REQUIRE(run_mean == nullptr || seq || G == 1, "rdfc_norm_forward: running statistics need G == 1 (batch norm)");
+    Map m = make_map(G, P, C, rdfc_vec(dtype));
+    const int nchunk = cdiv(P, m.chunk);
+    fold::Args fa;
+    double *muvar;
+    unsigned *cnt_all;
+    if (!plan_fold(G, nchunk, 2, C, cdiv(C / rdfc_vec(dtype), NT), scratch, 1, (hipStream_t)stream, fa, muvar, cnt_all)) {
+        if (int e = rdfc_norm_stats(x, scratch, G, P, C, ldx, dtype, stream)) return e;
+        if (seq) return rdfc_norm_finalize_seq(scratch, 0, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, group_momentum, stream);
+        return rdfc_norm_finalize(scratch, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, momentum, stream);
+    }
+    FinStats fs{mean, rstd, eps, run_mean, run_var, momentum, seq ? 1 : 0, Moms{}, muvar, cnt_all};
+    for (int g = 0; seq && g < G; ++g) fs.moms.m[g] = group_momentum[g];
+    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ldx, scratch, fa, fs));
+    RDFC_LAUNCH_CHECK("rdfc_norm_forward (statistics)");
+    return 0;
+}
+
+extern "C" int rdfc_norm_stats_final(const void *x, float *scratch, float *mean, float *rstd, int G, int P, int C, int ld, int dtype, float eps,
+                                     float *run_mean, float *run_var, float momentum, void *stream) {
+    return stats_folded(x, scratch, mean, rstd, G, P, C, ld, dtype, eps, run_mean, run_var, momentum, nullptr, stream);
+}
+
 extern "C" int rdfc_norm_forward(const void *x, float *scratch, float *mean, float *rstd, const float *gamma, const float *beta,
                                  const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
                                  float *run_mean, float *run_var, float momentum, int act, float slope, const float *prelu,
                                  void *stream) {
-    if (int e = rdfc_norm_stats(x, scratch, G, P, C, ldx, dtype, stream)) return e;
-    if (int e = rdfc_norm_finalize(scratch, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, momentum, stream)) return e;
+    if (int e = stats_folded(x, scratch, mean, rstd, G, P, C, ldx, dtype, eps, run_mean, run_var, momentum, nullptr, stream)) return e;
     return rdfc_norm_apply(x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, act, slope, prelu, stream);
 }
 
@@ -732,25 +931,40 @@ extern "C" int rdfc_norm_forward_seq(const void *x, float *scratch, float *mean,
                                      const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
                                      float *run_mean, float *run_var, const float *group_momentum, int act, float slope,
                                      const float *prelu, void *stream) {
+    static const float zeros[MAXSEQ] = {0};
+    if (g_fold_on) {
+        if (int e = stats_folded(x, scratch, mean, rstd, G, P, C, ldx, dtype, eps, run_mean, run_var, 0.f, group_momentum ? group_momentum : zeros, stream))
+            return e;
+        return rdfc_norm_apply(x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, act, slope, prelu, stream);
+    }
     if (int e = rdfc_norm_stats(x, scratch, G, P, C, ldx, dtype, stream)) return e;
-    if (int e = rdfc_norm_finalize_seq(scratch, 0, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, group_momentum, stream)) return e;
-    return rdfc_norm_apply(x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, act, slope, prelu, stream);
+    const int nchunk = rdfc_norm_nchunk(P, C, dtype);
+    double *muvar = reinterpret_cast<double *>(scratch + part_floats(G, nchunk, 2, C)) + fold::l2_doubles(G, nchunk, 2 * C);
+    return rdfc_norm_finalize_apply_seq(scratch, nchunk, muvar, x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, eps, run_mean,
+                                        run_var, group_momentum ? group_momentum : zeros, act, slope, prelu, stream);
 }
 
 extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
                                   const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P,
                                   int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
                                   const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream) {
-    if (int e = rdfc_norm_bwd_reduce(dz, x, mean, rstd, gamma, beta, res, scratch, G, P, C, lddz, ldx, ldr, dtype, act, slope, prelu,
-                                     stream))
-        return e;
-    if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, nullptr, nullptr, stream)) return e;
-    // (the affine gradients are accumulated by the apply pass, which reads the sums anyway: the groups in group order, no extra
-    //  launch, and the finalize stays one small workgroup per (group, sum, 32 channels))
     if (int e = check_map("rdfc_norm_backward", G, P, C, dtype, {lddz, ldx, lddx})) return e;
     RDFC_REQUIRE(dbeta_acc != nullptr || dgamma_acc == nullptr, "rdfc_norm_backward: d gamma accumulates together with d beta");
-    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
+    {   // pass 1: the three sums, finalized by the launch's last-arriving workgroup
+        Map m = make_map(G, P, C, rdfc_vec(dtype));
+        fold::Args fa;
+        double *tail_;
+        unsigned *extra_;
+        const bool folded = plan_fold(G, cdiv(P, m.chunk), 3, C, cdiv(C / rdfc_vec(dtype), NT), scratch, 0, (hipStream_t)stream, fa, tail_, extra_);
+        DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
+                                           (const T *)dz, (const T *)x, (const T *)res, scratch, lddz, ldx, ldr, fa, sums));
+        RDFC_LAUNCH_CHECK("rdfc_norm_backward (sums)");
+        if (!folded)
+            if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, nullptr, nullptr, stream)) return e;
+    }
+    // (the affine gradients are accumulated by the apply pass, which reads the sums anyway: the groups in group order)
+    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
                                        lddx, lddr, frozen_stats, dbeta_acc, dgamma_acc));
@@ -774,7 +988,7 @@ extern "C" int rdfc_adain_bwd_reduce(const void *dout, const void *x, const floa
     if (int e = check_map("rdfc_adain_bwd_reduce", N, P, C, dtype, {lddo, ldx})) return e;
     Map m = make_map(N, P, C, rdfc_vec(dtype));
     DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
-                                       mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, partial, lddo, ldx, ldgb));
+                                       mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, partial, lddo, ldx, ldgb, NO_FOLD, (float *)nullptr));
     RDFC_LAUNCH_CHECK("rdfc_adain_bwd_reduce");
     return 0;
 }
@@ -791,26 +1005,60 @@ extern "C" int rdfc_adain_bwd_apply(const void *dout, const void *x, const float
     return 0;
 }
 
+// W-AdaIN backward in one call: the sums (finalized inside the launch) + the apply pass.  scratch: rdfc_fold_scratch_floats(N, nchunk, 3, C)
+extern "C" int rdfc_adain_backward(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb, float *scratch,
+                                   float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx, int ldgb, int lddx, int lddgb,
+                                   int dtype, void *stream) {
+    if (int e = check_map("rdfc_adain_backward", N, P, C, dtype, {lddo, ldx, lddx})) return e;
+    Map m = make_map(N, P, C, rdfc_vec(dtype));
+    fold::Args fa;
+    double *tail_;
+    unsigned *extra_;
+    const bool folded = plan_fold(N, cdiv(P, m.chunk), 3, C, cdiv(C / rdfc_vec(dtype), NT), scratch, 0, (hipStream_t)stream, fa, tail_, extra_);
+    DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
+                                       mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, scratch, lddo, ldx, ldgb, fa, sums));
+    RDFC_LAUNCH_CHECK("rdfc_adain_backward (sums)");
+    if (!folded)
+        if (int e = rdfc_norm_bwd_finalize(scratch, sums, N, P, C, dtype, stream)) return e;
+    return rdfc_adain_bwd_apply(dout, x, mean, rstd, gb, sums, dx, dgb, N, P, C, lddo, ldx, ldgb, lddx, lddgb, dtype, stream);
+}
+
 extern "C" int rdfc_channel_sum(const void *x, float *partial, float *out, int P, int C, int ld, int dtype, void *stream) {
     return rdfc_channel_sum_acc(x, partial, out, nullptr, P, C, ld, dtype, stream);
+}
+
+static int channel_sum_geometry(int P, int C, int ld, int dtype, bool &vecpath, int &chunk) {
+    const int vec = rdfc_vec(dtype);
+    vecpath = C % vec == 0 && ld % vec == 0;
+    chunk = chunk_pixels(P, C, vecpath ? vec : 1);
+    return cdiv(P, chunk);
+}
+/* floats of scratch rdfc_channel_sum[_acc] needs */
+extern "C" int rdfc_channel_sum_scratch_floats(int P, int C, int ld, int dtype) {
+    bool vp;
+    int chunk;
+    return rdfc_fold_scratch_floats(1, channel_sum_geometry(P, C, ld, dtype, vp, chunk), 1, C);
 }
 
 extern "C" int rdfc_channel_sum_acc(const void *x, float *partial, float *out, float *acc, int P, int C, int ld, int dtype, void *stream) {
     RDFC_REQUIRE(rdfc_dtype_ok(dtype), "rdfc_channel_sum: bad dtype");
     RDFC_REQUIRE(P > 0 && C > 0 && ld >= C, "rdfc_channel_sum: bad size");
-    const int vec = rdfc_vec(dtype);
-    int nchunk;
-    if (C % vec == 0 && ld % vec == 0) {
+    bool vecpath;
+    int chunk;
+    const int nchunk = channel_sum_geometry(P, C, ld, dtype, vecpath, chunk), vec = rdfc_vec(dtype);
+    fold::Args fa;
+    double *tail_;
+    unsigned *extra_;
+    const bool folded = plan_fold(1, nchunk, 1, C, cdiv(vecpath ? C / vec : C, NT), partial, 0, (hipStream_t)stream, fa, tail_, extra_);
+    if (vecpath) {
         Map m = make_map(1, P, C, vec);
-        nchunk = cdiv(P, m.chunk);
-        DISPATCH(dtype, hipLaunchKernelGGL(chsum_vec_kernel<T>, grid_for(m, vec), dim3(NT), 0, (hipStream_t)stream, m, ld, (const T *)x, partial));
+        DISPATCH(dtype, hipLaunchKernelGGL(chsum_vec_kernel<T>, grid_for(m, vec), dim3(NT), 0, (hipStream_t)stream, m, ld, (const T *)x, partial, fa, out, acc));
     } else {
-        const int chunk = chunk_pixels(P, C, 1);
-        nchunk = cdiv(P, chunk);
         dim3 grid(nchunk, 1, cdiv(C, NT));
-        DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, chunk, (const T *)x, partial));
+        DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, chunk, (const T *)x, partial, fa, out, acc));
     }
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(FNT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out, acc, nullptr);
+    if (!folded)
+        hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(FNT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out, acc, nullptr);
     RDFC_LAUNCH_CHECK("rdfc_channel_sum");
     return 0;
 }

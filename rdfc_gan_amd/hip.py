@@ -425,6 +425,18 @@ def norm_nchunk(P, Cc, dtype_code):
     return n
 
 
+_fold_cache = {}
+
+
+def fold_scratch(G, nchunk, K, Cc):
+    """f32 elements of scratch a folded two-stage reduction needs (partial rows + level-2 rows: csrc/fold.h)"""
+    key = (G, nchunk, K, Cc)
+    n = _fold_cache.get(key)
+    if n is None:
+        n = _fold_cache[key] = lib().rdfc_fold_scratch_floats(G, nchunk, K, Cc)
+    return n
+
+
 _mom_arrays = {}
 
 
@@ -444,8 +456,8 @@ def norm_forward(x, G, eps, gamma, beta, res, z, act='none', slope=0.0, prelu=No
     N, H, W, Cc = x.shape
     P = N * H * W // G
     d = dt(x)
-    npart = G * norm_nchunk(P, Cc, d) * 2 * Cc
-    buf = torch.empty(npart + 2 * G * Cc, dtype=torch.float32, device=x.device)      # [partials | mean | rstd]
+    npart = fold_scratch(G, norm_nchunk(P, Cc, d), 2, Cc)
+    buf = torch.empty(npart + 2 * G * Cc, dtype=torch.float32, device=x.device)      # [partials, level-2 rows | mean | rstd]
     base = buf.data_ptr()
     if group_momenta is not None:
         assert len(group_momenta) == G
@@ -466,13 +478,13 @@ def norm_stats(x, G, eps, run_mean=None, run_var=None, momentum=0.1):
     """x [N,H,W,C]; G = 1 (batch) or N (instance). -> mean[G,C], rstd[G,C]"""
     N, H, W, Cc = x.shape
     P = N * H * W // G
-    partial = torch.empty(G * norm_nchunk(P, Cc, dt(x)) * 2 * Cc, dtype=torch.float32, device=x.device)
-    mean = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(G, Cc, dtype=torch.float32, device=x.device)
-    _chk(lib().rdfc_norm_stats(_p(x), _p(partial), G, P, Cc, ld(x), dt(x), _st()), 'rdfc_norm_stats')
-    _chk(lib().rdfc_norm_finalize(_p(partial), _p(mean), _p(rstd), G, P, Cc, dt(x), _f(eps), _p(run_mean), _p(run_var),
-                                  _f(momentum), _st()), 'rdfc_norm_finalize')
-    return mean, rstd
+    npart = fold_scratch(G, norm_nchunk(P, Cc, dt(x)), 2, Cc)
+    buf = torch.empty(npart + 2 * G * Cc, dtype=torch.float32, device=x.device)      # [partials, level-2 rows | mean | rstd]
+    base = buf.data_ptr()
+    _chk(lib().rdfc_norm_stats_final(_p(x), base, base + 4 * npart, base + 4 * (npart + G * Cc), G, P, Cc, ld(x), dt(x), _f(eps),
+                                     _p(run_mean), _p(run_var), _f(momentum), _st()), 'rdfc_norm_stats_final')
+    stats = buf[npart:].view(2, G, Cc)
+    return stats[0], stats[1]
 
 
 def norm_apply(x, mean, rstd, gamma, beta, res, z, act='none', slope=0.0, prelu=None):
@@ -494,8 +506,8 @@ def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, pr
     G = mean.shape[0]
     P = N * H * W // G
     d = dt(x)
-    npart = G * norm_nchunk(P, Cc, d) * 3 * Cc
-    buf = torch.empty(npart + G * 3 * Cc, dtype=torch.float32, device=x.device)       # [partials | sums]
+    npart = fold_scratch(G, norm_nchunk(P, Cc, d), 3, Cc)
+    buf = torch.empty(npart + G * 3 * Cc, dtype=torch.float32, device=x.device)       # [partials, level-2 rows | sums]
     base = buf.data_ptr()
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
     dres = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device) if want_dres else None
@@ -515,16 +527,13 @@ def adain_apply(x, mean, rstd, gb, out):
 def adain_backward(dout, x, mean, rstd, gb):
     N, H, W, Cc = x.shape
     P = H * W
-    nch = norm_nchunk(P, Cc, dt(x))
-    partial = torch.empty(N * nch * 3 * Cc, dtype=torch.float32, device=x.device)
-    sums = torch.empty(N, 3, Cc, dtype=torch.float32, device=x.device)
-    _chk(lib().rdfc_adain_bwd_reduce(_p(dout), _p(x), _p(mean), _p(rstd), _p(gb), _p(partial), N, P, Cc, ld(dout), ld(x),
-                                     ld(gb), dt(x), _st()), 'rdfc_adain_bwd_reduce')
-    _chk(lib().rdfc_norm_bwd_finalize(_p(partial), _p(sums), N, P, Cc, dt(x), _st()), 'rdfc_norm_bwd_finalize')
+    npart = fold_scratch(N, norm_nchunk(P, Cc, dt(x)), 3, Cc)
+    buf = torch.empty(npart + N * 3 * Cc, dtype=torch.float32, device=x.device)       # [partials, level-2 rows | sums]
+    base = buf.data_ptr()
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
     dgb = torch.empty(N, H, W, 2 * Cc, dtype=x.dtype, device=x.device)
-    _chk(lib().rdfc_adain_bwd_apply(_p(dout), _p(x), _p(mean), _p(rstd), _p(gb), _p(sums), _p(dx), _p(dgb), N, P, Cc,
-                                    ld(dout), ld(x), ld(gb), Cc, 2 * Cc, dt(x), _st()), 'rdfc_adain_bwd_apply')
+    _chk(lib().rdfc_adain_backward(_p(dout), _p(x), _p(mean), _p(rstd), _p(gb), base, base + 4 * npart, _p(dx), _p(dgb), N, P, Cc,
+                                   ld(dout), ld(x), ld(gb), Cc, 2 * Cc, dt(x), _st()), 'rdfc_adain_backward')
     return dx, dgb
 
 
@@ -532,7 +541,7 @@ def channel_sum(x, acc=None):
     """out[c] = sum over pixels; acc (f32 [C], optional): acc += out in the same launch"""
     N, H, W, Cc = x.shape
     P = N * H * W
-    partial = torch.empty(min(4096, P) * Cc, dtype=torch.float32, device=x.device)   # upper bound on chunks
+    partial = torch.empty(lib().rdfc_channel_sum_scratch_floats(P, Cc, ld(x), dt(x)), dtype=torch.float32, device=x.device)
     out = torch.empty(Cc, dtype=torch.float32, device=x.device)
     _chk(lib().rdfc_channel_sum_acc(_p(x), _p(partial), _p(out), _p(acc), P, Cc, ld(x), dt(x), _st()), 'rdfc_channel_sum_acc')
     return out

@@ -99,6 +99,11 @@ CONV_CASES = [
     (2, 12, 70, 128, 256, 3, 1, 0),         # >= 65536 pixels: the streaming head input-gradient kernel (conv_head_dgrad.hip)
     (4, 134, 146, 1, 64, 7, 1, 0),
     (4, 134, 146, 64, 3, 7, 1, 0),
+    # round 4's wave-per-task thin-input kernel (conv_thin_in.hip) takes launches of >= 256 tasks of 4 x 16 output pixels:
+    # PatchGAN's 4x4 / stride-2 first layers, the 3 -> 64 stem, an odd width
+    (4, 130, 140, 3, 64, 4, 2, 1),
+    (4, 130, 140, 1, 64, 4, 2, 1),
+    (4, 130, 141, 3, 64, 3, 1, 1),
 ]
 
 

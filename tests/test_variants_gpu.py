@@ -17,13 +17,18 @@ VARIANTS = [
     ('RDFC_T3S2', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # transposed 3x3 / stride 2 on igemm_glds' parity classes instead of the patch kernel
     ('RDFC_T3S2', '3', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # ... and the patch kernel also on the small launches the default leaves to igemm_glds
     ('RDFC_GLDS_STACK', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # per-image row tiles in the 3x3 kernel
+    # round 4: the finalize of the two-stage reductions folded into the reduction launch (csrc/fold.h; opt-in, measured no faster)
+    ('RDFC_NORM_FOLD', '1', 'test_norm_fwd_bwd or test_adain or stacked_batches or layout_window_pad_sum'),
+    ('RDFC_NORM_FOLD', '1', 'folded', 'test_fold_gpu.py'),
 ]
 
 
-@pytest.mark.parametrize('name,value,expr', VARIANTS, ids=[f'{n}={v}' for n, v, _ in VARIANTS])
-def test_variant_passes_the_default_kernels_tests(name, value, expr):
+@pytest.mark.parametrize('variant', VARIANTS, ids=[f'{v[0]}={v[1]}' + (f'-{v[3][5:-7]}' if len(v) > 3 else '') for v in VARIANTS])
+def test_variant_passes_the_default_kernels_tests(variant):
+    name, value, expr = variant[:3]
+    test_file = variant[3] if len(variant) > 3 else 'test_kernels_gpu.py'
     env = dict(os.environ, **{name: value})
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_kernels_gpu.py'), '-q', '-x', '-k', expr],
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', test_file), '-q', '-x', '-k', expr],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-2500:]
     assert r.returncode == 0, tail

@@ -1,19 +1,25 @@
 #!/bin/bash
-# per-kernel times of the norm kernels on cache-cold maps: bash tools/norm_cold.sh N H W C [G]
-root=$PWD
-cd /tmp && export TMPDIR=/tmp && cd $root
-rm -rf gpurun_out/prof_nc
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_nc -- python3 tools/norm_cold.py "$@" > gpurun_out/norm_cold.log 2>&1
-tail -1 gpurun_out/norm_cold.log
-python3 - "$@" <<'PY'
+# usage (GPU box): bash tools/norm_cold.sh   -> per-kernel time of the normalisation kernels on HBM-cold maps of the step's four main shapes
+mkdir -p gpurun_out/nc
+root=$PWD; cd /tmp && export TMPDIR=/tmp && cd $root
+for shp in "16 228 304 64" "16 114 152 128" "16 57 76 256" "16 29 38 512"; do
+  rm -rf gpurun_out/nc/raw
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/nc/raw -- python3 tools/norm_cold.py $shp > /dev/null 2>&1
+  echo "== $shp"
+  python3 - $shp <<'PY'
 import csv, glob, sys
-N, H, W, C = (int(v) for v in sys.argv[1:5])
-mb = N * H * W * C * 2 / 1e6
-traffic = dict(stats_kernel=1, apply_kernel=2, bwd_reduce=2, bwd_apply=3)
-for r in csv.DictReader(open(glob.glob('gpurun_out/prof_nc/*/*kernel_stats.csv')[0])):
-    for k, t in traffic.items():
-        if k in r['Name'] and ('bwd_' + k) not in r['Name']:
-            avg = float(r['AverageNs']) / 1e3
-            print(f"{k:14s} {int(r['Calls']):4d} calls  avg {avg:7.1f} us  min {float(r['MinNs'])/1e3:7.1f}  -> {t * mb / avg:5.2f} TB/s ({t} maps of {mb:.1f} MB)")
+N,H,W,C = map(int, sys.argv[1:5])
+nbytes = N*H*W*C*2
+f = glob.glob('gpurun_out/nc/raw/*/*kernel_stats.csv')[0]
+passes = dict(stats_kernel=1, apply_kernel=2, bwd_reduce=2, bwd_apply=3)
+for r in csv.DictReader(open(f)):
+    n = r['Name']
+    for key in ('stats_kernel','apply_kernel','bwd_reduce','bwd_apply','sum_finalize','stats_finalize','chsum'):
+        if key in n:
+            us = float(r['AverageNs'])/1e3
+            tb = f"{passes[key]*nbytes/us/1e6:.2f} TB/s" if key in passes else ''
+            print(f"   {key:16s} calls {r['Calls']:>4s} avg {us:7.1f} us   min {float(r['MinNs'])/1e3:7.1f}   {tb}")
+            break
 PY
-rm -rf gpurun_out/prof_nc
+done
+rm -rf gpurun_out/nc
