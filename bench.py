@@ -30,6 +30,7 @@ for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
 # forward GFLOP per pair (2*MAC over conv / conv-transpose / linear) at 228x304
 GFLOP_FWD = dict(G_A2B=209.64, G_B2A=73.28, D_A=6.49, D_B=6.56, G_label=72.49)   # G_label: train mode, both heads
 PEAK_TFLOPS = dict(bf16=2500.0, f16=2500.0, f32=157.3)        # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                                         # HBM3E spec (6 290 GB/s measured by a float4 copy), MI355X_MICROARCH.md
 
 
 def step_gflop_per_pair(exact_schedule, scale=1.0, label_net=False):
@@ -85,11 +86,13 @@ def _cpu_model():
     return 'unknown CPU'
 
 
-def cpu_baseline(B, H, W, exact_schedule=True, budget_s=150.0):
+def cpu_baseline(B, H, W, exact_schedule=True, budget_s=150.0, steps=0):
     """The oracle's train step (plain torch.nn on the host cores; SURVEY 8d / BASELINE.md section 4): the SAME batch size and
     resolution as the GPU run, upstream's literal schedule (dead forwards included), fp32.  Bounded sample: one warm-up step at
     batch 1 (thread pools, allocator, lazy initialisation -- a batch-8 step takes ~2 minutes on the GPU box's 128 threads), then
-    timed steps at the full batch for as long as `budget_s` allows (at least one; three when they fit), median."""
+    timed steps at the full batch for as long as `budget_s` allows (at least one; three when they fit), median.  steps > 0
+    (--cpu-steps): exactly that many timed steps whatever they cost -- BASELINE.md section 4's protocol is 3 (about 6 minutes of
+    host time on the GPU box, which is why the default run keeps to the budget and says so in the line)."""
     from oracle import nets as onets
     from oracle.step import HotPathStep
     torch.manual_seed(0)
@@ -109,12 +112,13 @@ def cpu_baseline(B, H, W, exact_schedule=True, budget_s=150.0):
 
     warm = one(1)
     times = [one(B)]
-    while len(times) < 3 and sum(times) + times[-1] <= budget_s:
+    while len(times) < steps if steps > 0 else (len(times) < 3 and sum(times) + times[-1] <= budget_s):
         times.append(one(B))
     times.sort()
     med = times[len(times) // 2]
     return dict(value=round(B / med, 5), unit='pairs/s', cores=torch.get_num_threads(), kind='port',
-                steps=len(times), warmup_steps=1, warmup_batch=1, budget_s=budget_s,
+                steps=len(times), warmup_steps=1, warmup_batch=1, budget_s=None if steps > 0 else budget_s,
+                protocol='BASELINE.md section 4: 1 warm-up + 3 timed steps' + ('' if len(times) >= 3 else f'; cut to {len(times)} timed step(s) by the {budget_s:.0f} s budget of the default run (--cpu-steps 3 runs it in full)'),
                 sample=f'{len(times)} timed train step(s) at batch {B} (median {med:.1f} s) after one warm-up step at batch 1 ({warm:.1f} s); '
                        f'upstream schedule incl. dead forwards, {H}x{W}, fp32 torch CPU oracle, torch threads {torch.get_num_threads()} on '
                        f'{os.cpu_count()} logical CPUs ({_cpu_model()})')
@@ -149,13 +153,32 @@ def rmse_deviation(model, H, W, dev):
     return worst
 
 
+def _count_gpus():
+    """GPUs of this node WITHOUT touching HIP (the parent must not initialise the runtime before it spawns the ranks): the KFD
+    topology lists every agent; GPU nodes are the ones with SIMDs.  Falls back to torch's count (NVML-style, no context) when
+    the topology is not readable."""
+    base = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        n = 0
+        for node in os.listdir(base):
+            props = dict(line.split()[:2] for line in open(os.path.join(base, node, 'properties')) if len(line.split()) >= 2)
+            if int(props.get('simd_count', 0)) > 0:
+                n += 1
+        vis = os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES'))
+        if vis is not None and vis.strip() != '':
+            n = min(n, len([v for v in vis.split(',') if v.strip() != '']))
+        return n
+    except (OSError, ValueError):
+        return torch.cuda.device_count()
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run job (one process per GPU,
     RCCL) before this process has touched the GPU -- a process that has initialised HIP must not exec another program on this
     pool --, relay the ranks' output (rank 0 prints the JSON line last) and return the job's exit code."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()          # (counting devices does not initialise the runtime)
+    have = _count_gpus()
     if have < n:
         print(f'bench.py: --gpus {n} but this node shows {have} GPU(s): refusing to report a smaller job under that label', file=sys.stderr)
         return 2
@@ -178,9 +201,11 @@ def main():
     ap.add_argument('--height', type=int, default=228)
     ap.add_argument('--width', type=int, default=304)
     ap.add_argument('--dtype', choices=('bf16', 'f16', 'f32'), default='f16',
-                    help='storage / MFMA operand type.  f16 (default): the one 16-bit format that meets the north-star accuracy figure '
-                         '(dense-depth RMSE within 1e-3 m of the f32 path; rounding the WEIGHTS to bf16 alone moves it by ~1.4e-3, '
-                         'tools/lowp_sim.py), same MFMA rate as bf16, dynamic loss scaling; bf16: BASELINE configs[1] as worded')
+                    help='storage / MFMA operand type of the conv operands.  f16 (default) is NOT the type BASELINE configs[1] words (bf16): same width, '
+                         'same MFMA rate, same kernels and speed, 11 instead of 8 significant bits in the stored WEIGHTS -- the CPU simulation '
+                         'tools/lowp_sim.py puts the eval-path RMSE shift of bf16 weights at up to ~1.4e-3 m by weight draw against <= 3.3e-4 m for '
+                         'f16 (profiles/r03_lowp_sim.txt; `rmse_dev_m` of one bench run is measured on near-random weights and cannot rank the two); '
+                         'the default run appends the bf16 figure of the same workload as `as_worded_bf16`.  bf16: configs[1] as worded')
     ap.add_argument('--nlspn', action='store_true', help='BASELINE configs[2]: NLSPN refinement on')
     ap.add_argument('--exact-schedule', action='store_true', help="run upstream's two dead forwards too")
     ap.add_argument('--label-net', action='store_true', help='SURVEY 8f rank 1 (not the headline workload): G_label (PSPNet) twice '
@@ -188,6 +213,10 @@ def main():
     ap.add_argument('--full-objective', action='store_true', help="--label-net plus G_normal (decoder on HIP behind the tests' stock-PyTorch "
                     'stand-in encoder): every term of upstream loss_G, six networks, four optimizers (not the headline workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=0, help='timed steps of the CPU baseline (BASELINE.md section 4: 3, ~6 minutes of host time); '
+                    'default 0 = as many as fit a 150 s budget, at least one -- the line says which')
+    ap.add_argument('--no-as-worded', action='store_true', help='skip the extra (untimed by the contract) run of the same workload in bf16 '
+                    '(BASELINE configs[1] as worded) that the default f16 run appends as `as_worded_bf16`')
     ap.add_argument('--rccl-self-test', action='store_true', help='N = 1 only: initialise a one-rank RCCL process group and send the step '
                     'through every collective of the data-parallel path (bucketed all-reduces, loss all-reduces); adds the comm block')
     ap.add_argument('--no-sync-losses', action='store_true', help='do not read the losses back every step (the host then runs ahead '
@@ -261,8 +290,9 @@ def main():
         # signal pools on first use, which would otherwise land in the first timed step (seen as rare 40 ms outliers)
         warm_ev = not graphed and not a.no_kernel_events and i == a.warmup - 1
         hip.PROFILE = [] if warm_ev else None
+        hip.PROFILE_HBM = [] if warm_ev else None
         one_step(i)
-        hip.PROFILE = None
+        hip.PROFILE = hip.PROFILE_HBM = None
     if graphed and a.warmup < 2:
         model.enable_graph(True, multi_stream=a.graph_multi_stream)
         one_step(a.warmup)                 # capture + first replay (untimed)
@@ -274,17 +304,17 @@ def main():
     # --event-every-th timed step (each pair costs ~3 us of host time; the step is launch-bound, so they are sampled).
     # A replayed graph cannot carry torch events: with --graph the LAST timed step runs eagerly with them instead.
     events = not a.no_kernel_events
-    prof_all, ev_steps = [], 0
+    prof_all, prof_hbm, ev_steps = [], [], 0
     t0 = time.perf_counter()
     for i in range(a.steps):
         with_ev = events and (i == a.steps - 1 if graphed else i % max(1, a.event_every) == 0)
         if with_ev:
             if graphed:
                 model.enable_graph(False)
-            hip.PROFILE = prof_all
+            hip.PROFILE, hip.PROFILE_HBM = prof_all, prof_hbm
             ev_steps += 1
         else:
-            hip.PROFILE = None
+            hip.PROFILE = hip.PROFILE_HBM = None
         losses = one_step(i)
     enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (== elapsed when launch-bound or synced)
     torch.cuda.synchronize()
@@ -292,7 +322,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof, hip.PROFILE = prof_all, None
+    prof, hip.PROFILE, hip.PROFILE_HBM = prof_all, None, None
     if isinstance(next(iter(losses.values())), float):
         final = losses
     else:
@@ -318,15 +348,15 @@ def main():
     ev_steps = max(1, ev_steps)                                   # timed steps that carried per-kernel events
     # Untimed extra step on ONE stream with the same events: in the timed steps a kernel shares the chip with the other
     # streams' kernels, so its duration there (what rocprofv3 of this command shows too) understates what it does alone.
-    iso = []
+    iso, iso_hbm = [], []
     if events:                          # on every rank: the step contains collectives
         if graphed:
             model.enable_graph(False)
         Fh.set_multi_stream(False)
-        hip.PROFILE = iso
+        hip.PROFILE, hip.PROFILE_HBM = iso, iso_hbm
         one_step(a.steps)
         torch.cuda.synchronize()
-        hip.PROFILE = None
+        hip.PROFILE = hip.PROFILE_HBM = None
         Fh.set_multi_stream(True)
     rmse_dev = rmse_deviation(model, a.height, a.width, dev) if rank == 0 else None     # (untimed; no collective in the eval path)
     comm = None
@@ -429,6 +459,29 @@ def main():
                               for k, v in sorted(sym.items(), key=lambda kv: -kv[1][1])[:8]}
             out['kernel_families'] = {k: dict(tflops=round(v[0] / v[1] / 1e12, 2), seconds=round(v[1], 4), launches=v[2],
                                               share_of_step=round(v[1] / (elapsed * ev_steps / a.steps), 4)) for k, v in sorted(fam.items())}
+        if prof_hbm:
+            # HBM-bound kernels: algorithmic bytes per launch / the launch's duration (HIP events on its stream, inside the
+            # timed steps that carried events); `isolated`: the same on the untimed single-stream step
+            def hbm_table(rows):
+                tab = {}
+                for kernel, nbytes, e0, e1, launches in rows:
+                    d = tab.setdefault(kernel, [0.0, 0.0, 0])
+                    d[0] += nbytes
+                    d[1] += e0.elapsed_time(e1) * 1e-3
+                    d[2] += launches
+                return tab
+            ht, hi = hbm_table(prof_hbm), hbm_table(iso_hbm)
+            keep = sorted(ht, key=lambda k: -ht[k][1])[:3] + [k for k in ht if k == 'prop_fwd']
+            out['roofline_hbm'] = []
+            for k in dict.fromkeys(keep):
+                nb, sec, n = ht[k]
+                e = dict(kernel=k, bound='hbm', launches=n, algorithmic_bytes_per_launch=round(nb / n), avg_launch_us=round(1e6 * sec / n, 2),
+                         achieved=round(nb / sec / 1e9, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(nb / sec / 1e9 / PEAK_HBM_GBS, 4),
+                         share_of_step=round(sec / (elapsed * ev_steps / a.steps), 4))
+                if k in hi and hi[k][1] > 0:
+                    e['isolated'] = dict(achieved=round(hi[k][0] / hi[k][1] / 1e9, 1), frac=round(hi[k][0] / hi[k][1] / 1e9 / PEAK_HBM_GBS, 4),
+                                         avg_launch_us=round(1e6 * hi[k][1] / hi[k][2], 2))
+                out['roofline_hbm'].append(e)
         if prof and a.by_shape:
             tab = {}
             for name, flops, e0, e1, shp, kernel in prof:
@@ -440,8 +493,30 @@ def main():
                 f.write('kernel N Hi Wi Ci Ho Wo Co K s | launches ms_total us_avg TFLOP/s\n')
                 for k, v in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                     f.write(' '.join(map(str, k)) + f' | {v[2]} {1e3 * v[1]:.2f} {1e6 * v[1] / v[2]:.1f} {v[0] / v[1] / 1e12:.1f}\n')
+        if a.dtype == 'f16' and world == 1 and not a.no_as_worded and not graphed and not a.label_net:
+            # BASELINE configs[1] words bf16: the same workload, same kernels, in bf16 on the same box (an extra, untimed by the contract)
+            del model
+            torch.cuda.empty_cache()
+            Fh.set_compute_dtype(torch.bfloat16)
+            Fh.invalidate_packed_weights()
+            torch.manual_seed(0)
+            mb = RDFCGAN(dev, False, model_cfg(a.nlspn), is_train=True, exact_schedule=a.exact_schedule)
+            mb.train()
+            for i in range(3 + a.steps):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    tb = time.perf_counter()
+                mb.set_input(batches[i % len(batches)])
+                lb = mb.optimize_parameters()
+            torch.cuda.synchronize()
+            eb = time.perf_counter() - tb
+            assert all(np.isfinite(v) for v in lb.values()), f'non-finite bf16 losses: {lb}'
+            out['as_worded_bf16'] = dict(value=round(a.batch * a.steps / eb, 3), unit='pairs/s', ms_per_step=round(1e3 * eb / a.steps, 3), steps=a.steps, warmup=3,
+                                         step_frac_of_mfma_peak=round(a.batch * a.steps / eb * gflop_pair / 1e3 / PEAK_TFLOPS['bf16'], 4),
+                                         note='BASELINE configs[1] as worded (bf16 conv operands): same process, same box, same schedule, after the f16 measurement')
+            Fh.set_compute_dtype(torch.float16)
         if not a.no_cpu_baseline and world == 1:    # rank 0 at N=1 only
-            out['cpu_baseline'] = cpu_baseline(a.batch, a.height, a.width, True)
+            out['cpu_baseline'] = cpu_baseline(a.batch, a.height, a.width, True, steps=a.cpu_steps)
     if world > 1 or a.rccl_self_test:
         dist.destroy_process_group()
     if rank == 0:

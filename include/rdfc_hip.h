@@ -201,6 +201,12 @@ int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const 
                         const float *beta, const void *res, const float *sums, void *dx, void *dres,
                         int G, int P, int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype,
                         int act, float slope, const float *prelu, int frozen_stats, void *stream);
+/* same; additionally the affine gradients land in the parameters' persistent .grad: dbeta_acc[c] += sum over groups of sums[g][0][c],
+ * dgamma_acc[c] += ... sums[g][1][c] (groups added in group order by one thread per channel: reproducible); either may be NULL */
+int rdfc_norm_bwd_apply_acc(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                            const float *beta, const void *res, const float *sums, void *dx, void *dres,
+                            int G, int P, int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype,
+                            int act, float slope, const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream);
 /* One layer's launches behind one call.  Round 4: the finalize of every two-stage reduction is done by the reduction launch's
  * LAST-ARRIVING workgroup (csrc/fold.h: write-through partial rows, one agent-scope ticket per workgroup, two levels of fixed-order
  * f64 sums -- bitwise reproducible like the separate finalize launches these calls used to make, which the three-call sequences

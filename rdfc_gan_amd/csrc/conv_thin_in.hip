@@ -42,16 +42,27 @@ __global__ __launch_bounds__(256, 2) void thin_in_kernel(TIParams p, const bf16_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int KP = p.KS * 32, WLD = KP + 8;                       // padded weight row (elements)
     bf16_t *Wl = reinterpret_cast<bf16_t *>(smem);                 // [16*MF][WLD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (provably wave-uniform: task geometry stays in SGPRs)
     unsigned short *Kt = reinterpret_cast<unsigned short *>(Wl + 16 * MF * WLD);                               // [MAXKS][4][8] gather offsets
     unsigned short *Tl = Kt + MAXKS * 32 + wave * (64 * MAXE + 8);                                            // this wave's patch
 
-    // ---- weights: w[co][K] -> Wl[co][KP], zero padded (once per workgroup) -------------------------------------------
-    for (int e = tid; e < 16 * MF * KP; e += 256) {
-        const int co = e / KP, k = e - co * KP;
-        bf16_t v = (bf16_t)0.f;
-        if (co < p.Cout && k < p.K) v = w[(size_t)co * p.K + k];
-        Wl[co * WLD + k] = v;
+    // ---- weights: w[co][K] -> Wl[co][KP], zero padded (once per workgroup; eight independent loads in flight per thread: every load is
+    //      UNCONDITIONAL from a clamped address and masked afterwards -- a load under a per-element condition makes hipcc branch around it
+    //      and wait for it before the next one, cdna_hip_programming.md section 5 trap (c): one dependent round trip per element) ------------
+    for (int e0 = tid; e0 < 16 * MF * KP; e0 += 256 * 8) {
+        bf16_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * 256, co = e / KP, k = e - co * KP;
+            const bool ok = e < 16 * MF * KP && co < p.Cout && k < p.K;
+            const bf16_t x = w[ok ? (size_t)co * p.K + k : 0];
+            v[q] = ok ? x : (bf16_t)0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * 256, co = e / KP, k = e - co * KP;
+            if (e < 16 * MF * KP) Wl[co * WLD + k] = v[q];
+        }
     }
     // ---- gather offsets: element offset of k inside the patch, table [ks][k-group of 8][8] (a lane reads its 8 with one ds_read_b128) ---
     const int prow = p.PW * p.ct;                                  // elements per patch row
@@ -75,6 +86,7 @@ __global__ __launch_bounds__(256, 2) void thin_in_kernel(TIParams p, const bf16_
         sgeo[i] = e < ne ? (row << 16 | col << 2 | c) : (0x7fff << 16);
     }
     const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
+    const bool fast_store = !p.out_f32 && (p.Cout & 15) == 0 && (p.ld_out & 3) == 0 && ns >= 0.f && ns <= 1.f && (reinterpret_cast<size_t>(yout) & 7) == 0;
     const int q4 = (lane >> 4) * 4;
     float bv[MF][4];
 #pragma unroll
@@ -88,20 +100,31 @@ __global__ __launch_bounds__(256, 2) void thin_in_kernel(TIParams p, const bf16_
 
     const int wstride = gridDim.x * 4;
     int task = blockIdx.x * 4 + wave;
-    unsigned short pre[MAXE];
+    unsigned okm = 0;
+    unsigned pre[MAXE];                                            // (one register per element: packing two per register made hipcc wait for every load before the next)
     auto fetch = [&](int tk) {                                     // the patch of task tk -> registers (loads stay in flight)
         int tt = tk;
         const int tx = tt % p.tiles_x;
         tt /= p.tiles_x;
         const int ty = tt % p.tiles_y, n = tt / p.tiles_y;
         const int gy0 = ty * TROWS * p.s + p.oy, gx0 = tx * TCOLS * p.s + p.ox;
-        const unsigned short *base = tsrc + ((long)(n * p.Ht + gy0) * p.Wt + gx0) * p.ldt;
+        const unsigned short *img = tsrc + (long)n * p.Ht * p.Wt * p.ldt;
+        // three separate passes -- offsets, loads, masks -- with the scheduler fenced between them: left alone hipcc re-uses one register
+        // for every load and waits for each before it issues the next (16 dependent round trips per task, the whole kernel's time)
+        int off[MAXE];
+        okm = 0;
 #pragma unroll
         for (int i = 0; i < MAXE; ++i) {
             const int row = sgeo[i] >> 16, col = (sgeo[i] >> 2) & 0x3fff, c = sgeo[i] & 3;
-            const bool ok = (unsigned)(gy0 + row) < (unsigned)p.Ht && (unsigned)(gx0 + col) < (unsigned)p.Wt;
-            pre[i] = ok ? base[(row * p.Wt + col) * p.ldt + c] : (unsigned short)0;
+            const int gy = gy0 + row, gx = gx0 + col;
+            if ((unsigned)gy < (unsigned)p.Ht && (unsigned)gx < (unsigned)p.Wt) okm |= 1u << i;
+            const int cy = min(max(gy, 0), p.Ht - 1), cx = min(max(gx, 0), p.Wt - 1);
+            off[i] = (cy * p.Wt + cx) * p.ldt + c;                 // (the map has < 2^31 elements: host)
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) pre[i] = img[off[i]];       // unconditional, from the clamped position
+        __builtin_amdgcn_sched_barrier(0);                         // (the out-of-image mask okm is applied when the values are written to LDS, a task later)
     };
     if (task < p.ntasks) fetch(task);
     for (; task < p.ntasks; task += wstride) {
@@ -113,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void thin_in_kernel(TIParams p, const bf16_
         // registers -> this wave's LDS patch (the previous task's gathers were issued before these stores: same wave, in order)
 #pragma unroll
         for (int i = 0; i < MAXE; ++i)
-            if (lane + 64 * i < ne) Tl[lane + 64 * i] = pre[i];
+            if (lane + 64 * i < ne) Tl[lane + 64 * i] = (okm >> i) & 1 ? (unsigned short)pre[i] : (unsigned short)0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (task + wstride < p.ntasks) fetch(task + wstride);      // next patch: in flight under this task's work
@@ -121,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void thin_in_kernel(TIParams p, const bf16_
         for (int j = 0; j < TROWS; ++j) {
             f32x4 acc[MF];
 #pragma unroll
-            for (int i = 0; i < MF; ++i) acc[i] = f32x4{0, 0, 0, 0};
+            for (int i = 0; i < MF; ++i) acc[i] = f32x4{bv[i][0], bv[i][1], bv[i][2], bv[i][3]};     // the bias is the accumulators' start value (PMC: 65 vector instructions per MFMA, most of them this epilogue)
             const int pbase = (j * p.s * p.PW + (lane & 15) * p.s) * p.ct;
 #pragma unroll 1
             for (int ks = 0; ks < p.KS; ++ks) {
@@ -141,25 +164,34 @@ __global__ __launch_bounds__(256, 2) void thin_in_kernel(TIParams p, const bf16_
             // ---- epilogue: lane holds channels 16 i + q4 .. +3 of pixel (row y0 + j, col x0 + (lane & 15)) ------------------
             const int oy = y0 + j, ox = x0 + (lane & 15);
             if (oy >= p.Ho || ox >= p.Wo) continue;
-            const size_t po = ((size_t)(n * p.Ho + oy) * p.Wo + ox) * p.ld_out;
+            const size_t po = ((size_t)(n * p.Ho + oy) * p.Wo + ox) * p.ld_out + q4;
+            if (fast_store) {              // 2-byte elements, every fragment's four channels inside Cout, 8-byte aligned rows: one address per row
+                bf16_t *y = reinterpret_cast<bf16_t *>(yout) + po;
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    if (16 * i >= p.Cout) continue;
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = cvt16<DT>(fmaxf(acc[i][r], acc[i][r] * ns));          // 0 <= ns <= 1: max(u, ns u) = leaky / plain ReLU / identity
+                    *reinterpret_cast<bf16x4 *>(y + 16 * i) = o;
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 const int co = 16 * i + q4;
                 if (co >= p.Cout) continue;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float u = acc[i][r] + bv[i][r];
-                    v[r] = u > 0.f ? u : u * ns;
-                }
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][r] > 0.f ? acc[i][r] : acc[i][r] * ns;
                 if (p.out_f32) {
-                    float *y = reinterpret_cast<float *>(yout) + po + co;
+                    float *y = reinterpret_cast<float *>(yout) + po - q4 + co;
                     if ((p.ld_out & 3) == 0 && co + 3 < p.Cout) *reinterpret_cast<f32x4 *>(y) = f32x4{v[0], v[1], v[2], v[3]};
                     else
                         for (int r = 0; r < 4; ++r)
                             if (co + r < p.Cout) y[r] = v[r];
                 } else {
-                    bf16_t *y = reinterpret_cast<bf16_t *>(yout) + po + co;
+                    bf16_t *y = reinterpret_cast<bf16_t *>(yout) + po - q4 + co;
                     if ((p.ld_out & 3) == 0 && co + 3 < p.Cout) {
                         bf16x4 o;
                         for (int r = 0; r < 4; ++r) o[r] = cvt16<DT>(v[r]);
@@ -180,7 +212,7 @@ int launch(const TIParams &p, const void *t, const void *w, const float *bias, v
     const size_t smem = (size_t)16 * MF * WLD * 2 + (size_t)MAXKS * 32 * 2 + (size_t)4 * (64 * MAXE + 8) * 2;
     if (smem > 64 * 1024) return 0;
     const int wtasks = cdiv(p.ntasks, 4);
-    int blocks = wtasks < 2048 ? wtasks : 2048;                    // 8 workgroups per CU at most; every wave then walks >= 1 task
+    int blocks = wtasks < 768 ? wtasks : 768;                      // persistent: three workgroups per CU (the weights are staged once per workgroup)
     rdfc_note_kernel("thin_in_kernel<%d, %d>", MF, dtype);
     if (dtype == RDFC_F16) hipLaunchKernelGGL((thin_in_kernel<MF, RDFC_F16>), dim3(blocks), dim3(256), smem, st, p, (const bf16_t *)t, (const bf16_t *)w, bias, y);
     else hipLaunchKernelGGL((thin_in_kernel<MF, RDFC_BF16>), dim3(blocks), dim3(256), smem, st, p, (const bf16_t *)t, (const bf16_t *)w, bias, y);
@@ -221,7 +253,7 @@ int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *i
     p.PH = (TROWS - 1) * p.s + d->KH;
     p.PW = (TCOLS - 1) * p.s + d->KW;
     if (p.PH * p.PW * p.ct > 64 * MAXE) return 0;
-    if ((double)p.N * p.Ht * p.Wt * p.ldt >= 2.0e9) return 0;
+    if ((double)p.Ht * p.Wt * p.ldt >= 2.0e9) return 0;           // (per-image element offsets are 32-bit)
     p.tiles_x = cdiv(p.Wo, TCOLS);
     p.tiles_y = cdiv(p.Ho, TROWS);
     p.ntasks = p.tiles_x * p.tiles_y * d->N;

@@ -63,16 +63,16 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWParams p, const bf
         wv[j] = e - wpx[j] * VPP;
     }
     const int nthin = p.KH * p.trow, nt = (nthin + 63) / 64;
-    int trc[MAXT], toff[MAXT];                                        // (row << 16 | column), global element offset
+    int trc[MAXT], tch[MAXT];                                         // (row << 16 | column), channel
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
         const int e = lane + 64 * j;
         trc[j] = -1;
-        toff[j] = 0;
+        tch[j] = 0;
         if (j < nt && e < nthin) {
             const int r = e / p.trow, ce = e - r * p.trow, col = ce / p.ct, c = ce - col * p.ct;
             trc[j] = (r << 16) | col;
-            toff[j] = (r * p.Wt + col) * p.ldt + c;
+            tch[j] = c;
         }
     }
     const int kg = lane >> 4;
@@ -97,28 +97,44 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWParams p, const bf
         for (int n = 0; n < NF; ++n) acc[f][n] = f32x4{0, 0, 0, 0};
 
     u32x4 rw[NF];
-    unsigned short rt[MAXT];
+    unsigned rt[MAXT];                                                 // (one register per element: see load_regs)
+    unsigned wok = 0, tok = 0;                                         // validity masks of the loads in flight, applied when they are staged
     const int wave_id = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    // Every load is UNCONDITIONAL from a clamped position and masked when it is staged one unit later; offsets, loads and masks are
+    // separate passes with the scheduler fenced between them.  (A load under a per-element condition makes hipcc branch around it and
+    // wait for it before it issues the next -- cdna_hip_programming.md section 5, trap (c): up to 14 + NF dependent round trips per
+    // 32-pixel unit were this kernel's time, 155-205 us for the 7x7 layers' one pass over a 142 MB map.)
     auto load_regs = [&](int u) {
         const int n = u / (p.Hw * p.segs_per_row), rem = u - n * p.Hw * p.segs_per_row;
         const int y = rem / p.segs_per_row, xs = (rem - y * p.segs_per_row) * SEG;
-        const bf16_t *wb = wide + ((size_t)(n * p.Hw + y) * p.Ww + xs) * p.ldw + cw0;
+        const bf16_t *wb = wide + ((size_t)(n * p.Hw + y) * p.Ww) * p.ldw + cw0;
+        const int ty0 = y + p.ry_min, tx0 = xs + p.rx_min;
+        const unsigned short *timg = reinterpret_cast<const unsigned short *>(thin) + (long)n * p.Ht * p.Wt * p.ldt;
+        int woff[NF], toffs[MAXT];
+        wok = tok = 0;
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
-            rw[j] = u32x4{0u, 0u, 0u, 0u};
-            if (xs + wpx[j] < p.Ww) rw[j] = *reinterpret_cast<const u32x4 *>(wb + (size_t)wpx[j] * p.ldw + wv[j] * 8);
+            const int px = xs + wpx[j];
+            if (px < p.Ww) wok |= 1u << j;
+            woff[j] = min(px, p.Ww - 1) * p.ldw + wv[j] * 8;
         }
-        const int ty0 = y + p.ry_min, tx0 = xs + p.rx_min;
-        const long tb = ((long)(n * p.Ht + ty0) * p.Wt + tx0) * p.ldt;
 #pragma unroll
         for (int j = 0; j < MAXT; ++j) {
-            rt[j] = 0;
+            toffs[j] = 0;
             if (j < nt) {
                 const int r = trc[j] >> 16, col = trc[j] & 0xffff;
-                if (trc[j] >= 0 && (unsigned)(ty0 + r) < (unsigned)p.Ht && (unsigned)(tx0 + col) < (unsigned)p.Wt)
-                    rt[j] = reinterpret_cast<const unsigned short *>(thin)[tb + toff[j]];
+                const int gy = ty0 + r, gx = tx0 + col;
+                if (trc[j] >= 0 && (unsigned)gy < (unsigned)p.Ht && (unsigned)gx < (unsigned)p.Wt) tok |= 1u << j;
+                toffs[j] = (min(max(gy, 0), p.Ht - 1) * p.Wt + min(max(gx, 0), p.Wt - 1)) * p.ldt + tch[j];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) rw[j] = *reinterpret_cast<const u32x4 *>(wb + woff[j]);
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j)
+            if (j < nt) rt[j] = timg[toffs[j]];
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     int u = wave_id;
@@ -126,10 +142,10 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWParams p, const bf
     for (; u < p.units; u += nwaves) {
         // stage (this wave's LDS region only; LDS executes a wave's instructions in order)
 #pragma unroll
-        for (int j = 0; j < NF; ++j) *reinterpret_cast<u32x4 *>(Wl + wpx[j] * LDW + wv[j] * 8) = rw[j];
+        for (int j = 0; j < NF; ++j) *reinterpret_cast<u32x4 *>(Wl + wpx[j] * LDW + wv[j] * 8) = (wok >> j) & 1 ? rw[j] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < MAXT; ++j)
-            if (j < nt && trc[j] >= 0) Tl[lane + 64 * j] = rt[j];
+            if (j < nt && trc[j] >= 0) Tl[lane + 64 * j] = (tok >> j) & 1 ? (unsigned short)rt[j] : (unsigned short)0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

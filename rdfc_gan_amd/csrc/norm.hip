@@ -873,18 +873,27 @@ extern "C" int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, 
     return rdfc_norm_bwd_finalize_acc(partial, sums, G, P, C, dtype, nullptr, nullptr, stream);
 }
 
-extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
-                                   const float *beta, const void *res, const float *sums, void *dx, void *dres, int G, int P,
-                                   int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
-                                   const float *prelu, int frozen_stats, void *stream) {
+extern "C" int rdfc_norm_bwd_apply_acc(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                                       const float *beta, const void *res, const float *sums, void *dx, void *dres, int G, int P,
+                                       int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
+                                       const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream) {
     if (int e = check_map("rdfc_norm_bwd_apply", G, P, C, dtype, {lddz, ldx, lddx})) return e;
+    RDFC_REQUIRE(dbeta_acc != nullptr || dgamma_acc == nullptr, "rdfc_norm_bwd_apply_acc: d gamma accumulates together with d beta");
     Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                        (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
-                                       lddx, lddr, frozen_stats, (float *)nullptr, (float *)nullptr));
+                                       lddx, lddr, frozen_stats, dbeta_acc, dgamma_acc));
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_apply");
     return 0;
+}
+
+extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                                   const float *beta, const void *res, const float *sums, void *dx, void *dres, int G, int P,
+                                   int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
+                                   const float *prelu, int frozen_stats, void *stream) {
+    return rdfc_norm_bwd_apply_acc(dz, x, mean, rstd, gamma, beta, res, sums, dx, dres, G, P, C, lddz, ldx, ldr, lddx, lddr, dtype, act, slope,
+                                   prelu, frozen_stats, nullptr, nullptr, stream);
 }
 
 // ---- composites: the launches of one layer's forward / backward behind ONE call (the step makes ~360 of them and is partly

@@ -22,6 +22,10 @@ F32, BF16, F16 = 0, 1, 2
 # bench.py sets this to a list: every conv launch then appends (family, algorithmic flops, start, end) with
 # HIP events recorded on the launch stream (per-kernel roofline measured inside the timed region)
 PROFILE = None
+# bench.py sets this to a list as well: the HBM-bound kernels of the normalisation layers (and NLSPN's propagation) then run as
+# one C call per kernel with a HIP event pair around each: (kernel, algorithmic bytes, start, end, launches) -- the HBM-roofline
+# entries of the bench line ("each reported as achieved GB/s / 8 TB/s")
+PROFILE_HBM = None
 ACT = dict(none=0, relu=1, lrelu=2, tanh=3, sigmoid=4, prelu=5)
 _lib = None
 
@@ -273,6 +277,24 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
+class _TimedHBM:
+    """records (kernel, algorithmic bytes, event pair, launches) around one call when PROFILE_HBM is active"""
+
+    def __init__(self, kernel, nbytes, launches=1):
+        self.on = PROFILE_HBM is not None
+        if self.on:
+            self.rec = [kernel, float(nbytes), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), launches]
+
+    def __enter__(self):
+        if self.on:
+            self.rec[2].record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.rec[3].record()
+            PROFILE_HBM.append(self.rec)
+
+
 def conv_forward(d, x, w_fwd, bias, y, reflect=False):
     """reflect: d.ph = d.pw is a REFLECTION padding (conv_reflect_supported(d) must hold)"""
     with _Timed('igemm_kernel (conv fwd / dgrad)', d):
@@ -459,6 +481,23 @@ def norm_forward(x, G, eps, gamma, beta, res, z, act='none', slope=0.0, prelu=No
     npart = fold_scratch(G, norm_nchunk(P, Cc, d), 2, Cc)
     buf = torch.empty(npart + 2 * G * Cc, dtype=torch.float32, device=x.device)      # [partials, level-2 rows | mean | rstd]
     base = buf.data_ptr()
+    if PROFILE_HBM is not None:
+        # one call and one event pair per kernel (same kernels and results as the composites below, which stay un-timed)
+        mb = x.numel() * x.element_size()
+        pm, pr = base + 4 * npart, base + 4 * (npart + G * Cc)
+        with _TimedHBM('stats_kernel', mb):
+            _chk(lib().rdfc_norm_stats(_p(x), base, G, P, Cc, ld(x), d, _st()), 'rdfc_norm_stats')
+        if group_momenta is not None:
+            _chk(lib().rdfc_norm_finalize_seq(base, 0, pm, pr, G, P, Cc, d, _f(eps), _p(run_mean), _p(run_var), _momenta(group_momenta),
+                                              _st()), 'rdfc_norm_finalize_seq')
+        else:
+            _chk(lib().rdfc_norm_finalize(base, pm, pr, G, P, Cc, d, _f(eps), _p(run_mean), _p(run_var), _f(momentum), _st()),
+                 'rdfc_norm_finalize')
+        with _TimedHBM('apply_kernel', mb * (2 + (res is not None))):
+            _chk(lib().rdfc_norm_apply(_p(x), pm, pr, _p(gamma), _p(beta), _p(res), _p(z), G, P, Cc, ld(x),
+                                       ld(res) if res is not None else 0, ld(z), d, ACT[act], _f(slope), _p(prelu), _st()), 'rdfc_norm_apply')
+        stats = buf[npart:].view(2, G, Cc)
+        return stats[0], stats[1]
     if group_momenta is not None:
         assert len(group_momenta) == G
         _chk(lib().rdfc_norm_forward_seq(_p(x), base, base + 4 * npart, base + 4 * (npart + G * Cc), _p(gamma), _p(beta), _p(res), _p(z),
@@ -511,6 +550,18 @@ def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, pr
     base = buf.data_ptr()
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
     dres = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device) if want_dres else None
+    if PROFILE_HBM is not None:
+        mb, nr = x.numel() * x.element_size(), 2 + (res is not None)
+        ps = base + 4 * npart
+        with _TimedHBM('bwd_reduce_kernel', mb * nr):
+            _chk(lib().rdfc_norm_bwd_reduce(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), base, G, P, Cc, ld(dz), ld(x),
+                                            ld(res) if res is not None else 0, d, ACT[act], _f(slope), _p(prelu), _st()), 'rdfc_norm_bwd_reduce')
+        _chk(lib().rdfc_norm_bwd_finalize(base, ps, G, P, Cc, d, _st()), 'rdfc_norm_bwd_finalize')
+        with _TimedHBM('bwd_apply_kernel', mb * (nr + 1 + bool(want_dres))):
+            _chk(lib().rdfc_norm_bwd_apply_acc(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ps, _p(dx), _p(dres), G, P, Cc,
+                                               ld(dz), ld(x), ld(res) if res is not None else 0, Cc, Cc, d, ACT[act], _f(slope), _p(prelu),
+                                               int(frozen), _p(acc_beta), _p(acc_gamma), _st()), 'rdfc_norm_bwd_apply_acc')
+        return dx, dres, buf[npart:].view(G, 3, Cc)
     _chk(lib().rdfc_norm_backward(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), base, base + 4 * npart, _p(dx),
                                   _p(dres), G, P, Cc, ld(dz), ld(x), ld(res) if res is not None else 0, Cc, Cc, d, ACT[act], _f(slope),
                                   _p(prelu), int(frozen), _p(acc_beta), _p(acc_gamma), _st()), 'rdfc_norm_backward')
@@ -792,8 +843,9 @@ def nlspn_propagate(feat0, offset, aff, weight, bias, T):
     B, Cc, H, W = feat0.shape
     assert Cc == 1 and feat0.dtype == torch.float32
     feats = torch.empty(T + 1, B, 1, H, W, dtype=torch.float32, device=feat0.device)
-    _chk(lib().rdfc_nlspn_propagate_forward(_p(feat0.contiguous()), _p(offset), _p(aff), _p(weight), _p(bias), B, H, W, T, _p(feats),
-                                            _st()), 'rdfc_nlspn_propagate_forward')
+    with _TimedHBM('prop_fwd', 116.0 * B * H * W * T, launches=T):          # per step and pixel: 18 offsets + 9 affinities + 1 read + 1 write, f32
+        _chk(lib().rdfc_nlspn_propagate_forward(_p(feat0.contiguous()), _p(offset), _p(aff), _p(weight), _p(bias), B, H, W, T, _p(feats),
+                                                _st()), 'rdfc_nlspn_propagate_forward')
     return feats
 
 

@@ -1,5 +1,3 @@
-python -m pytest tests/test_fold_gpu.py tests/test_kernels_gpu.py tests/test_variants_gpu.py -x -q 2>&1 | tail -3
-b() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'])"; }
-b par; b par; b par
+python -m pytest tests/test_kernels_gpu.py -x -q -k "test_conv_fwd_dgrad_wgrad" 2>&1 | tail -3
+RDFC_BRANCH_STREAMS=0 RDFC_NET_STREAMS=0 RDFC_WGRAD_STREAM=0 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-as-worded --event-every 1 --by-shape gpurun_out/r04a_by_shape.txt > /dev/null 2>&1
+grep -E "thin" gpurun_out/r04a_by_shape.txt
