@@ -37,6 +37,7 @@ struct GParams {
     const void *addend;          // optional map (2-byte elements, pixel stride ld_add) added to the result before the store: the
     int ld_add;                  // input gradient of a residual junction in one pass (rdfc_conv2d_dgrad_add)
     int reflect;                 // forward only: out-of-image patch pixels read their mirror image (ReflectionPad2d folded into the loader)
+    int row_store;               // epilogue through LDS: whole 128-byte channel rows per store instruction (see the epilogue)
 };
 
 constexpr int BK = 32, TC = 16, PW = TC + 2;
@@ -354,6 +355,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
         }
     }
     auto store_all = [&](auto actf) {
+#ifdef RDFC_EXP_NOSTORE          // timing-only experiment build (tools/build_variant.sh): what the epilogue's stores cost -- results are wrong
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < JR; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < JR; ++j) {
             const int oy = oyr[j], ox = x0 + (lane & 15);
@@ -395,6 +403,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
             }
         }
     };
+    // ---- whole-row stores (round 4).  A lane's accumulators are 4 consecutive channels (8 bytes) of 16 pixels: a wave's store
+    //      instruction touches 32 bytes of each of 16 pixel rows, and a timing build without the stores showed what that costs --
+    //      64 -> 64 @ 16 x 228 x 304: 138 -> 81 us, 128 -> 128 @ 114 x 152: 103 -> 80, 256 -> 256 @ 57 x 76: 101 -> 83 (the HBM time of
+    //      those outputs is 28 / 14 / 14 us).  Here every wave passes its 64 px x 64 co tile through its own 9 KB of the (now dead)
+    //      staging LDS -- 16 ds_write_b64 + 8 ds_read_b128 per lane -- and every store instruction writes 8 pixels x 128 contiguous
+    //      bytes: a quarter of the write requests, each a full line.  (Not with an addend or an f32 result: those keep the direct path.)
+    if (p.row_store) {
+        const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
+        constexpr int OROW = 144;                                  // bytes per pixel row of the wave's tile: 128 + 16 (bank spread; 16-byte aligned)
+        __syncthreads();                                           // every wave is done with the operand tiles
+        unsigned char *Ot = smem + wave * (64 * OROW);
+#pragma unroll
+        for (int j = 0; j < JR; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = acc[i][j][r] + bv[i][r];
+                    o[r] = cvt16<DT>(u > 0.f ? u : u * ns);
+                }
+                *reinterpret_cast<bf16x4 *>(Ot + (16 * j + (lane & 15)) * OROW + (16 * i + q4) * 2) = o;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int chunk = lane & 7, cow = co0 + wr * 64 + chunk * 8;
+        bf16_t *ybase = reinterpret_cast<bf16_t *>(yout) + cow;
+#pragma unroll
+        for (int k = 0; k < 2 * JR; ++k) {                         // pixels 8 k .. 8 k + 7 of the tile: row k / 2, columns 8 (k & 1) ...
+            const int j = k >> 1, col = 8 * (k & 1) + (lane >> 3);
+            const int oy = oyr[j], ox = x0 + col;
+            if (oy < 0 || ox >= p.W || cow >= p.Cout) continue;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(Ot + (16 * j + col) * OROW + chunk * 16);
+            *reinterpret_cast<u32x4 *>(ybase + (((size_t)on[j] * p.H + oy) * p.W + ox) * p.ld_out) = v;
+        }
+        return;
+    }
     if (p.act == RDFC_ACT_TANH) store_all([](float u) { return tanhf(u); });
     else if (p.act == RDFC_ACT_SIGMOID) store_all([](float u) { return 1.f / (1.f + expf(-u)); });
     else {
@@ -486,7 +531,12 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     const int pad = d->ph;
     GParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo,
               Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
-              d->act, d->slope, d->out_f32, 0, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect};
+              d->act, d->slope, d->out_f32, 0, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect, 0};
+    // whole-row stores: 2-byte results without an addend, channel rows of whole 16-byte chunks at 16-byte aligned addresses, a
+    // piecewise-linear epilogue (RDFC_GLDS_ROWSTORE=0: the direct 8-byte stores, for A/B runs)
+    static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
+    p.row_store = rows_on && !d->out_f32 && addend == nullptr && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+                  d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
     p.tiles_x = cdiv(p.W, TC);                                 // 128 co x (8 x 16) px or 64 co x (16 x 16) px per workgroup
     p.vstride = stack_rows(p.N, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, !reflect && stats == nullptr, p.tiles_y);
     if (d->dtype == RDFC_F16)
