@@ -171,6 +171,39 @@ __device__ inline float act_grad_out(float y, int act, float slope) {
     }
 }
 
+// ---- whole-row epilogue stores (round 4) ------------------------------------------------------
+// An MFMA accumulator lane holds 4 consecutive channels (8 bytes) of one pixel: stored directly, a wave's store instruction touches
+// 32 bytes of each of 16 pixel rows.  A timing build of conv3x3_glds without its stores showed what that costs: 64 -> 64 @
+// 16 x 228 x 304 138 -> 81 us, 128 -> 128 @ 114 x 152 103 -> 80, 256 -> 256 @ 57 x 76 101 -> 83 (the HBM time of those outputs is
+// 28 / 14 / 14 us).  The conv kernels therefore pass a wave's 64 px x 64 ch tile through the wave's own 9 KB of the (by then dead)
+// staging LDS -- 16 ds_write_b64 + 8 ds_read_b128 per lane -- and every store instruction writes 8 pixels x 128 contiguous bytes:
+// a quarter of the write requests, each a whole line (64 -> 64: 139 -> 117 us, 128 -> 128: 105 -> 91, 256 -> 256: 97 -> 87).
+// Usage: workgroup barrier (nobody reads the operand tiles any more) -> rs_put for every (pixel, 4-channel group) of the wave ->
+// rs_flush.  Both touch the calling wave's tile only: no further workgroup barrier.
+constexpr int RS_ROW = 144;                  // bytes per pixel row of the tile: 128 + 16 (bank spread, keeps rows 16-byte aligned)
+constexpr int RS_TILE = 64 * RS_ROW;         // bytes per wave
+template <int DT> __device__ __forceinline__ void rs_put(unsigned char *Ot, int px, int ch, const float (&v)[4]) {
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = cvt16<DT>(v[r]);
+    *reinterpret_cast<bf16x4 *>(Ot + px * RS_ROW + ch * 2) = o;
+}
+// y: the map's element 0 + the wave's first channel; nch: how many of the wave's 64 channels exist (a multiple of 8);
+// addr(px) -> element offset of tile pixel px (0 .. 63) in the map, < 0: no such pixel
+template <typename A> __device__ __forceinline__ void rs_flush(const unsigned char *Ot, int lane, bf16_t *y, int nch, A &&addr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int chunk = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int px = 8 * k + (lane >> 3);
+        const long off = addr(px);
+        if (off < 0 || chunk * 8 >= nch) continue;
+        *reinterpret_cast<u32x4 *>(y + off + chunk * 8) = *reinterpret_cast<const u32x4 *>(Ot + px * RS_ROW + chunk * 16);
+    }
+    __builtin_amdgcn_wave_barrier();         // (the tile may be refilled by the same wave)
+}
+
 // ---- wave / block reductions ---------------------------------------------------------
 __device__ inline float wave_sum(float v) {
 #pragma unroll

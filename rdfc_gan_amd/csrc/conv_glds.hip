@@ -403,41 +403,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
             }
         }
     };
-    // ---- whole-row stores (round 4).  A lane's accumulators are 4 consecutive channels (8 bytes) of 16 pixels: a wave's store
-    //      instruction touches 32 bytes of each of 16 pixel rows, and a timing build without the stores showed what that costs --
-    //      64 -> 64 @ 16 x 228 x 304: 138 -> 81 us, 128 -> 128 @ 114 x 152: 103 -> 80, 256 -> 256 @ 57 x 76: 101 -> 83 (the HBM time of
-    //      those outputs is 28 / 14 / 14 us).  Here every wave passes its 64 px x 64 co tile through its own 9 KB of the (now dead)
-    //      staging LDS -- 16 ds_write_b64 + 8 ds_read_b128 per lane -- and every store instruction writes 8 pixels x 128 contiguous
-    //      bytes: a quarter of the write requests, each a full line.  (Not with an addend or an f32 result: those keep the direct path.)
+    // ---- whole-row stores (common.h: rs_put / rs_flush); an f32 result keeps the direct path ---------------------------------------------
     if (p.row_store) {
         const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
-        constexpr int OROW = 144;                                  // bytes per pixel row of the wave's tile: 128 + 16 (bank spread; 16-byte aligned)
         __syncthreads();                                           // every wave is done with the operand tiles
-        unsigned char *Ot = smem + wave * (64 * OROW);
+        unsigned char *Ot = smem + wave * RS_TILE;
 #pragma unroll
         for (int j = 0; j < JR; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                bf16x4 o;
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float u = acc[i][j][r] + bv[i][r];
-                    o[r] = cvt16<DT>(u > 0.f ? u : u * ns);
+                    v[r] = u > 0.f ? u : u * ns;
                 }
-                *reinterpret_cast<bf16x4 *>(Ot + (16 * j + (lane & 15)) * OROW + (16 * i + q4) * 2) = o;
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int chunk = lane & 7, cow = co0 + wr * 64 + chunk * 8;
-        bf16_t *ybase = reinterpret_cast<bf16_t *>(yout) + cow;
+                const int co = co0 + wr * 64 + 16 * i + q4, ox = x0 + (lane & 15);
+                if (p.addend != nullptr && oyr[j] >= 0 && ox < p.W && co < p.Cout) {        // (the addend, in f32, from its 8-byte pieces)
+                    const size_t po = ((size_t)on[j] * p.H + oyr[j]) * p.W + ox;
+                    const bf16x4 t = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const bf16_t *>(p.addend) + po * p.ld_add + co);
 #pragma unroll
-        for (int k = 0; k < 2 * JR; ++k) {                         // pixels 8 k .. 8 k + 7 of the tile: row k / 2, columns 8 (k & 1) ...
-            const int j = k >> 1, col = 8 * (k & 1) + (lane >> 3);
-            const int oy = oyr[j], ox = x0 + col;
-            if (oy < 0 || ox >= p.W || cow >= p.Cout) continue;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(Ot + (16 * j + col) * OROW + chunk * 16);
-            *reinterpret_cast<u32x4 *>(ybase + (((size_t)on[j] * p.H + oy) * p.W + ox) * p.ld_out) = v;
-        }
+                    for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t[r]);
+                }
+                rs_put<DT>(Ot, 16 * j + (lane & 15), 16 * i + q4, v);
+            }
+        const int cow = co0 + wr * 64;
+        rs_flush(Ot, lane, reinterpret_cast<bf16_t *>(yout) + cow, p.Cout - cow, [&](int px) -> long {
+            const int j = px >> 4, ox = x0 + (px & 15);            // (j: compile-time after unrolling)
+            if (oyr[j] < 0 || ox >= p.W) return -1;
+            return (((long)on[j] * p.H + oyr[j]) * p.W + ox) * p.ld_out;
+        });
         return;
     }
     if (p.act == RDFC_ACT_TANH) store_all([](float u) { return tanhf(u); });
@@ -535,7 +530,8 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     // whole-row stores: 2-byte results without an addend, channel rows of whole 16-byte chunks at 16-byte aligned addresses, a
     // piecewise-linear epilogue (RDFC_GLDS_ROWSTORE=0: the direct 8-byte stores, for A/B runs)
     static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
-    p.row_store = rows_on && !d->out_f32 && addend == nullptr && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+    p.row_store = rows_on && !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+                  (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
     p.tiles_x = cdiv(p.W, TC);                                 // 128 co x (8 x 16) px or 64 co x (16 x 16) px per workgroup
     p.vstride = stack_rows(p.N, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, !reflect && stats == nullptr, p.tiles_y);

@@ -26,6 +26,7 @@ struct IGParams {
     int out_f32;
     const void *addend;          // optional map added to the result before the store (rdfc_conv2d_dgrad_add)
     int ld_add;
+    int row_store;               // epilogue through LDS: whole 128-byte channel rows per store instruction (common.h)
 };
 
 __device__ inline void glds16(const void *gsrc, unsigned lds_base) {
@@ -210,6 +211,38 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
             for (int r = 0; r < 4; ++r) bv[i][r] = (bias != nullptr && co + r < p.Cout) ? bias[co + r] : 0.f;
         }
     }
+    // ---- whole-row stores (common.h: rs_put / rs_flush); an addend is added here, in f32, from its 8-byte pieces -----------------------
+    if (p.row_store) {
+        const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
+        __syncthreads();                                           // every wave is done with the operand tiles
+        unsigned char *Ot = smem + wave * RS_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int po = pxo[wc * 64 + 16 * j + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + wr * 64 + 16 * i + q4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = acc[i][j][r] + bv[i][r];
+                    v[r] = u > 0.f ? u : u * ns;
+                }
+                if (p.addend != nullptr && po >= 0 && co < p.Cout) {       // (Cout and ld_add are multiples of 8 on this path)
+                    const bf16x4 t = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const bf16_t *>(p.addend) + (size_t)po * p.ld_add + co);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t[r]);
+                }
+                rs_put<DT>(Ot, 16 * j + (lane & 15), 16 * i + q4, v);
+            }
+        }
+        const int cow = co0 + wr * 64;
+        rs_flush(Ot, lane, reinterpret_cast<bf16_t *>(yout) + cow, p.Cout - cow, [&](int px) -> long {
+            const int po = pxo[wc * 64 + px];
+            return po < 0 ? -1 : (long)po * p.ld_out;
+        });
+        return;
+    }
     with_act(p.act, p.slope, [&](auto actf) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -312,7 +345,11 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
     if (zero == nullptr) return 0;
     IGParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, Cin, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo, Cout,
                d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw, ld_in, transposed ? d->ldx : d->ldy, transposed,
-               d->act, d->slope, d->out_f32, addend, ld_add};
+               d->act, d->slope, d->out_f32, addend, ld_add, 0};
+    static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
+    p.row_store = rows_on && !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+                  (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
+                  d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
     if (d->dtype == RDFC_F16)
         return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, st);
     if (Cout > 64 || mode == 3) return launch<128>(p, in, w, bias, out, zero, st);

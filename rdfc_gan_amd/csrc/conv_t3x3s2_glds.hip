@@ -32,6 +32,7 @@ struct TParams {
     int tiles_x, tiles_y;
     const void *addend;          // optional map added to the result before the store (rdfc_conv2d_dgrad_add)
     int ld_add;
+    int row_store;               // epilogue through LDS: whole 128-byte channel rows per store instruction (common.h)
 };
 
 constexpr int BK = 32, NT = 256, TCO = 64;
@@ -226,6 +227,48 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
             }
         }
     };
+    // ---- whole-row stores (common.h: rs_put / rs_flush): per result-row parity ry the wave's two column classes are 2 rows x 32
+    //      CONSECUTIVE result pixels x 64 channels = one 64-pixel tile (tile pixel = 32 j + 2 col + rx) -----------------------------------
+    if (p.row_store) {
+        const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
+        __syncthreads();                                           // every wave is done with the operand tiles
+        unsigned char *Ot = smem + wave * RS_TILE;
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+#pragma unroll
+            for (int rx = 0; rx < 2; ++rx) {
+                const int c = 2 * ry + rx;
+#pragma unroll
+                for (int j = 0; j < JR; ++j) {
+                    const int oy = 2 * (y0 + JR * wave + j) + ry, ox = 2 * (x0 + (lane & 15)) + rx;
+                    const bool live = oy < p.Hr && ox < p.Wr;
+                    const size_t po = ((size_t)n * p.Hr + oy) * p.Wr + ox;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = co0 + 16 * i + q4;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float u = acc[c][i][j][r] + bv[i][r];
+                            v[r] = u > 0.f ? u : u * ns;
+                        }
+                        if (p.addend != nullptr && live && co < p.Cout) {          // (Cout and ld_add are multiples of 8 / 4 on this path)
+                            const bf16x4 t4 = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const bf16_t *>(p.addend) + po * p.ld_add + co);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t4[r]);
+                        }
+                        rs_put<DT>(Ot, 32 * j + 2 * (lane & 15) + rx, 16 * i + q4, v);
+                    }
+                }
+            }
+            rs_flush(Ot, lane, reinterpret_cast<bf16_t *>(yout) + co0, p.Cout - co0, [&](int px) -> long {
+                const int j = px >> 5, oy = 2 * (y0 + JR * wave + j) + ry, ox = 2 * x0 + (px & 31);
+                if (oy >= p.Hr || ox >= p.Wr) return -1;
+                return (((long)n * p.Hr + oy) * p.Wr + ox) * p.ld_out;
+            });
+        }
+        return;
+    }
     with_act(p.act, p.slope, store_all);
 }
 
@@ -276,7 +319,11 @@ int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const voi
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
     TParams p{d->N, d->Ho, d->Wo, d->Hi, d->Wi, d->Co, d->Ci, d->ldy, d->ldx, d->act, d->slope, d->out_f32, cdiv(d->Wo, TC), cdiv(d->Ho, TRS),
-              addend, ld_add};
+              addend, ld_add, 0};
+    static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
+    p.row_store = rows_on && !d->out_f32 && p.Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(res) & 15) == 0 &&
+                  (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
+                  d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
     if (KS == 4) return d->dtype == RDFC_F16 ? launch<RDFC_F16, 4>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16, 4>(p, src, w_bwd, bias, res, zero, st);
     return d->dtype == RDFC_F16 ? launch<RDFC_F16, 3>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16, 3>(p, src, w_bwd, bias, res, zero, st);
 }
