@@ -111,6 +111,12 @@ int rdfc_conv2d_wgrad_reflect(const rdfc_conv_desc *d, const void *x, const void
  * the order of the adds).  torch.nn.grad.conv2d_weight in upstream's autograd (torch.nn.Conv2d, common.py:11-17) has no such
  * guarantee either; a caller that needs run-to-run identical training asks here. */
 int rdfc_conv2d_wgrad_deterministic(const rdfc_conv_desc *d, int reflect);
+/* The deterministic kernels keep their split-K partials in a scratch slab per (device, stream), grown on demand -- except inside a
+ * stream capture, where nothing can be allocated: a launch recorded into a HIP graph on a stream without a slab goes to the
+ * float-atomics kernels (rdfc_conv2d_wgrad_deterministic does not know about captures).  Call this BEFORE capturing on `stream` to
+ * give it its slab (bytes 0: the default 64 MB, enough for every layer of the hot path); a slab a captured graph refers to is never
+ * freed or moved afterwards. */
+int rdfc_wgrad_ring_reserve(void *stream, size_t bytes);
 
 /* y = act(conv(x, w_fwd) + bias).  bias: f32[Co] or NULL. */
 int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias,

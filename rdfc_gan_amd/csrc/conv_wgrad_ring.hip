@@ -305,30 +305,40 @@ const bf16_t *zero_page() {
 }
 
 // Scratch for the partial slabs: one buffer per (device, stream) -- launches on one stream run one after the other, so the next
-// launch's workgroups cannot overwrite slabs a reduction still reads.  Grown on demand (never while the stream is being captured).
-float *slab_for(hipStream_t st, size_t bytes) {
-    struct Ent {
-        int dev;
-        hipStream_t st;
-        void *ptr;
-        size_t cap;
-    };
-    static Ent tab[64];
-    static int n = 0;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
+// launch's workgroups cannot overwrite slabs a reduction still reads.  Grown on demand, with two exceptions: never while the stream is
+// being captured (no allocation inside a capture: the launch then goes to the float-atomics kernels unless the stream's slab was
+// reserved beforehand, rdfc_wgrad_ring_reserve), and never once a captured graph holds the pointer (a replay would read freed memory).
+namespace {
+struct SlabEnt {
+    int dev;
+    hipStream_t st;
+    void *ptr;
+    size_t cap;
+    bool pinned;                 // a captured graph refers to ptr: neither freed nor moved any more
+};
+SlabEnt g_slabs[64];
+int g_nslabs = 0;
+std::mutex g_slab_mu;
+}  // namespace
+
+float *slab_for(hipStream_t st, size_t bytes, bool reserve_only = false) {
+    std::lock_guard<std::mutex> lock(g_slab_mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    Ent *e = nullptr;
-    for (int i = 0; i < n; ++i)
-        if (tab[i].dev == dev && tab[i].st == st) e = &tab[i];
-    if (e != nullptr && e->cap >= bytes) return (float *)e->ptr;
+    SlabEnt *e = nullptr;
+    for (int i = 0; i < g_nslabs; ++i)
+        if (g_slabs[i].dev == dev && g_slabs[i].st == st) e = &g_slabs[i];
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // no allocation inside a capture
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (e != nullptr && e->cap >= bytes) {
+        if (capturing) e->pinned = true;
+        return (float *)e->ptr;
+    }
+    if (capturing || (e != nullptr && e->pinned)) return nullptr;           // no allocation inside a capture; a pinned slab stays where it is
     if (e == nullptr) {
-        if (n == 64) return nullptr;
-        e = &tab[n++];
-        *e = Ent{dev, st, nullptr, 0};
+        if (g_nslabs == 64) return nullptr;
+        e = &g_slabs[g_nslabs++];
+        *e = SlabEnt{dev, st, nullptr, 0, false};
     }
     if (e->ptr != nullptr) {
         if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
@@ -342,6 +352,7 @@ float *slab_for(hipStream_t st, size_t bytes) {
         return nullptr;
     }
     e->cap = cap;
+    (void)reserve_only;
     return (float *)e->ptr;
 }
 
@@ -421,6 +432,15 @@ static bool ring_takes(const rdfc_conv_desc *d, int reflect, int &L) {
 extern "C" int rdfc_conv2d_wgrad_deterministic(const rdfc_conv_desc *d, int reflect) {
     int L = 0;
     return d != nullptr && ring_takes(d, reflect, L) ? 1 : 0;
+}
+
+// include/rdfc_hip.h: make sure `stream` owns a slab of at least `bytes` (0: the default 64 MB, enough for every layer of the hot path)
+// BEFORE the stream is captured into a graph -- inside a capture nothing can be allocated, and a launch without a slab falls back to the
+// float-atomics kernels (same values up to the order of the adds, not bitwise reproducible).
+extern "C" int rdfc_wgrad_ring_reserve(void *stream, size_t bytes) {
+    RDFC_REQUIRE(slab_for((hipStream_t)stream, bytes ? bytes : (size_t)(64u << 20), true) != nullptr,
+                 "rdfc_wgrad_ring_reserve: cannot allocate %zu bytes for this stream (capturing already, or out of memory)", bytes);
+    return 0;
 }
 
 // Called by rdfc_try_wgrad_glds (conv_wgrad_glds.hip) ahead of its own kernels; returns 1 if it took the launch.

@@ -372,6 +372,11 @@ def conv_wgrad(d, x, dy, into=None, stream=None, reflect=False):
     return dw
 
 
+def wgrad_ring_reserve(stream, nbytes=0):
+    """give `stream` (a torch.cuda.Stream) the deterministic weight-gradient kernels' scratch slab before it is captured into a graph"""
+    _chk(lib().rdfc_wgrad_ring_reserve(stream.cuda_stream, C.c_size_t(nbytes)), 'rdfc_wgrad_ring_reserve')
+
+
 def wgrad_is_deterministic(d, reflect=False):
     """whether conv_wgrad(d, ...) sums its split-K partials in a fixed order (bitwise reproducible) or with float atomics"""
     return bool(lib().rdfc_conv2d_wgrad_deterministic(C.byref(d), int(reflect)))

@@ -66,6 +66,24 @@ class LossScaler:
         """steps each attached optimizer has skipped so far (host read-back)"""
         return [int(o._ostate[1]) for o in self._optimizers]
 
+    # ---- checkpointing: a resumed f16 run continues with the scale it had reached, not with the initial one -----------------
+    def state_dict(self):
+        st = [float(v) for v in self.state.cpu()]
+        return dict(scale=st[0], clean_steps=int(st[2]), skipped=self.skipped())
+
+    def load_state_dict(self, sd):
+        """call AFTER the optimizers' load_state_dict (which stores the steps really taken and zeroes the skip counters): restores
+        the scale, the clean-step counter and every optimizer's skip counter (its step count grows by the same number, so the
+        bias corrections -- over steps minus skipped -- continue unchanged)"""
+        scale = float(sd['scale'])
+        self.state.copy_(torch.tensor([scale, 1.0 / scale, float(sd.get('clean_steps', 0)), 0.0], dtype=torch.float32))
+        for o, k in zip(self._optimizers, sd.get('skipped', [])):
+            k = int(k)
+            o._ostate.copy_(torch.tensor([0.0, float(k)], dtype=torch.float32))
+            o.steps += k
+            if o._hyper is not None:
+                o._hyper[1] = float(o.steps)
+
 
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-3, betas=(0.5, 0.999), eps=1e-8, weight_decay=None):

@@ -766,7 +766,13 @@ class RDFCGAN:
         torch.cuda.synchronize()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls belong to the graph
-        mode = dict(capture_error_mode='thread_local')
+        # one capture stream for the three graphs, given the deterministic weight-gradient kernels' scratch slab first (nothing can be
+        # allocated inside a capture: without it every captured weight gradient would fall back to the float-atomics kernels)
+        cs = self.__dict__.get('_capture_stream')
+        if cs is None:
+            cs = self._capture_stream = torch.cuda.Stream(self.device)
+        hip.wgrad_ring_reserve(cs)
+        mode = dict(capture_error_mode='thread_local', stream=cs)
         try:
             with torch.cuda.graph(g1, **mode):
                 stats = self._seg_G()
@@ -937,6 +943,8 @@ class RDFCGAN:
                 ckpt[f'{name}_optimizer_state_dict'] = o.state_dict()
             for name, s in self.lr_schedulers.items():
                 ckpt[f'{name}_lr_scheduler_state_dict'] = s.state_dict()
+            if self.scaler is not None:           # (a key of its own: upstream-format checkpoints simply do not have it)
+                ckpt['loss_scaler_state_dict'] = self.scaler.state_dict()
         torch.save(ckpt, filename)
 
     def load_from(self, load_path, strict=False):
@@ -956,6 +964,8 @@ class RDFCGAN:
         for name, s in self.lr_schedulers.items():
             if f'{name}_lr_scheduler_state_dict' in ckpt:
                 s.load_state_dict(ckpt[f'{name}_lr_scheduler_state_dict'])
+        if self.scaler is not None and 'loss_scaler_state_dict' in ckpt:
+            self.scaler.load_state_dict(ckpt['loss_scaler_state_dict'])
         return ckpt['meta'].get('epoch', 0)
 
     def save_samples(self, save_dir, iters):

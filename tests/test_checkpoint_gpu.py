@@ -92,3 +92,47 @@ def test_resume_from_a_checkpoint_written_upstreams_way(tmp_path):
     for i in range(n_a2b):
         assert torch.equal(got[i]['exp_avg'].cpu(), state[i]['exp_avg']) and torch.equal(got[i]['exp_avg_sq'].cpu(), state[i]['exp_avg_sq'])
     assert m.optimizer_G.steps == 1
+
+
+def test_f16_overflow_skips_the_whole_step_and_resume_keeps_the_scaler_state(tmp_path):
+    """Model-level overflow path (the kernels are covered in test_kernels_gpu.py): with an absurd loss scale the f16 backward overflows,
+    BOTH optimizers must skip -- parameters, Adam moments and the step count that a checkpoint stores unchanged --, the scale halves, and a
+    model resumed from a checkpoint continues with that scale and those skip counters (not with the initial 1024 / 0)."""
+    from rdfc_gan_amd import functional as Fh
+    setup_dtype(torch.float16)
+    try:
+        a = _model()
+        for key, net in a.models.items():
+            net.load_state_dict(det_state_dict(net.state_dict(), 0))
+        Fh.invalidate_packed_weights()
+        a.train()
+        assert a.scaler is not None and a.scaler.dynamic
+        _step(a, 0)                                                   # a clean step first: moments are non-zero afterwards
+        assert a.scaler.skipped() == [0, 0]
+        before = {n: (o.flat.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone()) for n, o in a.optimizers.items()}
+        a.scaler.set_scale(2.0 ** 40)                                 # every gradient overflows half precision
+        losses = _step(a, 1)
+        assert all(np.isfinite(v) for v in losses.values())           # the forward (and the logged losses) are unaffected
+        assert a.scaler.skipped() == [1, 1]
+        assert a.scaler.scale() == 2.0 ** 39                          # backed off once
+        for n, o in a.optimizers.items():
+            for got, ref in zip((o.flat, o.exp_avg, o.exp_avg_sq), before[n]):
+                assert torch.equal(got, ref), f'{n}: a skipped step changed optimizer state'
+            assert o.steps_taken() == 1
+            assert float(o.state_dict()['state'][0]['step']) == 1.0   # what a checkpoint stores: steps really taken
+        a.scaler.set_scale(512.0)
+        path = str(tmp_path / 'f16.pth')
+        a.save_ckpt(path, meta=dict(epoch=1))
+        assert torch.load(path, map_location='cpu')['loss_scaler_state_dict'] == dict(scale=512.0, clean_steps=0, skipped=[1, 1])
+        la = _step(a, 2)
+        b = _model()
+        assert b.scaler.scale() == 1024.0
+        b.resume_from(path)
+        assert b.scaler.scale() == 512.0 and b.scaler.skipped() == [1, 1]
+        assert all(o.steps_taken() == 1 for o in b.optimizers.values())
+        b.train()
+        lb = _step(b, 2)
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 2e-3 * abs(la[k]) + 1e-4, (k, la[k], lb[k])
+    finally:
+        setup_dtype(torch.float32)

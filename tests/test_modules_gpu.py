@@ -51,7 +51,7 @@ def err(a, b):
     return float(np.abs(a - b).max()), float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-def check(net, res, g, out_atol, grad_in_l2, grad_l2, norm_median, norm_max, buf_rtol, stock=None):
+def check(net, res, g, out_atol, grad_in_l2, grad_l2, norm_median, norm_max, buf_rtol, stock=None, out_rms=None):
     """collect every metric first (printed with -s / on failure), then assert.
 
     Outputs: max abs error (maps live in [-1, 1]).  Gradients: relative L2 error -- an
@@ -71,6 +71,9 @@ def check(net, res, g, out_atol, grad_in_l2, grad_l2, norm_median, norm_max, buf
     for k in g.files:
         if k.startswith(('eval.', 'train.')):
             note(k, err(res[k].detach().cpu().numpy(), g[k])[0], out_atol)
+            if out_rms is not None:          # (where a max over 9 120 pixels says little: bf16 guidance in front of 18 sampling steps)
+                d = res[k].detach().cpu().numpy().astype(np.float64) - g[k]
+                note(k + '/rms', float(np.sqrt(np.mean(d * d))), out_rms)
         elif k.startswith('grad_in.'):
             e = err(res[k].detach().cpu().numpy(), g[k])[1]
             note(k, e, grad_in_l2)
@@ -119,10 +122,14 @@ TOLS = {
               # f16 measured: out 9.5e-3, grad_in 0.116 (0.91x a stock f16 evaluation), sampled grads 0.29, median 2.3e-3, max 6.8e-2, buffers 1.1e-4
     'g_a2b_nlspn': {torch.float32: dict(out_atol=1e-4, grad_in_l2=2e-3, grad_l2=2e-3, norm_median=2e-4, norm_max=1e-3, buf_rtol=1e-5),
                     # f32 measured with the fused NLSPN kernels: out 4.7e-5 (18 propagation steps), grad_in 6.7e-4, grads 9.5e-4, max 3.0e-4
-                    torch.bfloat16: dict(out_atol=0.8, grad_in_l2=0.6, grad_l2=1.1, norm_median=2e-2, norm_max=1.1, buf_rtol=2e-3),
-                    # bf16: offsets come from bf16 guidance features; 18 steps of sampling at slightly different positions: out 0.41, aff_scale_const 0.53
-                    torch.float16: dict(out_atol=7e-2, grad_in_l2=0.2, grad_l2=0.7, norm_median=6e-3, norm_max=8e-2, buf_rtol=3e-4)},
-                    # f16 measured: out 3.2e-2, grad_in 9.5e-2, sampled grads 0.33, median 2.7e-3, max 3.7e-2, buffers 1.1e-4
+                    torch.bfloat16: dict(out_atol=0.8, out_rms=3e-2, grad_in_l2=0.6, grad_l2=1.1, norm_median=2e-2, norm_max=1.1, buf_rtol=2e-3),
+                    # bf16: offsets come from bf16 guidance features; 18 steps of sampling at slightly different positions move a few pixels
+                    # of the train-mode map a long way (max 0.41, 99.9th percentile 0.12, on this fixture's N(0, 0.02) guidance weights the
+                    # recursion amplifies rounding: test_shapes_gpu.py::test_config3_*).  The max limit is a ceiling only; what is asserted
+                    # for this combination is the RMS error over each output map: measured 1.5e-2 (train.depth_map_2; 8.9e-3 on pred_depth),
+                    # limit 2x.  aff_scale_const 0.53
+                    torch.float16: dict(out_atol=7e-2, out_rms=4e-3, grad_in_l2=0.2, grad_l2=0.7, norm_median=6e-3, norm_max=8e-2, buf_rtol=3e-4)},
+                    # f16 measured: out 3.2e-2 (rms 1.7e-3), grad_in 9.5e-2, sampled grads 0.33, median 2.7e-3, max 3.7e-2, buffers 1.1e-4
     'g_b2a': {torch.float32: dict(out_atol=3e-5, grad_in_l2=7e-3, grad_l2=7e-3, norm_median=4e-5, norm_max=1.1e-2, buf_rtol=1e-5),
               # f32 measured: out 1.25e-5, grad_in 3.5e-3, grads 3.1e-3, median 1.8e-5, max 5.3e-3 (a weight in front of an InstanceNorm)
               torch.bfloat16: dict(out_atol=0.12, grad_in_l2=0.45, grad_l2=5e-2, norm_median=3e-3, norm_max=0.3, buf_rtol=2e-3),
