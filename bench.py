@@ -368,18 +368,21 @@ def main():
         # of every gradient bucket costs alone, so that a scaling curve can be read against it
         comm = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), buckets=[])
         for oname, o in model.optimizers.items():
-            for bi, (lo, hi) in enumerate(o._buckets):
-                view = o.flat_grad[lo:hi]
-                dist.all_reduce(view)                                  # warm-up (RCCL sets up its rings per size class)
+            for bi in range(len(o._buckets)):
+                views = [o.flat_grad[lo:hi] for lo, hi in o.bucket_ranges(bi)]      # (a bucket is one or a few ranges of the flat gradient)
+                nel = sum(v.numel() for v in views)
+                for v in views:
+                    dist.all_reduce(v)                                 # warm-up (RCCL sets up its rings per size class)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                dist.all_reduce(view)
+                for v in views:
+                    dist.all_reduce(v)
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1)
-                comm['buckets'].append(dict(optimizer=oname, bucket=bi, mbytes=round(4e-6 * (hi - lo), 1), allreduce_ms=round(ms, 3),
-                                            bus_gb_s=round(2 * (world - 1) / world * 4e-9 * (hi - lo) / (ms * 1e-3), 1)))
+                comm['buckets'].append(dict(optimizer=oname, bucket=bi, ranges=len(views), mbytes=round(4e-6 * nel, 1), allreduce_ms=round(ms, 3),
+                                            bus_gb_s=round(2 * (world - 1) / world * 4e-9 * nel / (ms * 1e-3), 1)))
     assert all(np.isfinite(v) for v in final.values()), f'non-finite losses: {final}'
 
     if rank == 0:

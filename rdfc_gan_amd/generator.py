@@ -170,15 +170,26 @@ class RDFGenerator(nn.Module):
         r1, r1a, r1b = Fh.fanout(self.rgb_branch_en1(nrm), 3)
         d, skip = [None, d1], {}
         r, rskip = [None, r1], {}
+        # Backward markers for the data-parallel gradient exchange (rdfc_gan.py: init_optimizer): `bwd_marks(name)` is called from inside
+        # the backward when it has passed the en6 output ('dec': everything on the decoder side of this branch is final) and the input
+        # of en5 ('deep': en5 + en6 are final) -- twice each, once per branch.  None: no markers (single-process runs).
+        marks = self.__dict__.get('bwd_marks')
+
+        def mark(t, name):
+            return Fh.backward_marker(t, lambda: marks(name)) if marks is not None else t
         for idx in range(2, 7):
             with on_side():
-                nxt = D.forward_encoder_layer(d[-1], idx)
+                nxt = D.forward_encoder_layer(mark(d[-1], 'deep') if idx == 5 else d[-1], idx)
                 if idx < 6:                                  # en2..en5 feed the next stage and a decoder skip connection
                     nxt, skip[idx] = Fh.fanout(nxt, 2)
+                else:
+                    nxt = mark(nxt, 'dec')
                 d.append(nxt)
-            nxt = R.forward_encoder_layer(r[-1], idx)
+            nxt = R.forward_encoder_layer(mark(r[-1], 'deep') if idx == 5 else r[-1], idx)
             if idx < 6:
                 nxt, rskip[idx] = Fh.fanout(nxt, 2)
+            else:
+                nxt = mark(nxt, 'dec')
             r.append(nxt)
         ready = []                                           # one event per fusion input (depth-decoder feature of a level)
 

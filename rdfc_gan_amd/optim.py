@@ -11,6 +11,8 @@ buffer (autograd accumulates into it in place).
 """
 import os
 
+import numpy as np
+
 import torch
 import torch.distributed as dist
 
@@ -116,8 +118,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.scaler = None            # LossScaler.attach(): device-side (dynamic) loss scale + overflow check, replaces loss_scale
         self._ostate = None           # device {overflow in this step, steps skipped}
         self._pending = []            # events of the in-flight bucket all-reduces
-        self._buckets = [(0, n)]
+        self._buckets = [[(0, n)]]
         self._started = set()
+        self.started_order = []       # bucket indices in the order their exchange was started in the current step (tests read it)
         self._comm_stream = None
         self._hyper = None            # device {lr, step}: set by make_capturable(); the step then launches rdfc_adam_step_dev
         self._hyper_lr = None
@@ -143,12 +146,14 @@ class FlatAdam(torch.optim.Optimizer):
         the captured zero-fill but no Python: without this every bucket still counts as started from the capture on and the
         replicas would stop exchanging gradients"""
         self._started = set()
+        self.started_order = []
 
     def zero_grad(self, set_to_none=False):
         # (no join of the helper streams here: step() / the all-reduce joined them before they read the gradients, and the
         # other optimizer's weight gradients may keep running under this one's backward)
         self.wait_grads()
         self._started = set()
+        self.started_order = []
         if self.flat_grad.is_cuda:
             hip.zero_(self.flat_grad)       # hipMemsetAsync
         else:
@@ -170,13 +175,30 @@ class FlatAdam(torch.optim.Optimizer):
     # the train step starts a bucket's sum-all-reduce (RCCL over xGMI, on a communication stream of its own) as soon as
     # the backward of the network that owns it has been enqueued, so that the exchange runs under the rest of the
     # backward / the next phase of the step.  1/world_size is folded into the Adam kernel.  Default: one bucket.
-    def set_buckets(self, ranges):
-        """ranges: [(start, end), ...] element ranges of the flat buffers, disjoint, covering everything"""
-        ranges = [(int(a), int(b)) for a, b in ranges if b > a]
-        assert sorted(ranges)[0][0] == 0 and sorted(ranges)[-1][1] == self.flat.numel()
-        assert all(x[1] == y[0] for x, y in zip(sorted(ranges), sorted(ranges)[1:])), 'buckets must tile the flat buffer'
-        self._buckets = ranges
+    def set_buckets(self, buckets):
+        """buckets: [bucket, ...]; a bucket is an element range (start, end) of the flat buffers or a list of such ranges (the
+        parameters whose gradients become final together need not be neighbours in the flat buffer: RDFGenerator's decoders sit between
+        its encoders in parameter order).  All ranges disjoint, covering everything."""
+        norm = []
+        for b in buckets:
+            rs = [b] if isinstance(b[0], (int, np.integer)) else list(b)
+            rs = sorted((int(a), int(c)) for a, c in rs if c > a)
+            merged = []
+            for a, c in rs:                       # neighbours become one collective
+                if merged and merged[-1][1] == a:
+                    merged[-1] = (merged[-1][0], c)
+                else:
+                    merged.append((a, c))
+            if merged:
+                norm.append(merged)
+        flat = sorted(r for b in norm for r in b)
+        assert flat[0][0] == 0 and flat[-1][1] == self.flat.numel()
+        assert all(x[1] == y[0] for x, y in zip(flat, flat[1:])), 'buckets must tile the flat buffer'
+        self._buckets = norm
         self._started = set()
+
+    def bucket_ranges(self, i):
+        return list(self._buckets[i])
 
     def param_range(self, params):
         """element range of a run of consecutive parameters (as passed to the constructor) in the flat buffers"""
@@ -208,10 +230,11 @@ class FlatAdam(torch.optim.Optimizer):
         if not self._distributed() or i in self._started:
             return
         self._started.add(i)
-        a, b = self._buckets[i]
-        view = self.flat_grad[a:b]
+        self.started_order.append(i)
+        views = [self.flat_grad[a:b] for a, b in self._buckets[i]]
         if not self.flat_grad.is_cuda:
-            dist.all_reduce(view)             # gloo / CPU tests
+            for view in views:
+                dist.all_reduce(view)         # gloo / CPU tests
             return
         dev = self.flat_grad.device
         cur = torch.cuda.current_stream(dev)
@@ -224,7 +247,8 @@ class FlatAdam(torch.optim.Optimizer):
                 if s_ is not None:
                     cs.wait_stream(s_)
             with torch.cuda.stream(cs):
-                dist.all_reduce(view)
+                for view in views:
+                    dist.all_reduce(view)
             ev = torch.cuda.Event()
             ev.record(cs)
             self._pending.append(ev)
@@ -236,7 +260,8 @@ class FlatAdam(torch.optim.Optimizer):
             if s_ != issue and s_ != cur:
                 issue.wait_stream(s_)
         with torch.cuda.stream(issue):
-            self._pending.append(dist.all_reduce(view, async_op=True))
+            for view in views:
+                self._pending.append(dist.all_reduce(view, async_op=True))
 
     def all_reduce_grads_async(self):
         """start the all-reduce of every bucket that has not been started in this step.  No-op when not distributed."""

@@ -286,19 +286,37 @@ class RDFCGAN:
             for o in self.optimizers.values():
                 self.scaler.attach(o)
         # Data-parallel exchange in buckets, in the order in which the gradients become final (upstream: DDP's 25 MB
-        # reverse-order buckets, rdfc_gan.py:102-119).  G: G_B2A's backward completes first (bucket 0, started by a marker on
-        # its input while G_A2B's backward still runs), then G_A2B in three chunks when the backward ends; D: one bucket per
-        # discriminator, each started when its own backward has been enqueued.
+        # reverse-order buckets, rdfc_gan.py:102-119), each started from INSIDE the backward by a marker (functional.backward_marker):
+        #   0  G_B2A (31 MB): its backward completes first (marker on its input);
+        #   1  G_A2B's decoder side -- decoders, W-AdaIN fusion layers, heads, NLSPN (~27 MB): final when the backward of both
+        #      branches has passed the en6 outputs (markers in RDFGenerator.forward);
+        #   2  G_A2B's deep encoder stages en5 + en6 of both branches (~86 MB, two thirds of the network's parameters): final when
+        #      the backward has passed the inputs of en5;
+        #   3  the rest (en1 .. en4, ~24 MB): at the end of the backward.
+        # Round 3 cut G_A2B into three chunks in PARAMETER order and started all of them when the backward had ended.
         oG, oD = self.optimizer_G, self.optimizer_D
         a0, a1 = oG.param_range(list(self.G_A2B.parameters()))
         b0, b1 = oG.param_range(list(self.G_B2A.parameters()))
-        cuts, off, third = [a0], a0, (a1 - a0 + 2) // 3
-        for p in self.G_A2B.parameters():       # chunk boundaries on parameter boundaries
-            off += p.numel()
-            if off - cuts[-1] >= third and off < a1:
-                cuts.append(off)
-        cuts.append(a1)
-        oG.set_buckets([(b0, b1)] + list(zip(cuts[:-1], cuts[1:])))
+        G = self.G_A2B
+        if hasattr(G, 'rgb_branch_encoder_decoder'):
+
+            def rng(mods):
+                return [oG.param_range(list(m.parameters())) for m in mods if next(m.parameters(), None) is not None]
+            R, Dn = G.rgb_branch_encoder_decoder, G.depth_branch_encoder_decoder
+            deep = rng([R.en5, R.en6, Dn.en5, Dn.en6])
+            shallow = rng([G.rgb_branch_en1, R.en2, R.en3, R.en4, G.depth_branch_en1_rgb, G.depth_branch_en1_depth, Dn.en2, Dn.en3, Dn.en4])
+            dec, at = [], a0                                  # everything of G_A2B that is neither: the decoder side
+            for lo, hi in sorted(deep + shallow):
+                if lo > at:
+                    dec.append((at, lo))
+                at = hi
+            if at < a1:
+                dec.append((at, a1))
+            oG.set_buckets([[(b0, b1)], dec, deep, shallow])
+            self._G_bucket = dict(G_B2A=0, dec=1, deep=2, rest=3)
+        else:                                                 # any other generator class: one bucket behind G_B2A's
+            oG.set_buckets([(b0, b1), (a0, a1)])
+            self._G_bucket = dict(G_B2A=0, rest=1)
         oD.set_buckets([oD.param_range(list(self.disc_A.parameters())), oD.param_range(list(self.disc_B.parameters()))])
         if self.use_label_net:
             self.optimizer_Label = FlatAdam(self.G_label.parameters(), lr=lr, betas=betas)   # rdfc_gan.py:145-147
@@ -436,8 +454,15 @@ class RDFCGAN:
         normal_again = self._normal('fake_A_again', None)
         # group 0 = G_A2B(real_A, ...) of forward() (:193); group 1 = G_A2B(fake_A, ...): the dead forward (:207) and the
         # recomputation in backward_G (:234) see the same batch statistics -> two running-statistics updates
-        with layers.bn_groups((1, 2)):
-            out = self.G_A2B(None, _stack2(self.aux_A, self.aux_A), _stack2(self.fake_normal_realA, normal_again))['pred_depth']
+        # (under data parallelism G_A2B's backward starts its own gradient buckets: markers at the decoder / encoder boundary and
+        #  in front of the deep encoder stages of both branches, init_optimizer)
+        self._G_marks = dict(dec=0, deep=0)
+        self.G_A2B.__dict__['bwd_marks'] = self._on_G_mark if (dp_active() and self.is_train and not getattr(self, '_graph_mode', False)) else None
+        try:
+            with layers.bn_groups((1, 2)):
+                out = self.G_A2B(None, _stack2(self.aux_A, self.aux_A), _stack2(self.fake_normal_realA, normal_again))['pred_depth']
+        finally:
+            self.G_A2B.__dict__['bwd_marks'] = None
         fake_B, self.rec_B = _SplitBatch.apply(out, B)
         self.fake_B = self._pepper(fake_B)
         # fake_B feeds G_B2A, D_A and the L1 term; fake_A feeds D_B and its L1 term: their cotangents are summed by one HIP pass
@@ -449,6 +474,14 @@ class RDFCGAN:
         out = self.G_B2A(Fh.backward_marker(_stack2(self.real_B, fB_cyc), self._start_G_B2A_bucket))
         self.fake_A, self.rec_A = _SplitBatch.apply(out, B)
         self._fA_D, self._fA_L1 = Fh.fanout_flat(self.fake_A, 2)
+
+    def _on_G_mark(self, name):
+        """called from inside G_A2B's backward (RDFGenerator.forward's markers), once per branch: when both branches have passed the
+        point, the bucket whose gradients are final by then starts its all-reduce (the weight-gradient stream, from which it is
+        issued, has the layers' weight gradients in front of it; the other branch's stream is waited for: helpers=True)"""
+        self._G_marks[name] += 1
+        if self._G_marks[name] == 2 and name in self._G_bucket:
+            self.optimizer_G.all_reduce_bucket_async(self._G_bucket[name])
 
     def _start_G_B2A_bucket(self):
         if self.is_train and not getattr(self, '_graph_mode', False):

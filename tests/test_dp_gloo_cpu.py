@@ -48,6 +48,20 @@ def _worker(rank, world, port, q):
         opt.all_reduce_grads_async()                        # the rest; bucket 0 is not reduced a second time
         opt.wait_grads()
         assert torch.all(opt.flat_grad == 3.0), 'a bucket was skipped or reduced twice'
+        # a bucket made of several ranges (parameters that become final together need not be neighbours: G_A2B's decoder side sits
+        # between its encoders in parameter order): both ranges go out with the bucket, the issue order is recorded
+        opt.zero_grad()
+        l0, h0 = opt.param_range(list(net[0].parameters()))
+        l1, h1 = opt.param_range(list(net[1].parameters()))
+        assert (l0, h1, h0) == (0, lo, l1)
+        opt.set_buckets([[(l0, h0), (lo, hi)], [(l1, h1)]])
+        assert opt.bucket_ranges(0) == [(l0, h0), (lo, hi)] and opt.bucket_ranges(1) == [(l1, h1)]
+        opt.flat_grad.fill_(float(rank + 1))
+        opt.all_reduce_bucket_async(0)
+        assert torch.all(opt.flat_grad[l0:h0] == 3.0) and torch.all(opt.flat_grad[lo:hi] == 3.0) and torch.all(opt.flat_grad[l1:h1] == float(rank + 1))
+        opt.all_reduce_grads_async()
+        opt.wait_grads()
+        assert torch.all(opt.flat_grad == 3.0) and opt.started_order == [0, 1]
         opt.set_buckets([(0, opt.flat.numel())])
         # autograd accumulates into the persistent views (no re-allocation of .grad)
         opt.zero_grad()

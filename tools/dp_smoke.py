@@ -62,6 +62,16 @@ def two_steps(distributed):
 m, trace = two_steps(True)
 losses = trace[-1]
 flat = torch.cat([o.flat for o in m.optimizers.values()]).float()
+# the issue order of the last eager step's gradient buckets: G = [G_B2A, G_A2B decoder side, deep encoder stages, the rest] -- the first
+# three are started from INSIDE the backward (markers), i.e. they are in flight before it ends; the discriminators' buckets likewise
+if not graph and not full:
+    oG = m.optimizers['G']
+    assert len(oG._buckets) == 4 and oG.started_order == [0, 1, 2, 3], (len(oG._buckets), oG.started_order)
+    assert m.__dict__['_G_marks'] == dict(dec=2, deep=2), m.__dict__['_G_marks']
+    sizes = [sum(b - a for a, b in oG.bucket_ranges(i)) * 4e-6 for i in range(4)]
+    assert sizes[2] > 2 * sizes[1] > 0 and sizes[2] > 2 * sizes[3] > 0, sizes           # the deep stages are the bulk (86 of 168 MB)
+    if rank == 0:
+        print(f'dp_smoke: G buckets in issue order (MB): {[round(x, 1) for x in sizes]}')
 if backend == 'nccl':
     from rdfc_gan_amd.optim import dp_active
     assert dp_active() and dist.get_backend() == 'nccl'
