@@ -122,9 +122,10 @@ int rdfc_wgrad_ring_reserve(void *stream, size_t bytes);
 int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias,
                         void *y, void *stream);
 /* Forward convolution that also produces the per-tile partial statistics {sum, sum of squares}[G][nchunk][2][Co] of the
- * values it stores, for the normalisation layer behind it (G = 1 batch norm, G = N instance norm): the separate
- * rdfc_norm_stats pass over y disappears.  nchunk = rdfc_conv_stats_nchunk(d, G); 0 means no fused kernel covers the
- * shape (call rdfc_conv2d_forward + rdfc_norm_stats instead).  Finalize with rdfc_norm_finalize_n. */
+ * values it stores, for the normalisation layer behind it: G groups of N / G consecutive images each (G = 1 batch norm, G = N
+ * instance norm, in between BatchNorm over G stacked batches); the separate rdfc_norm_stats pass over y disappears.
+ * nchunk = rdfc_conv_stats_nchunk(d, G) rows per group; 0 means no fused kernel covers the shape (call rdfc_conv2d_forward +
+ * rdfc_norm_stats instead).  Finalize with rdfc_norm_finalize_n / rdfc_norm_finalize_seq / rdfc_norm_finalize_apply_seq. */
 int rdfc_conv_stats_nchunk(const rdfc_conv_desc *d, int G);
 int rdfc_conv2d_forward_stats(const rdfc_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
                               float *partial, int G, void *stream);

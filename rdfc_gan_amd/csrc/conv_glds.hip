@@ -33,7 +33,10 @@ struct GParams {
     int out_f32;
     int tiles_x, tiles_y;
     int vstride;                 // > 0: the batch is tiled as ONE tall map, image n at virtual rows [n * vstride, n * vstride + H) (stack_rows below)
-    int stats_groups;            // fused statistics: 0 = off, 1 = one group (batch norm), N = one group per image (instance norm)
+    int gstride, npg;            // fused statistics over G groups of npg consecutive images: group g starts at virtual row g * gstride (a multiple
+                                 // of the tile height: no tile straddles two groups), image l of it at + l * vstride; gstride 0: one run of images
+    int stats_groups;            // fused statistics: 0 = off, else the number of groups G (1: batch norm, N: instance norm, in between: BatchNorm
+                                 // over G stacked batches)
     const void *addend;          // optional map (2-byte elements, pixel stride ld_add) added to the result before the store: the
     int ld_add;                  // input gradient of a residual junction in one pass (rdfc_conv2d_dgrad_add)
     int reflect;                 // forward only: out-of-image patch pixels read their mirror image (ReflectionPad2d folded into the loader)
@@ -72,6 +75,23 @@ __device__ unsigned long long g_stamps[8][9][6];
 #else
 #define RDFC_STAMP(TAP, K)
 #endif
+
+// virtual row of the stacked batch -> (image, row inside it); image = N: the row belongs to no image (it reads zeros / stores nothing)
+__device__ __forceinline__ void vrow(const GParams &p, int v, int &img, int &row) {
+    if (v < 0) {
+        img = p.N;
+        row = 0;
+        return;
+    }
+    int g = 0;
+    if (p.gstride) {
+        g = v / p.gstride;
+        v -= g * p.gstride;
+    }
+    const int l = v / p.vstride;
+    row = v - l * p.vstride;
+    img = (p.gstride && l >= p.npg) ? p.N : g * p.npg + l;
+}
 
 // Variants measured and removed in round 3 (numbers in DESIGN.md section 7 and profiles/r01_conv_glds_stamps.txt): producer / consumer
 // specialisation (4 consumer + 4 | 2 producer waves, fragment reads pipelined one phase ahead), 64 co x 128 px wave tiles, 8-wave
@@ -134,10 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
             if (q < NPATCH) {
                 const int py = q / PW, px = q - py * PW;
                 int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px, ni = n;
-                if (p.vstride) {           // virtual row -> (image, row); the rows between two images read zeros (iy >= Hin below)
-                    ni = iy >= 0 ? iy / p.vstride : p.N;
-                    iy -= ni * p.vstride;
-                }
+                if (p.vstride) vrow(p, iy, ni, iy);         // virtual row -> (image, row); the rows between two images read zeros (iy >= Hin below)
                 if (p.reflect) {           // LDS-DMA sources are per lane: the halo of a reflection-padded map is just another address
                     iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);
                     ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
@@ -273,10 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
 #pragma unroll
     for (int j = 0; j < JR; ++j) {
         int v = y0 + JR * wc + j, ni = n;
-        if (p.vstride) {
-            ni = v / p.vstride;
-            v -= ni * p.vstride;
-        }
+        if (p.vstride) vrow(p, v, ni, v);
         on[j] = ni;
         oyr[j] = (ni < p.N && v < p.H) ? v : -1;
     }
@@ -345,9 +359,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
                 a2 += red[((wrc * WPX + k) * 2 + 1) * 64 + cc];
             }
             if (co < p.Cout) {
-                const int per_img = p.tiles_x * p.tiles_y;
-                const int g = p.stats_groups == 1 ? 0 : n, chunk = p.stats_groups == 1 ? t_all : t_all - n * per_img;
-                const int nchunk = p.stats_groups == 1 ? (int)gridDim.x : per_img;
+                // (statistics launches tile the stacked batch group by group: tiles_y / G tile rows per group, rows [g][chunk] in tile order)
+                const int nchunk = (p.tiles_y / p.stats_groups) * p.tiles_x;
+                const int g = t_all / nchunk, chunk = t_all - g * nchunk;
                 float *dst = stats + ((size_t)(g * nchunk + chunk) * 2) * p.Cout + co;
                 dst[0] = a1;
                 dst[p.Cout] = a2;
@@ -504,11 +518,27 @@ static int stack_rows(int N, int H, int Hin, int oy0, int TR, bool allowed, int 
     tiles_y = stacked;
     return S;
 }
+// Launches with fused statistics (round 4: stacked too).  The statistics are per group of npg = N / G consecutive images (G = 1 batch
+// norm, N instance norm, in between BatchNorm over stacked batches) and every tile writes ONE row of one group, so a tile must not
+// straddle two groups: the images of a group are stacked at stride S as above and every group starts on a tile boundary (gstride, a
+// multiple of TR; its unused tail rows belong to no image).  -> S; tiles_y covers all groups.
+static int stack_groups(int N, int G, int H, int Hin, int oy0, int TR, int &tiles_y, int &gstride) {
+    const int npg = N / G;
+    int S = H > Hin - oy0 ? H : Hin - oy0;
+    if (H + 1 + oy0 >= Hin && S < H + 2 + oy0) S = H + 2 + oy0;
+    static const int on = getenv("RDFC_GLDS_STACK") ? atoi(getenv("RDFC_GLDS_STACK")) : 1;
+    if (!on || npg < 2) S = cdiv(S, TR) * TR;                   // per-image tiles: every image starts on a tile boundary
+    gstride = cdiv(npg * S, TR) * TR;                           // (S > H: the last row of a group's slot is a zero row, like the rows between two images)
+    if (npg == 1) S = gstride;
+    tiles_y = G * (gstride / TR);
+    return S;
+}
 
 int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G) {
-    if (!glds_shape_ok(d, 0) || (G != 1 && G != d->N)) return 0;
-    const int tiles = cdiv(d->Wo, TC) * cdiv(d->Ho, d->Co > 64 ? 8 : 16);        // (launches with fused statistics keep per-image tiles)
-    return G == 1 ? tiles * d->N : tiles;
+    if (!glds_shape_ok(d, 0) || G < 1 || d->N % G != 0) return 0;
+    int tiles_y, gstride;
+    stack_groups(d->N, G, d->Ho, d->Hi, -d->ph, d->Co > 64 ? 8 : 16, tiles_y, gstride);
+    return (tiles_y / G) * cdiv(d->Wo, TC);                     // rows per group
 }
 
 // Called by conv_igemm.hip's entry points before the register-staged 3x3 kernels. Returns 1 if it took the launch.
@@ -526,7 +556,7 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     const int pad = d->ph;
     GParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo,
               Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
-              d->act, d->slope, d->out_f32, 0, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect, 0};
+              d->act, d->slope, d->out_f32, 0, 0, 0, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect, 0};
     // whole-row stores: 2-byte results without an addend, channel rows of whole 16-byte chunks at 16-byte aligned addresses, a
     // piecewise-linear epilogue (RDFC_GLDS_ROWSTORE=0: the direct 8-byte stores, for A/B runs)
     static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
@@ -534,7 +564,12 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
     p.tiles_x = cdiv(p.W, TC);                                 // 128 co x (8 x 16) px or 64 co x (16 x 16) px per workgroup
-    p.vstride = stack_rows(p.N, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, !reflect && stats == nullptr, p.tiles_y);
+    if (stats != nullptr) {
+        if (G < 1 || p.N % G != 0 || transposed || reflect) return 0;
+        p.npg = p.N / G;
+        p.vstride = stack_groups(p.N, G, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, p.tiles_y, p.gstride);
+    } else
+        p.vstride = stack_rows(p.N, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, !reflect, p.tiles_y);
     if (d->dtype == RDFC_F16)
         return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, stats, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, stats, st);
     return Cout > 64 ? launch<128>(p, in, w, bias, out, zero, stats, st) : launch<64>(p, in, w, bias, out, zero, stats, st);

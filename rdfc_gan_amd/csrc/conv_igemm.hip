@@ -420,9 +420,10 @@ extern "C" int rdfc_conv2d_forward_reflect(const rdfc_conv_desc *d, const void *
 
 extern "C" int rdfc_conv_stats_nchunk(const rdfc_conv_desc *d, int G) {
     if (d == nullptr || G < 1) return 0;
-    // Opt-in (RDFC_FUSED_STATS=1): measured neutral inside the train step -- the statistics pass it removes (0.8 ms) is
-    // paid back by the longer conv epilogue (+0.5 ms) and a finalize over 2-4x more partial rows (+0.5 ms).
-    static const bool on = getenv("RDFC_FUSED_STATS") != nullptr;
+    // Round 4: on by default (RDFC_FUSED_STATS=0 switches it off).  Rounds 1-3 measured it neutral -- the launches with statistics
+    // kept per-image tiles (losing the stacked-batch row tiling) and their finalize walked two to four times more partial rows in one
+    // workgroup; now they are stacked too (group-aligned: conv_glds.hip stack_groups) and the finalize is one workgroup per (group, 32 channels).
+    static const bool on = !(getenv("RDFC_FUSED_STATS") != nullptr && atoi(getenv("RDFC_FUSED_STATS")) == 0);
     return on ? rdfc_conv3x3_glds_stats_nchunk(d, G) : 0;
 }
 

@@ -53,7 +53,9 @@ inline Map make_map_stream(int G, int P, int C, int vec) {
 // body(p) for p = begin + r0, +RPB, ... < end, four rows per trip so four independent loads are in flight
 // streamed outputs are written once and read by a later kernel: non-temporal stores measured +1..5 % (A/B on one
 // device); non-temporal LOADS measured 10-15 % slower (RDFC_NORM_NT_LOAD) and stay off
-#ifndef RDFC_NORM_PLAIN_STORE
+// (round 4: plain stores again -- inside the step the consumer of a streamed map is the next kernel, and with plain stores it finds more
+//  of it in the Infinity Cache: 241.0 vs 240.0 pairs/s, two interleaved pairs on one box; -DRDFC_NORM_NT_STORE for the other arm)
+#ifdef RDFC_NORM_NT_STORE
 #define ST store_nt
 #else
 #define ST store
@@ -831,7 +833,7 @@ extern "C" int rdfc_norm_finalize_apply_seq(const float *partial, int nchunk, do
                                             int ldr, int ldz, int dtype, float eps, float *run_mean, float *run_var,
                                             const float *group_momentum, int act, float slope, const float *prelu, void *stream) {
     if (int e = check_map("rdfc_norm_finalize_apply_seq", G, P, C, dtype, {ldx, ldz})) return e;
-    RDFC_REQUIRE(G <= MAXSEQ, "rdfc_norm_finalize_apply_seq: 1 <= G <= %d groups", MAXSEQ);
+    RDFC_REQUIRE(G <= MAXSEQ || run_mean == nullptr, "rdfc_norm_finalize_apply_seq: running statistics need 1 <= G <= %d groups", MAXSEQ);
     RDFC_REQUIRE(run_mean == nullptr || (group_momentum != nullptr && muvar != nullptr), "rdfc_norm_finalize_apply_seq: running statistics need the per-group momenta and the f64 scratch");
     RDFC_REQUIRE(act != RDFC_ACT_PRELU || prelu != nullptr, "rdfc_norm_finalize_apply_seq: PReLU needs the slope pointer");
     RDFC_REQUIRE(act != RDFC_ACT_TANH && act != RDFC_ACT_SIGMOID, "rdfc_norm_finalize_apply_seq: tanh / sigmoid never follow a norm on this path");
@@ -839,7 +841,7 @@ extern "C" int rdfc_norm_finalize_apply_seq(const float *partial, int nchunk, do
     hipLaunchKernelGGL(stats_finalize_par_kernel, dim3(cdiv(C, 32), G), dim3(FNT), 0, (hipStream_t)stream, mr, nchunk > 0 ? nchunk : cdiv(P, mr.chunk),
                        partial, mean, rstd, eps, run_mean != nullptr ? muvar : nullptr);
     RunUpd ru{run_mean, run_var, muvar, Moms{}};
-    for (int g = 0; g < G && group_momentum != nullptr; ++g) ru.moms.m[g] = group_momentum[g];
+    for (int g = 0; g < G && g < MAXSEQ && group_momentum != nullptr; ++g) ru.moms.m[g] = group_momentum[g];
     Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     DISPATCH(dtype, hipLaunchKernelGGL(apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,

@@ -328,11 +328,10 @@ class _ConvBlock(torch.autograd.Function):
         elif not spec.transposed:
             d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
                               act=epi_act, slope=spec.slope, out_f32=out_f32)
-            G_ = N if spec.norm == 'in' else 1
+            # groups of the statistics: per image (instance norm), per stacked batch, or the whole batch
+            G_ = N if spec.norm == 'in' else (len(gm) if gm is not None else 1)
             if live_stats and hip.conv_stats_nchunk(d, G_) > 0:
-                upd = spec.norm == 'bn' and run_mean is not None
-                fused = hip.conv_forward_stats(d, x, wf, bias, y, G_, spec.eps, run_mean if upd else None,
-                                               run_var if upd else None, spec.momentum, group_momenta=gm)
+                fused = hip.conv_forward_partials(d, x, wf, bias, y, G_)     # the conv's epilogue wrote the partial statistics rows
             else:
                 hip.conv_forward(d, x, wf, bias, y)
         else:   # equivalent conv maps the (larger) output map onto x
@@ -360,8 +359,9 @@ class _ConvBlock(torch.autograd.Function):
             upd = spec.norm == 'bn' and run_mean is not None
             z, buf = _out_for_cat(N, Ho, Wo, Cout, dtype, x.device, cat_with)
             if fused is not None:
-                mean, rstd = fused
-                hip.norm_apply(y, mean, rstd, gamma, beta, res, z, spec.act, spec.slope, prelu)
+                mom = gm if gm is not None else ((spec.momentum,) if upd else None)
+                mean, rstd = hip.norm_from_partials(fused[0], fused[1], y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
+                                                    run_mean if upd else None, run_var if upd else None, mom)
             else:
                 mean, rstd = hip.norm_forward(y, G, spec.eps, gamma, beta, res, z, spec.act, spec.slope, prelu,
                                               run_mean if upd else None, run_var if upd else None, spec.momentum, group_momenta=gm)

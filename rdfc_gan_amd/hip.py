@@ -321,29 +321,50 @@ def conv_stats_nchunk(d, G):
     return lib().rdfc_conv_stats_nchunk(C.byref(d), int(G))
 
 
-def conv_forward_stats(d, x, w_fwd, bias, y, G, eps, run_mean=None, run_var=None, momentum=0.1, group_momenta=None):
-    """conv forward with the normalisation statistics fused into its epilogue (conv_stats_nchunk(d, G) must be > 0).
-    -> mean[G,Co], rstd[G,Co].  group_momenta (BatchNorm over len(group_momenta) stacked batches; call with G = 1): the
-    per-tile rows are ordered by image, so the stacked batches are contiguous row ranges of the one-group layout."""
+def conv_forward_partials(d, x, w_fwd, bias, y, G):
+    """conv forward with the normalisation statistics fused into its epilogue (n = conv_stats_nchunk(d, G) must be > 0): G groups of
+    N / G consecutive images.  -> (buf, n): buf = f32 [partial rows G * n * 2 * Co | f64 scratch [G][2][Co] for norm_from_partials]"""
     n = conv_stats_nchunk(d, G)
     assert n > 0
-    partial = torch.empty(G * n * 2 * d.Co, dtype=torch.float32, device=x.device)
+    npart = (G * n * 2 * d.Co + 1) & ~1
+    buf = torch.empty(npart + 4 * G * d.Co, dtype=torch.float32, device=x.device)
     with _Timed('igemm_kernel (conv fwd / dgrad)', d):
-        _chk(lib().rdfc_conv2d_forward_stats(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial), int(G), _st()),
+        _chk(lib().rdfc_conv2d_forward_stats(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), _p(buf), int(G), _st()),
              'rdfc_conv2d_forward_stats')
+    return buf, n
+
+
+def norm_from_partials(buf, n, y, G, eps, gamma, beta, res, z, act='none', slope=0.0, prelu=None, run_mean=None, run_var=None,
+                       momenta=None):
+    """statistics per group from the partial rows of conv_forward_partials (one small workgroup per (group, 32 channels)), then the
+    normalise (+ residual + activation) pass, which also advances the running statistics once per group in group order (momenta: G
+    floats; BatchNorm only).  -> mean[G,C], rstd[G,C]; z is written."""
+    N, H, W, Cc = y.shape
+    P = N * H * W // G
+    npart = (G * n * 2 * Cc + 1) & ~1
+    stats = torch.empty(2, G, Cc, dtype=torch.float32, device=y.device)
+    base = buf.data_ptr()
+    _chk(lib().rdfc_norm_finalize_apply_seq(base, int(n), base + 4 * npart, _p(y), _p(stats[0]), _p(stats[1]), _p(gamma), _p(beta), _p(res),
+                                            _p(z), G, P, Cc, ld(y), ld(res) if res is not None else 0, ld(z), dt(y), _f(eps), _p(run_mean),
+                                            _p(run_var), _momenta(momenta) if momenta is not None else None, ACT[act], _f(slope), _p(prelu),
+                                            _st()), 'rdfc_norm_finalize_apply_seq')
+    return stats[0], stats[1]
+
+
+def conv_forward_stats(d, x, w_fwd, bias, y, G, eps, run_mean=None, run_var=None, momentum=0.1, group_momenta=None):
+    """conv forward with fused statistics, finalized: -> mean[G,Co], rstd[G,Co] (G = 1 with group_momenta of length Gs: BatchNorm over
+    Gs stacked batches, -> [Gs,Co]).  (The train step uses conv_forward_partials + norm_from_partials; this form serves the tests.)"""
+    Gs = len(group_momenta) if group_momenta is not None else G
+    buf, n = conv_forward_partials(d, x, w_fwd, bias, y, Gs)
+    mean = torch.empty(Gs, d.Co, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(Gs, d.Co, dtype=torch.float32, device=x.device)
+    P = d.N * d.Ho * d.Wo // Gs
     if group_momenta is not None:
-        Gs = len(group_momenta)
-        assert G == 1 and n % Gs == 0 and d.N % Gs == 0
-        mean = torch.empty(Gs, d.Co, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(Gs, d.Co, dtype=torch.float32, device=x.device)
-        _chk(lib().rdfc_norm_finalize_seq(_p(partial), n // Gs, _p(mean), _p(rstd), Gs, d.N * d.Ho * d.Wo // Gs, d.Co, dt(x), _f(eps),
+        _chk(lib().rdfc_norm_finalize_seq(_p(buf), n, _p(mean), _p(rstd), Gs, P, d.Co, dt(x), _f(eps),
                                           _p(run_mean), _p(run_var), _momenta(group_momenta), _st()), 'rdfc_norm_finalize_seq')
-        return mean, rstd
-    mean = torch.empty(G, d.Co, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(G, d.Co, dtype=torch.float32, device=x.device)
-    P = d.N * d.Ho * d.Wo // G
-    _chk(lib().rdfc_norm_finalize_n(_p(partial), n, _p(mean), _p(rstd), int(G), P, d.Co, _f(eps), _p(run_mean), _p(run_var),
-                                    _f(momentum), _st()), 'rdfc_norm_finalize_n')
+    else:
+        _chk(lib().rdfc_norm_finalize_n(_p(buf), n, _p(mean), _p(rstd), int(G), P, d.Co, _f(eps), _p(run_mean), _p(run_var),
+                                        _f(momentum), _st()), 'rdfc_norm_finalize_n')
     return mean, rstd
 
 

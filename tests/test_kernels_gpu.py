@@ -273,13 +273,15 @@ def test_norm_fwd_bwd(dtype, mode, act, res):
 @pytest.mark.parametrize('case', [(3, 21, 37, 64, 64, 1), (2, 19, 23, 64, 128, 0), (4, 18, 20, 96, 256, 1)],
                          ids=lambda c: 'x'.join(map(str, c)))
 def test_conv_fused_statistics(case, monkeypatch):
-    """rdfc_conv2d_forward_stats (opt-in, RDFC_FUSED_STATS=1): the conv epilogue's per-tile statistics + rdfc_norm_finalize_n against the separate
-    rdfc_norm_stats pass over the stored map, batch-norm (G = 1, with running statistics) and instance-norm (G = N)."""
+    """rdfc_conv2d_forward_stats (default since round 4, RDFC_FUSED_STATS=0 switches it off): the conv epilogue's per-tile statistics +
+    rdfc_norm_finalize_n against the separate rdfc_norm_stats pass over the stored map, batch-norm (G = 1, with running statistics) and
+    instance-norm (G = N); then BatchNorm over two stacked batches through norm_from_partials (statistics per group in parallel, running
+    statistics advanced by the normalise pass) against norm_forward(group_momenta) on the stored map."""
     h = hip()
     N, H, W, Ci, Co, pad = case
     dtype = torch.bfloat16
     if h.conv_stats_nchunk(h.conv_desc((N, H, W, Ci), Co, 3, 1, pad, ldx=Ci, ldy=Co, dtype=h.dt(torch.empty(0, dtype=dtype))), 1) == 0:
-        pytest.skip('fused statistics are opt-in: run with RDFC_FUSED_STATS=1')
+        pytest.skip('fused statistics switched off (RDFC_FUSED_STATS=0)')
     x = to_pm(rnd(N, Ci, H, W, seed=1), dtype)
     w = rnd(Co, Ci, 3, 3, seed=2, scale=(Ci * 9) ** -0.5).to(DEV)
     b = rnd(Co, seed=3, scale=0.1).to(DEV)
@@ -300,6 +302,21 @@ def test_conv_fused_statistics(case, monkeypatch):
         assert rel_err(mean, mean_ref) < 2e-5 and rel_err(rstd, rstd_ref) < 2e-5
         if upd:
             assert rel_err(rm2, rm1) < 2e-5 and rel_err(rv2, rv1) < 2e-5
+    if N % 2 == 0:                          # two stacked batches: the launch tiles the batch group by group (no tile straddles the two)
+        moms = (0.1, 0.19)
+        gamma, beta = rnd(Co, seed=5).to(DEV) + 1.5, rnd(Co, seed=6).to(DEV)
+        y_ref = torch.empty(N, Ho, Wo, Co, dtype=dtype, device=DEV)
+        h.conv_forward(d, x, wf, b, y_ref)
+        rm1, rv1 = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        rm2, rv2 = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        z_ref, z = torch.empty_like(y_ref), torch.empty_like(y_ref)
+        mean_ref, rstd_ref = h.norm_forward(y_ref, 2, 1e-5, gamma, beta, None, z_ref, 'lrelu', 0.2, None, rm1, rv1, 0.1, group_momenta=moms)
+        y = torch.empty_like(y_ref)
+        buf, n = h.conv_forward_partials(d, x, wf, b, y, 2)
+        mean, rstd = h.norm_from_partials(buf, n, y, 2, 1e-5, gamma, beta, None, z, 'lrelu', 0.2, None, rm2, rv2, moms)
+        assert torch.equal(y, y_ref)
+        assert rel_err(mean, mean_ref) < 2e-5 and rel_err(rstd, rstd_ref) < 2e-5
+        assert rel_err(z, z_ref) < 1e-2 and rel_err(rm2, rm1) < 2e-5 and rel_err(rv2, rv1) < 2e-5
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
