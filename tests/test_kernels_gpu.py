@@ -653,7 +653,7 @@ def test_combine_losses_and_flat_fanout():
     for v, w in zip(vals, ws):
         term = torch.tensor(v) * w
         acc = term if acc is None else acc + term
-    assert float(total) == float(acc * 0.5)                                   # sequential f32 adds, in order
+    assert float(total.detach()) == float(acc * 0.5)                          # sequential f32 adds, in order
     assert torch.equal(scaled.cpu(), torch.tensor([torch.tensor(v) * w for v, w in zip(vals, ws)]))
     assert not scaled.requires_grad
     (total * 3.0).backward()

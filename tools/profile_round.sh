@@ -9,7 +9,7 @@ tail -c 600 gpurun_out/${tag}_bench.err
 root=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $root
 rm -rf gpurun_out/prof_${tag}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" \
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-as-worded "$@" \
     > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_rocprof.err
 cp gpurun_out/prof_${tag}/*/*_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
 rm -rf gpurun_out/prof_${tag}
