@@ -968,11 +968,16 @@ extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *me
         double *tail_;
         unsigned *extra_;
         const bool folded = plan_fold(G, cdiv(P, m.chunk), 3, C, cdiv(C / rdfc_vec(dtype), NT), scratch, 0, (hipStream_t)stream, fa, tail_, extra_);
+#ifdef RDFC_EXP_SKIP_BWD_REDUCE      // timing-only experiment (results are wrong): what the backward sums + their finalize cost the step
+        (void)folded;
+        hipMemsetAsync(sums, 0, (size_t)G * 3 * C * 4, (hipStream_t)stream);
+#else
         DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
                                            (const T *)dz, (const T *)x, (const T *)res, scratch, lddz, ldx, ldr, fa, sums));
         RDFC_LAUNCH_CHECK("rdfc_norm_backward (sums)");
         if (!folded)
             if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, nullptr, nullptr, stream)) return e;
+#endif
     }
     // (the affine gradients are accumulated by the apply pass, which reads the sums anyway: the groups in group order)
     Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
