@@ -12,10 +12,16 @@
 #include "fold.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int NT = 256;
+#ifdef RDFC_NORM_FOLD_OFF
+constexpr bool FOLD_COMPILED = false;
+#else
+constexpr bool FOLD_COMPILED = true;
+#endif
 
 struct Map {       // geometry shared by the kernels
     int G, P, C;   // groups, pixels per group, channels
@@ -91,6 +97,34 @@ inline Map make_map_stream(int G, int P, int C, int vec) {
         for (; p_ < (cx).p_end; p_ += st_) body(p_);                                 \
     }
 
+// Reductions: the same rows in the same order as ROW_LOOP, with the NEXT trip's four loads issued before the current trip's sums
+// (hipcc does not pipeline the loop by itself: four loads, wait for all four, ~100 VALU instructions, and only then the next loads --
+// a wave had nothing in flight while it computed; the read-only reductions ran at 3.4-4.1 TB/s beside 6 TB/s of the read+write passes)
+template <int NR, typename CX, typename L, typename A>
+__device__ __forceinline__ void row_loop_pf(const CX &cx, L ld, A acc) {
+    int p = cx.p_begin + cx.r0;
+    const int st = cx.RPB;
+    using V = decltype(ld(0));
+    if (p + (NR - 1) * st < cx.p_end) {
+        V a[NR], b[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) a[i] = ld(p + i * st);
+        p += NR * st;
+        for (; p + (NR - 1) * st < cx.p_end; p += NR * st) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) b[i] = ld(p + i * st);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) acc(a[i]);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) a[i] = b[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) acc(a[i]);
+    }
+    for (; p < cx.p_end; p += st) acc(ld(p));
+}
+
 template <typename T>
 struct Ctx {
     static constexpr int VEC = Elem<T>::VEC;
@@ -124,6 +158,15 @@ inline dim3 grid_for(const Map &m, int vec) {
 // handful of threads serially adding up to 64 rows out of LDS (that tail used to cost more than the streaming part).
 template <typename T, int K>
 __device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K][Elem<T>::VEC], float *partial) {
+#ifdef RDFC_EXP_NOTAIL              // timing-only (results are wrong): what the in-block reduction costs
+    {
+        float t = 0.f;
+        for (int k = 0; k < K; ++k)
+            for (int v = 0; v < Elem<T>::VEC; ++v) t += s[k][v];
+        if (t == 12345.f) partial[threadIdx.x] = t;
+        return;
+    }
+#endif
     // Every thread deposits its K x VEC sums in LDS ([k][thread][v], 16-byte stores), then the K * CVT * VEC outputs are dealt to
     // ALL 256 threads: output o = (k, channel vector, v) sums its RPB rows (fixed order r = 0 .. RPB-1: reproducible) and is stored
     // with its neighbours in one coalesced line.  (Before: a butterfly of 24 runtime-offset shuffles plus a tail in which CVT
@@ -231,9 +274,12 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
     for (int v = 0; v < VEC; ++v) s[0][v] = s[1][v] = 0.f;
     if (cx.active) {
         const T *base = x + (size_t)cx.g * m.P * ld + cx.c0;
-        auto body = [&](int p) {
+        auto fetch = [&](int p) {
             Vec16<T> a;
             a.load(base + (size_t)p * ld);
+            return a;
+        };
+        auto add = [&](const Vec16<T> &a) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const float f = a.get(v);
@@ -241,16 +287,21 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
                 s[1][v] += f * f;
             }
         };
+#ifdef RDFC_NORM_NO_PF
+        auto body = [&](int p) { add(fetch(p)); };
         ROW_LOOP(cx, body);
+#else
+        row_loop_pf<4>(cx, fetch, add);
+#endif
     }
     block_reduce_store<T, 2>(cx, m, s, partial);
-    if (fa.cnt != nullptr) finish_stats(fa, fs, m.G, m.P, m.C, cx.g, cx.chunk, partial);
+    if (FOLD_COMPILED && fa.cnt != nullptr) finish_stats(fa, fs, m.G, m.P, m.C, cx.g, cx.chunk, partial);
 }
 
 // fixed-order sum over the chunk partials of one (group, k, channel): 32 channels x FL lanes per workgroup,
 // lane l adds chunks l, l+FL, ... in f64, then the FL lane sums are added in lane order (deterministic)
 #ifndef RDFC_NORM_FL
-#define RDFC_NORM_FL 32
+#define RDFC_NORM_FL 16
 #endif
 constexpr int FL = RDFC_NORM_FL, FNT = 32 * FL;
 __device__ inline double chunk_sum(const float *__restrict__ partial, int g, int K, int k, int C, int c, int nchunk,
@@ -432,8 +483,16 @@ __device__ inline void finish_sums(const fold::Args &fa, int C, int g, int chunk
 }
 
 // backward pass 1: sums of du, du*xhat, dz*min(u,0)
-template <typename T>
-__global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
+#ifndef RDFC_NORM_BR_WAVES
+#define RDFC_NORM_BR_WAVES 3
+#endif
+#ifndef RDFC_NORM_BR_ROWS
+#define RDFC_NORM_BR_ROWS 2
+#endif
+// RES: a residual map joins the pre-activation; PRELU: the slope's gradient (third sum) is wanted -- compile-time, so the common
+// layer (neither) carries no registers for them: 4 waves per SIMD with two trips of rows in flight
+template <typename T, bool RES, bool PRELU>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RDFC_NORM_BR_WAVES))) void bwd_reduce_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
                                                         const T *__restrict__ res, float *__restrict__ partial, int lddz,
                                                         int ldx, int ldr, fold::Args fa, float *__restrict__ sums) {
     constexpr int VEC = Elem<T>::VEC;
@@ -442,46 +501,62 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(Map m, ApplyArgs a, cons
 #pragma unroll
     for (int v = 0; v < VEC; ++v) s[0][v] = s[1][v] = s[2][v] = 0.f;
     if (cx.active) {
-        float sc[VEC], sh[VEC], mu[VEC], rs[VEC];
-        float gav[VEC], bev[VEC];
-        load_consts<VEC>(a.gamma, cx.c0, 1.f, gav);
-        load_consts<VEC>(a.beta, cx.c0, 0.f, bev);
-        load_consts<VEC>(a.rstd, cx.g * m.C + cx.c0, 1.f, rs);
-        load_consts<VEC>(a.mean, cx.g * m.C + cx.c0, 0.f, mu);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            sc[v] = gav[v] * rs[v];                       // the forward's (apply_kernel) pre-activation, bit for bit,
-            sh[v] = bev[v] - mu[v] * gav[v] * rs[v];      // so the activation mask cannot disagree with the forward
-        }
-        const float ns = neg_slope_of(a);
-        const bool want_slope_grad = a.act == RDFC_ACT_PRELU;
-        const size_t gb = (size_t)cx.g * m.P;
-        auto body = [&](int p) {
-            Vec16<T> dv, xv, rv;
-            dv.load(dz + (gb + p) * lddz + cx.c0);
-            xv.load(x + (gb + p) * ldx + cx.c0);
-            if (res) rv.load(res + (gb + p) * ldr + cx.c0);
+        float sc[VEC], sh[VEC], mu[VEC];
+        {
+            float gav[VEC], bev[VEC], rs[VEC];
+            load_consts<VEC>(a.gamma, cx.c0, 1.f, gav);
+            load_consts<VEC>(a.beta, cx.c0, 0.f, bev);
+            load_consts<VEC>(a.rstd, cx.g * m.C + cx.c0, 1.f, rs);
+            load_consts<VEC>(a.mean, cx.g * m.C + cx.c0, 0.f, mu);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const float xv_ = xv.get(v);
-                const float xh = (xv_ - mu[v]) * rs[v];
+                sc[v] = gav[v] * rs[v];                       // the forward's (apply_kernel) pre-activation, bit for bit,
+                sh[v] = bev[v] - mu[v] * gav[v] * rs[v];      // so the activation mask cannot disagree with the forward
+            }
+        }
+        const float ns = neg_slope_of(a);
+        const size_t gb = (size_t)cx.g * m.P;
+        struct Row2 {
+            Vec16<T> dv, xv;
+        };
+        struct Row3 {
+            Vec16<T> dv, xv, rv;
+        };
+        using Row = typename std::conditional<RES, Row3, Row2>::type;
+        auto fetch = [&](int p) {
+            Row r;
+            r.dv.load(dz + (gb + p) * lddz + cx.c0);
+            r.xv.load(x + (gb + p) * ldx + cx.c0);
+            if constexpr (RES) r.rv.load(res + (gb + p) * ldr + cx.c0);
+            return r;
+        };
+        auto add = [&](const Row &r) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float xv_ = r.xv.get(v);
+                const float xc = xv_ - mu[v];                  // (x - mean); the common factor rstd multiplies the finished sum below
                 float u = sc[v] * xv_ + sh[v];
-                if (res) u += rv.get(v);
-                const float d = dv.get(v);
+                if constexpr (RES) u += r.rv.get(v);
+                const float d = r.dv.get(v);
                 const float du = u > 0.f ? d : d * ns;
                 s[0][v] += du;
-                s[1][v] += du * xh;
-                if (want_slope_grad) s[2][v] += d * fminf(u, 0.f);
+                s[1][v] += du * xc;
+                if constexpr (PRELU) s[2][v] += d * fminf(u, 0.f);
             }
         };
-#ifdef RDFC_NORM_ROWS8
-        ROW_LOOP8(cx, body);
-#else
+#ifdef RDFC_NORM_NO_PF
+        auto body = [&](int p) { add(fetch(p)); };
         ROW_LOOP(cx, body);
+#else
+        row_loop_pf<RDFC_NORM_BR_ROWS>(cx, fetch, add);
 #endif
+        float rs[VEC];                                        // (loaded here, not held across the loop: registers)
+        load_consts<VEC>(a.rstd, cx.g * m.C + cx.c0, 1.f, rs);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s[1][v] *= rs[v];
     }
     block_reduce_store<T, 3>(cx, m, s, partial);
-    if (fa.cnt != nullptr) finish_sums<3>(fa, m.C, cx.g, cx.chunk, partial, sums, nullptr);
+    if (FOLD_COMPILED && fa.cnt != nullptr) finish_sums<3>(fa, m.C, cx.g, cx.chunk, partial, sums, nullptr);
 }
 
 __global__ __launch_bounds__(FNT) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
@@ -618,7 +693,7 @@ __global__ __launch_bounds__(NT) void adain_bwd_reduce_kernel(Map m, const float
         ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 3>(cx, m, s, partial);
-    if (fa.cnt != nullptr) finish_sums<3>(fa, m.C, cx.g, cx.chunk, partial, sums, nullptr);
+    if (FOLD_COMPILED && fa.cnt != nullptr) finish_sums<3>(fa, m.C, cx.g, cx.chunk, partial, sums, nullptr);
 }
 
 template <typename T>
@@ -684,7 +759,7 @@ __global__ __launch_bounds__(NT) void chsum_vec_kernel(Map m, int ld, const T *_
         ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 1>(cx, m, s, partial);
-    if (fa.cnt != nullptr) finish_sums<1>(fa, m.C, 0, cx.chunk, partial, out, acc);
+    if (FOLD_COMPILED && fa.cnt != nullptr) finish_sums<1>(fa, m.C, 0, cx.chunk, partial, out, acc);
 }
 // scalar path (C = 1, 3, ...): thread t -> channel t % Cb, rows t / Cb
 template <typename T>
@@ -705,7 +780,7 @@ __global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, int chu
         for (int r = 0; r < RPB; ++r) a += red[r * Cb + t];
         fold::st_f32(&partial[(size_t)blockIdx.x * C + c], a);
     }
-    if (fa.cnt != nullptr) finish_sums<1>(fa, C, 0, blockIdx.x, partial, out, acc);
+    if (FOLD_COMPILED && fa.cnt != nullptr) finish_sums<1>(fa, C, 0, blockIdx.x, partial, out, acc);
 }
 
 template <typename T>
@@ -850,14 +925,31 @@ extern "C" int rdfc_norm_finalize_apply_seq(const float *partial, int nchunk, do
     return 0;
 }
 
+template <typename T>
+static void launch_bwd_reduce_t(const Map &m, const ApplyArgs &a, const void *dz, const void *x, const void *res, float *partial, int lddz,
+                                int ldx, int ldr, const fold::Args &fa, float *sums, hipStream_t st) {
+    const dim3 grid = grid_for(m, Elem<T>::VEC);
+    const bool pr = a.act == RDFC_ACT_PRELU;
+#define RDFC_BR(R, P_) hipLaunchKernelGGL((bwd_reduce_kernel<T, R, P_>), grid, dim3(NT), 0, st, m, a, (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr, fa, sums)
+    if (res != nullptr) {
+        if (pr) RDFC_BR(true, true); else RDFC_BR(true, false);
+    } else {
+        if (pr) RDFC_BR(false, true); else RDFC_BR(false, false);
+    }
+#undef RDFC_BR
+}
+static void launch_bwd_reduce(int dtype, const Map &m, const ApplyArgs &a, const void *dz, const void *x, const void *res, float *partial,
+                              int lddz, int ldx, int ldr, const fold::Args &fa, float *sums, void *stream) {
+    DISPATCH(dtype, launch_bwd_reduce_t<T>(m, a, dz, x, res, partial, lddz, ldx, ldr, fa, sums, (hipStream_t)stream));
+}
+
 extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
                                     const float *beta, const void *res, float *partial, int G, int P, int C, int lddz,
                                     int ldx, int ldr, int dtype, int act, float slope, const float *prelu, void *stream) {
     if (int e = check_map("rdfc_norm_bwd_reduce", G, P, C, dtype, {lddz, ldx})) return e;
     Map m = make_map(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
-    DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                       (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr, NO_FOLD, (float *)nullptr));
+    launch_bwd_reduce(dtype, m, a, dz, x, res, partial, lddz, ldx, ldr, NO_FOLD, nullptr, stream);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_reduce");
     return 0;
 }
@@ -972,8 +1064,7 @@ extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *me
         (void)folded;
         hipMemsetAsync(sums, 0, (size_t)G * 3 * C * 4, (hipStream_t)stream);
 #else
-        DISPATCH(dtype, hipLaunchKernelGGL(bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                           (const T *)dz, (const T *)x, (const T *)res, scratch, lddz, ldx, ldr, fa, sums));
+        launch_bwd_reduce(dtype, m, a, dz, x, res, scratch, lddz, ldx, ldr, fa, sums, stream);
         RDFC_LAUNCH_CHECK("rdfc_norm_backward (sums)");
         if (!folded)
             if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, nullptr, nullptr, stream)) return e;

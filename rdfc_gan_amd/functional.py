@@ -296,8 +296,9 @@ def _geometry(spec, x, weight):
 
 class _ConvBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with=None):
+    def forward(ctx, x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with=None, chain=None):
         dtype = x.dtype
+        ctx.chain = chain
         N, H, W, Cin = x.shape
         Cout, Ho, Wo = _geometry(spec, x, weight)
         wf, wb = _packed(weight, dtype, spec.wscale)
@@ -442,7 +443,10 @@ class _ConvBlock(torch.autograd.Function):
                 g_x = torch.empty(N, H, W, Cin, dtype=x.dtype, device=x.device)
                 if d_alias is not None and d_alias.dtype != x.dtype:
                     d_alias = d_alias.to(x.dtype)
-                hip.conv_dgrad(d, dy, wb, None, g_x, addend=d_alias)
+                chain = ctx.chain if d_alias is None else None
+                hip.conv_dgrad(d, dy, wb, None, g_x, addend=d_alias if chain is None else chain.take(x.dtype))
+                if chain is not None:
+                    g_x = chain.put(g_x)
             elif d_alias is not None:
                 g_x = d_alias
             if ctx.needs_input_grad[1]:
@@ -458,14 +462,17 @@ class _ConvBlock(torch.autograd.Function):
                 d = hip.conv_desc((N, Ho, Wo, Cout), Cin, spec.k, spec.stride, spec.pad, ldx=hip.ld(dy), ldy=hip.ld(x),
                                   dtype=hip.dt(x), out_hw=(H, W))
                 g_w = _wgrad(d, dy, x, weight, Cin, Cout, spec.k, spec.wscale)     # [O = Cin][T][I = Cout]
-        return g_x, g_w, g_bias, g_gamma, g_beta, g_res, g_prelu, None, None, None, None, g_cat
+        return g_x, g_w, g_bias, g_gamma, g_beta, g_res, g_prelu, None, None, None, None, g_cat, None
 
 
 def conv_block(x, weight, bias=None, gamma=None, beta=None, res=None, prelu=None, *, spec, training=True,
                run_mean=None, run_var=None, cat_with=None):
     """cat_with (blocks with a normalisation layer): return cat((block output, cat_with), channels) -- the normalise pass writes the
     block's channels of the concatenation directly (no separate copy of them); same shape [N, Ho, Wo, *] required"""
-    return _ConvBlock.apply(x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with)
+    chain = getattr(x, '_rdfc_chain', None)
+    if chain is not None and (spec.transposed or spec.reflect or spec.passthrough):
+        chain = None                         # (those input-gradient paths take no addend: the sum falls back to _FanOut.backward)
+    return _ConvBlock.apply(x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with, chain)
 
 
 def _out_for_cat(N, Ho, Wo, Cout, dtype, device, cat_with):
@@ -571,19 +578,67 @@ def cat(a, b):
     return _Cat.apply(a, b)
 
 
+class _Chain:
+    """Running sum of the cotangents of one activation whose consumers are conv blocks (fanout(..., chained=True)): each consumer's
+    input-gradient launch adds the sum so far in its epilogue (rdfc_conv2d_dgrad_add) and keeps the result here instead of
+    returning it; the last one to run hands the total to autograd.  No rdfc_sum_maps pass, whatever order the consumers' backward
+    nodes run in; a consumer that never runs (unused output) leaves the sum in `partial`, which _FanOut.backward picks up."""
+    __slots__ = ('n', 'seen', 'partial', 'stream')
+
+    def __init__(self, n):
+        self.n, self.seen, self.partial, self.stream = n, 0, None, None
+
+    def take(self, dtype):
+        """-> the sum so far (None for the first consumer), safe to read on the current stream"""
+        p = self.partial
+        if p is None or p.dtype != dtype:
+            return None
+        cur = torch.cuda.current_stream(p.device)
+        if self.stream is not None and self.stream != cur:
+            cur.wait_stream(self.stream)
+            p.record_stream(cur)
+        self.partial = None
+        return p
+
+    def put(self, total):
+        """total = this consumer's input gradient (+ what take() returned).  -> what the consumer returns to autograd"""
+        self.seen += 1
+        if self.partial is not None:                 # take() declined it (dtype): leave both to _FanOut.backward
+            return total
+        if self.seen < self.n:
+            self.partial, self.stream = total, torch.cuda.current_stream(total.device)
+            return None
+        return total
+
+    def drain(self):
+        p, self.partial, self.seen, self.stream = self.partial, None, 0, None
+        return p
+
+
 class _FanOut(torch.autograd.Function):
     """An activation with n consumers: n aliases forward, ONE rdfc_sum_maps pass backward (autograd would add the
     cotangents pairwise with stock elementwise kernels, after copying channel-slice cotangents contiguous)."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, chain=None):
         ctx.meta = (tuple(x.shape), x.dtype, x.device)
+        ctx.chain = chain
+        ctx.set_materialize_grads(False)          # an alias without a cotangent stays None (not a map of zeros to add)
         return tuple(x.view(x.shape) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *gs):
         shape, dtype, dev = ctx.meta
         live = []
+        if ctx.chain is not None:
+            st = ctx.chain.stream
+            p = ctx.chain.drain()
+            if p is not None:
+                cur = torch.cuda.current_stream(dev)
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
+                    p.record_stream(cur)
+                gs = gs + (p,)
         for g in gs:
             if g is None:
                 continue
@@ -593,20 +648,30 @@ class _FanOut(torch.autograd.Function):
                 g = g.contiguous()
             live.append(g)
         if not live:
-            return None, None
+            return None, None, None
         if len(live) == 1:
-            return live[0], None
+            return live[0], None, None
         out = None
         while len(live) > 4:
             out = hip.sum_maps(live[:4])
             live = [out] + live[4:]
-        return hip.sum_maps(live), None
+        return hip.sum_maps(live), None, None
 
 
-def fanout(x, n):
-    """x -> n aliases whose gradients are summed by one HIP pass"""
+_CHAINED = os.environ.get('RDFC_FANOUT_CHAIN', '1') != '0'
+
+
+def fanout(x, n, chained=False):
+    """x -> n aliases whose gradients are summed by one HIP pass; chained=True (every consumer is a conv_block): summed inside the
+    consumers' input-gradient launches instead (_Chain)"""
     if n <= 1 or not x.requires_grad:
         return (x,) * n
+    if chained and _CHAINED and x.is_cuda:
+        chain = _Chain(n)
+        outs = _FanOut.apply(x, n, chain)
+        for o in outs:
+            o._rdfc_chain = chain
+        return outs
     return _FanOut.apply(x, n)
 
 

@@ -209,7 +209,7 @@ class RDFGenerator(nn.Module):
             with on_side():                                  # depth decoder level `lvl` (its output feeds the NEXT RGB level) ...
                 nxt = dec_cat(D, df, lvl, skip[lvl])
                 if lvl == 2:
-                    heads = Fh.fanout(nxt, nh)               # the last decoder feature only feeds the heads
+                    heads = Fh.fanout(nxt, nh, chained=True) # the last decoder feature only feeds the heads' first convs
                 else:
                     df, ff = Fh.fanout(nxt, 2)
                     dfs.append(publish(ff))
@@ -225,7 +225,7 @@ class RDFGenerator(nn.Module):
                 depth_map_2 = self.nlspn_refine_module(pred_init, guide, conf_prop, depth)
             else:
                 depth_map_2 = pred_init
-        rfa, rfb = Fh.fanout(rf, 2)
+        rfa, rfb = Fh.fanout(rf, 2, chained=True)
         depth_map_1 = self._head(self.rgb_pred_dec0, self.rgb_pred_dec1(rfa, cat_with=r1a), 'tanh')
         confidence_map_1 = self.rgb_conf_dec0(self.rgb_conf_dec1(rfb, cat_with=r1b))
         if two:

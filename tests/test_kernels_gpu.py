@@ -625,6 +625,64 @@ def test_sum_maps_and_fanout(dtype):
     assert torch.equal(g1, torch.full_like(x, 2.0)) and torch.equal(x.grad, exp)
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
+def test_chained_fanout_sums_inside_the_input_gradient_launches(dtype):
+    """fanout(..., chained=True): conv-block consumers add the running sum of the cotangents in their own input-gradient epilogue.
+    Same gradients as the rdfc_sum_maps form, no rdfc_sum_maps launch; consumers on two streams; an unused consumer; a consumer
+    the chain does not cover (a channel slice)."""
+    h = hip()
+    from rdfc_gan_amd import functional as Fh
+    N, H, W, C = 2, 20, 24, 32
+    x0 = to_pm(rnd(N, C, H, W, seed=1), dtype).contiguous()
+    ws = [rnd(co, C, 3, 3, seed=10 + i, scale=0.2).to(DEV) for i, co in enumerate((16, 32, 8))]
+    spec = Fh.ConvSpec(3, 1, 1, act='lrelu', slope=0.2)
+    side = torch.cuda.Stream()
+
+    def run(chained, use=(0, 1, 2), sliced=False, two_streams=False):
+        x = x0.clone().requires_grad_(True)
+        wl = [w.clone().requires_grad_(True) for w in ws]
+        outs = Fh.fanout(x, 3 + int(sliced), chained=chained)
+        assert (getattr(outs[0], '_rdfc_chain', None) is not None) == chained
+        total = 0.0
+        for i in use:
+            if two_streams and i == 1:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    y = Fh.conv_block(outs[i], wl[i], spec=spec)
+                    total = total + (y.float() * (i + 1.5)).sum()
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                y = Fh.conv_block(outs[i], wl[i], spec=spec)
+                total = total + (y.float() * (i + 1.5)).sum()
+        if sliced:
+            total = total + (outs[3][..., :8].float() * 0.75).sum()
+        calls = []
+        orig = h.sum_maps
+        h.sum_maps = lambda maps: (calls.append(len(maps)), orig(maps))[1]
+        try:
+            total.backward()
+        finally:
+            h.sum_maps = orig
+        torch.cuda.synchronize()
+        return x.grad.float(), [w.grad for w in wl], calls
+
+    t = {torch.float32: 2e-6, torch.bfloat16: 1.2e-2, torch.float16: 2e-3}[dtype]
+    Fh.set_compute_dtype(dtype)
+    try:
+        for kw in (dict(), dict(two_streams=True), dict(use=(0, 2)), dict(sliced=True), dict(use=(1,))):
+            g_ref, w_ref, c_ref = run(False, **kw)
+            g, wg, calls = run(True, **kw)
+            assert rel_err(g, g_ref) < t, kw
+            for a, b in zip(wg, w_ref):
+                assert (a is None) == (b is None) and (a is None or rel_err(a, b) < 1e-5)       # (same launches; f32 atomics in some)
+            n_in = len(kw.get('use', (0, 1, 2))) + int(kw.get('sliced', False))
+            assert c_ref == ([n_in] if n_in > 1 else [])
+            # the chain leaves one rdfc_sum_maps only where a cotangent arrives from outside it
+            assert calls == ([2] if kw.get('sliced') else []), (kw, calls)
+    finally:
+        Fh.set_compute_dtype(torch.bfloat16)
+
+
 def test_small_elementwise_ops():
     h = hip()
     g = rnd(3, 3, 10, 12, seed=1).to(DEV)
