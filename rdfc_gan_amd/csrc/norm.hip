@@ -298,46 +298,65 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
     if (FOLD_COMPILED && fa.cnt != nullptr) finish_stats(fa, fs, m.G, m.P, m.C, cx.g, cx.chunk, partial);
 }
 
-// fixed-order sum over the chunk partials of one (group, k, channel): 32 channels x FL lanes per workgroup,
-// lane l adds chunks l, l+FL, ... in f64, then the FL lane sums are added in lane order (deterministic)
+// fixed-order sum over the chunk partials of one (group, k, channel): FC channels x FLn lanes per workgroup,
+// lane l adds chunks l, l+FLn, ... in f64, then the FLn lane sums are added in lane order (deterministic).
+// Workgroup shape (round 4).  1024 threads (32 x 32) waited in the step for a CU with 16 free wave slots beside the conv kernels: 512
+// threads + 1.5 % on the step.  Then by row count: the conv epilogues' fused statistics leave one row per TILE (4332 on a full-resolution
+// map), i.e. 135 dependent-latency rows per lane at 32 x 16 -- 256 threads as 8 x 32 or 4 x 64 (pick_fc) give 4-8 x the workgroups
+// and a quarter of the rows per lane.
 #ifndef RDFC_NORM_FL
 #define RDFC_NORM_FL 16
 #endif
 constexpr int FL = RDFC_NORM_FL, FNT = 32 * FL;
+constexpr int FNT2 = 256;                       // threads of the <FC> kernels: FC channels x (256 / FC) lanes
+template <int FC = 32, int FLn = FL>
 __device__ inline double chunk_sum(const float *__restrict__ partial, int g, int K, int k, int C, int c, int nchunk,
-                                   double *red /* [FL][32] */) {
-    const int lane = threadIdx.x >> 5, cl = threadIdx.x & 31;
+                                   double *red /* [FLn][FC] */) {
+    const int lane = threadIdx.x / FC, cl = threadIdx.x % FC;
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // fixed association -> still deterministic; 8 loads in flight (a lane has ~17)
     if (c < C) {
         const float *base = partial + ((size_t)g * nchunk * K + k) * C + c;
         const size_t stride = (size_t)K * C;
         int j = lane;
-        for (; j + 7 * FL < nchunk; j += 8 * FL) {
+        for (; j + 7 * FLn < nchunk; j += 8 * FLn) {
             float v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = base[(size_t)(j + q * FL) * stride];
+            for (int q = 0; q < 8; ++q) v[q] = base[(size_t)(j + q * FLn) * stride];
 #pragma unroll
             for (int q = 0; q < 8; ++q) a[q] += v[q];
         }
-        for (int q = 0; j < nchunk; j += FL, ++q) a[q & 7] += base[(size_t)j * stride];
+        for (int q = 0; j < nchunk; j += FLn, ++q) a[q & 7] += base[(size_t)j * stride];
     }
     const double s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
-    red[lane * 32 + cl] = s;
+    red[lane * FC + cl] = s;
     __syncthreads();
     double t = 0;
-    for (int l = 0; l < FL; ++l) t += red[l * 32 + cl];
+    for (int l = 0; l < FLn; ++l) t += red[l * FC + cl];
     return t;
 }
+// channels per workgroup of the <FC> finalize kernels by the number of rows to add
+inline int pick_fc(int nchunk) {
+    static const int force = getenv("RDFC_NORM_FC") ? atoi(getenv("RDFC_NORM_FC")) : 0;      // A/B knob: 4 | 8 | 32
+    if (force == 4 || force == 8 || force == 32) return force;
+    return nchunk <= 256 ? 32 : (nchunk <= 1024 ? 8 : 4);
+}
+#define RDFC_FC_DISPATCH(fc, ...)                                   \
+    do {                                                            \
+        if ((fc) == 32) { constexpr int FC = 32; __VA_ARGS__; }     \
+        else if ((fc) == 8) { constexpr int FC = 8; __VA_ARGS__; }  \
+        else { constexpr int FC = 4; __VA_ARGS__; }                 \
+    } while (0)
 
-__global__ __launch_bounds__(FNT) void stats_finalize_kernel(Map m, int nchunk, const float *__restrict__ partial,
-                                                            float *__restrict__ mean, float *__restrict__ rstd, float eps,
-                                                            float *run_mean, float *run_var, float momentum) {
-    __shared__ double red[FL * 32];
-    const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const double s1 = chunk_sum(partial, g, 2, 0, m.C, c, nchunk, red);
-    const double s2 = chunk_sum(partial, g, 2, 1, m.C, c, nchunk, red);
-    if (threadIdx.x >= 32 || c >= m.C) return;
+template <int FC>
+__global__ __launch_bounds__(FNT2) void stats_finalize_kernel(Map m, int nchunk, const float *__restrict__ partial,
+                                                             float *__restrict__ mean, float *__restrict__ rstd, float eps,
+                                                             float *run_mean, float *run_var, float momentum) {
+    __shared__ double red[FNT2];
+    const int g = blockIdx.y, c = blockIdx.x * FC + (threadIdx.x % FC);
+    const double s1 = chunk_sum<FC, FNT2 / FC>(partial, g, 2, 0, m.C, c, nchunk, red);
+    const double s2 = chunk_sum<FC, FNT2 / FC>(partial, g, 2, 1, m.C, c, nchunk, red);
+    if (threadIdx.x >= FC || c >= m.C) return;
     const int i = g * m.C + c;
     const double mu = s1 / m.P;
     double var = s2 / m.P - mu * mu;
@@ -384,14 +403,15 @@ __global__ __launch_bounds__(FNT) void stats_finalize_seq_kernel(Map m, int nchu
 // Round 4: the same per (group, 32 channels) -- grid (C / 32, G) instead of one workgroup walking the groups -- which leaves the
 // in-order update of the running statistics to ONE thread per channel of the normalise pass that follows (apply_kernel, RunUpd): it
 // reads every group's (mean, biased variance) in f64 from muvar[G][2][C].  13.9 -> ~6 us per launch at two stacked batches.
-__global__ __launch_bounds__(FNT) void stats_finalize_par_kernel(Map m, int nchunk, const float *__restrict__ partial,
-                                                                float *__restrict__ mean, float *__restrict__ rstd, float eps,
-                                                                double *__restrict__ muvar) {
-    __shared__ double red[FL * 32];
-    const int g = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const double s1 = chunk_sum(partial, g, 2, 0, m.C, c, nchunk, red);
-    const double s2 = chunk_sum(partial, g, 2, 1, m.C, c, nchunk, red);
-    if (threadIdx.x >= 32 || c >= m.C) return;
+template <int FC>
+__global__ __launch_bounds__(FNT2) void stats_finalize_par_kernel(Map m, int nchunk, const float *__restrict__ partial,
+                                                                 float *__restrict__ mean, float *__restrict__ rstd, float eps,
+                                                                 double *__restrict__ muvar) {
+    __shared__ double red[FNT2];
+    const int g = blockIdx.y, c = blockIdx.x * FC + (threadIdx.x % FC);
+    const double s1 = chunk_sum<FC, FNT2 / FC>(partial, g, 2, 0, m.C, c, nchunk, red);
+    const double s2 = chunk_sum<FC, FNT2 / FC>(partial, g, 2, 1, m.C, c, nchunk, red);
+    if (threadIdx.x >= FC || c >= m.C) return;
     const double mu = s1 / m.P;
     double var = s2 / m.P - mu * mu;
     if (var < 0) var = 0;
@@ -559,12 +579,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RDFC_NORM_BR
     if (FOLD_COMPILED && fa.cnt != nullptr) finish_sums<3>(fa, m.C, cx.g, cx.chunk, partial, sums, nullptr);
 }
 
-__global__ __launch_bounds__(FNT) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
-                                                          float *__restrict__ sums, float *__restrict__ acc0, float *__restrict__ acc1) {
-    __shared__ double red[FL * 32];
-    const int g = blockIdx.y / K, k = blockIdx.y % K, c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const double s = chunk_sum(partial, g, K, k, C, c, nchunk, red);
-    if (threadIdx.x < 32 && c < C) {
+template <int FC>
+__global__ __launch_bounds__(FNT2) void sum_finalize_kernel(int G, int C, int K, int nchunk, const float *__restrict__ partial,
+                                                           float *__restrict__ sums, float *__restrict__ acc0, float *__restrict__ acc1) {
+    __shared__ double red[FNT2];
+    const int g = blockIdx.y / K, k = blockIdx.y % K, c = blockIdx.x * FC + (threadIdx.x % FC);
+    const double s = chunk_sum<FC, FNT2 / FC>(partial, g, K, k, C, c, nchunk, red);
+    if (threadIdx.x < FC && c < C) {
         sums[((size_t)g * K + k) * C + c] = (float)s;
         // optional in-place accumulation of sum 0 / sum 1 (a bias gradient: ONE group, so one add per channel and launch; atomic
         // because the same parameter's two uses per step may run their backward on different streams)
@@ -856,8 +877,11 @@ extern "C" int rdfc_norm_finalize(const float *partial, float *mean, float *rstd
     RDFC_REQUIRE(G > 0 && P > 0 && C > 0, "rdfc_norm_finalize: non-positive size");
     RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_finalize: running statistics need G == 1 (batch norm)");
     Map m = make_map(G, P, C, rdfc_vec(dtype));
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(C, 32), G), dim3(FNT), 0, (hipStream_t)stream, m, cdiv(P, m.chunk),
-                       partial, mean, rstd, eps, run_mean, run_var, momentum);
+    {
+        const int nchunk = cdiv(P, m.chunk);
+        RDFC_FC_DISPATCH(pick_fc(nchunk), hipLaunchKernelGGL(stats_finalize_kernel<FC>, dim3(cdiv(C, FC), G), dim3(FNT2), 0, (hipStream_t)stream, m,
+                                                             nchunk, partial, mean, rstd, eps, run_mean, run_var, momentum));
+    }
     RDFC_LAUNCH_CHECK("rdfc_norm_finalize");
     return 0;
 }
@@ -867,8 +891,8 @@ extern "C" int rdfc_norm_finalize_n(const float *partial, int nchunk, float *mea
     RDFC_REQUIRE(G > 0 && P > 0 && C > 0 && nchunk > 0, "rdfc_norm_finalize_n: non-positive size");
     RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_finalize_n: running statistics need G == 1 (batch norm)");
     Map m{G, P, C, 0};
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(C, 32), G), dim3(FNT), 0, (hipStream_t)stream, m, nchunk, partial, mean, rstd,
-                       eps, run_mean, run_var, momentum);
+    RDFC_FC_DISPATCH(pick_fc(nchunk), hipLaunchKernelGGL(stats_finalize_kernel<FC>, dim3(cdiv(C, FC), G), dim3(FNT2), 0, (hipStream_t)stream, m, nchunk,
+                                                         partial, mean, rstd, eps, run_mean, run_var, momentum));
     RDFC_LAUNCH_CHECK("rdfc_norm_finalize_n");
     return 0;
 }
@@ -913,8 +937,11 @@ extern "C" int rdfc_norm_finalize_apply_seq(const float *partial, int nchunk, do
     RDFC_REQUIRE(act != RDFC_ACT_PRELU || prelu != nullptr, "rdfc_norm_finalize_apply_seq: PReLU needs the slope pointer");
     RDFC_REQUIRE(act != RDFC_ACT_TANH && act != RDFC_ACT_SIGMOID, "rdfc_norm_finalize_apply_seq: tanh / sigmoid never follow a norm on this path");
     Map mr = make_map(G, P, C, rdfc_vec(dtype));
-    hipLaunchKernelGGL(stats_finalize_par_kernel, dim3(cdiv(C, 32), G), dim3(FNT), 0, (hipStream_t)stream, mr, nchunk > 0 ? nchunk : cdiv(P, mr.chunk),
-                       partial, mean, rstd, eps, run_mean != nullptr ? muvar : nullptr);
+    {
+        const int rows = nchunk > 0 ? nchunk : cdiv(P, mr.chunk);
+        RDFC_FC_DISPATCH(pick_fc(rows), hipLaunchKernelGGL(stats_finalize_par_kernel<FC>, dim3(cdiv(C, FC), G), dim3(FNT2), 0, (hipStream_t)stream, mr, rows,
+                                                           partial, mean, rstd, eps, run_mean != nullptr ? muvar : nullptr));
+    }
     RunUpd ru{run_mean, run_var, muvar, Moms{}};
     for (int g = 0; g < G && g < MAXSEQ && group_momentum != nullptr; ++g) ru.moms.m[g] = group_momentum[g];
     Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
@@ -958,8 +985,11 @@ extern "C" int rdfc_norm_bwd_finalize_acc(const float *partial, float *sums, int
                                           float *dgamma_acc, void *stream) {
     // in-place accumulation from here: one statistics group only (several groups: rdfc_norm_backward adds them in group order)
     RDFC_REQUIRE(G == 1 || (dbeta_acc == nullptr && dgamma_acc == nullptr), "rdfc_norm_bwd_finalize_acc: accumulators need G == 1");
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), G * 3), dim3(FNT), 0, (hipStream_t)stream, G, C, 3,
-                       cdiv(P, chunk_pixels(P, C, rdfc_vec(dtype))), partial, sums, dbeta_acc, dgamma_acc);
+    {
+        const int nchunk = cdiv(P, chunk_pixels(P, C, rdfc_vec(dtype)));
+        RDFC_FC_DISPATCH(pick_fc(nchunk), hipLaunchKernelGGL(sum_finalize_kernel<FC>, dim3(cdiv(C, FC), G * 3), dim3(FNT2), 0, (hipStream_t)stream, G, C, 3,
+                                                             nchunk, partial, sums, dbeta_acc, dgamma_acc));
+    }
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_finalize");
     return 0;
 }
@@ -1165,7 +1195,8 @@ extern "C" int rdfc_channel_sum_acc(const void *x, float *partial, float *out, f
         DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, chunk, (const T *)x, partial, fa, out, acc));
     }
     if (!folded)
-        hipLaunchKernelGGL(sum_finalize_kernel, dim3(cdiv(C, 32), 1), dim3(FNT), 0, (hipStream_t)stream, 1, C, 1, nchunk, partial, out, acc, nullptr);
+        RDFC_FC_DISPATCH(pick_fc(nchunk), hipLaunchKernelGGL(sum_finalize_kernel<FC>, dim3(cdiv(C, FC), 1), dim3(FNT2), 0, (hipStream_t)stream, 1, C, 1, nchunk,
+                                                             partial, out, acc, nullptr));
     RDFC_LAUNCH_CHECK("rdfc_channel_sum");
     return 0;
 }
