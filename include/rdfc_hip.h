@@ -138,6 +138,9 @@ int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd
  * downsample path -- without a separate summation pass. */
 int rdfc_conv2d_dgrad_add(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const void *addend, int ld_add,
                           void *dx, void *stream);
+/* the same with two maps added (a passthrough block's alias cotangent and a skip connection's: functional._Chain) */
+int rdfc_conv2d_dgrad_add2(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const void *addend, int ld_add,
+                           const void *addend2, int ld_add2, void *dx, void *stream);
 /* dw_packed f32 [Co][KH*KW][Ci] += sum_pixels dy (x) x   (caller zeroes dw_packed first). */
 int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream);
 

@@ -369,7 +369,7 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
                         hipStream_t st, const void *addend = nullptr, int ld_add = 0);       // conv_igemm_glds.hip
 int rdfc_try_head_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const float *bias, void *dx, hipStream_t st);   // conv_head_dgrad.hip
 int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const void *w_bwd, const float *bias, void *res, hipStream_t st,
-                             const void *addend = nullptr, int ld_add = 0);                                                    // conv_t3x3s2_glds.hip
+                             const void *addend = nullptr, int ld_add = 0, const void *addend2 = nullptr, int ld_add2 = 0);     // conv_t3x3s2_glds.hip
 int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st);               // conv_thin_in.hip
 static bool patch_enabled() {
@@ -479,5 +479,22 @@ extern "C" int rdfc_conv2d_dgrad_add(const rdfc_conv_desc *d, const void *dy, co
     if (int e = rdfc_conv2d_dgrad(d, dy, w_bwd, nullptr, dx, stream)) return e;
     const void *srcs[2] = {dx, addend};
     const int lds[2] = {d->ldx, ld_add};
+    return rdfc_sum_maps(2, srcs, lds, dx, d->N * d->Hi * d->Wi, d->Ci, d->ldx, d->dtype, stream);
+}
+
+// input gradient + TWO maps (the alias cotangent of a passthrough block and a skip connection's): in the transposed stride-2 kernel's epilogue
+// where that kernel takes the launch, else rdfc_conv2d_dgrad_add followed by one in-place rdfc_sum_maps
+extern "C" int rdfc_conv2d_dgrad_add2(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const void *addend, int ld_add,
+                                      const void *addend2, int ld_add2, void *dx, void *stream) {
+    if (int e = check_desc(d, "rdfc_conv2d_dgrad_add2")) return e;
+    RDFC_REQUIRE(addend != nullptr && ld_add >= d->Ci && addend2 != nullptr && ld_add2 >= d->Ci, "rdfc_conv2d_dgrad_add2: addend missing or ld < Ci");
+    RDFC_REQUIRE(d->act == RDFC_ACT_NONE && !d->out_f32, "rdfc_conv2d_dgrad_add2: plain input gradient only");
+    if (rdfc_is16(d->dtype) && rdfc_try_convt3x3s2_glds(d, dy, w_bwd, nullptr, dx, (hipStream_t)stream, addend, ld_add, addend2, ld_add2)) {
+        RDFC_LAUNCH_CHECK("rdfc_conv2d_dgrad_add2");
+        return 0;
+    }
+    if (int e = rdfc_conv2d_dgrad_add(d, dy, w_bwd, addend, ld_add, dx, stream)) return e;
+    const void *srcs[2] = {dx, addend2};
+    const int lds[2] = {d->ldx, ld_add2};
     return rdfc_sum_maps(2, srcs, lds, dx, d->N * d->Hi * d->Wi, d->Ci, d->ldx, d->dtype, stream);
 }

@@ -33,6 +33,8 @@ struct TParams {
     const void *addend;          // optional map added to the result before the store (rdfc_conv2d_dgrad_add)
     int ld_add;
     int row_store;               // epilogue through LDS: whole 128-byte channel rows per store instruction (common.h)
+    const void *addend2;         // a second one (rdfc_conv2d_dgrad_add2: the alias cotangent AND a skip connection's)
+    int ld_add2;
 };
 
 constexpr int BK = 32, NT = 256, TCO = 64;
@@ -197,15 +199,17 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = actf(acc[c][i][j][r] + bv[i][r]);
-                    if (p.addend != nullptr) {
-                        const bf16_t *ad = reinterpret_cast<const bf16_t *>(p.addend) + po * p.ld_add + co;
-                        if ((p.ld_add & 3) == 0 && co + 3 < p.Cout) {
+                    auto add_map = [&](const void *a, int ld) {
+                        const bf16_t *ad = reinterpret_cast<const bf16_t *>(a) + po * ld + co;
+                        if ((ld & 3) == 0 && co + 3 < p.Cout && (reinterpret_cast<size_t>(a) & 7) == 0) {
                             const bf16x4 t4 = *reinterpret_cast<const bf16x4 *>(ad);
                             for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t4[r]);
                         } else
                             for (int r = 0; r < 4; ++r)
                                 if (co + r < p.Cout) v[r] += f32of<DT>(ad[r]);
-                    }
+                    };
+                    if (p.addend != nullptr) add_map(p.addend, p.ld_add);
+                    if (p.addend2 != nullptr) add_map(p.addend2, p.ld_add2);
                     const size_t off = po * p.ld_out + co;
                     if (p.out_f32) {
                         float *y = reinterpret_cast<float *>(yout) + off;
@@ -257,6 +261,11 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t4[r]);
                         }
+                        if (p.addend2 != nullptr && live && co < p.Cout) {
+                            const bf16x4 t4 = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const bf16_t *>(p.addend2) + po * p.ld_add2 + co);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t4[r]);
+                        }
                         rs_put<DT>(Ot, 32 * j + 2 * (lane & 15) + rx, 16 * i + q4, v);
                     }
                 }
@@ -305,7 +314,7 @@ int launch(const TParams &p, const void *x, const void *w, const float *bias, vo
 // this kernel = d's input map, source = d's output map); returns 1 if it took the launch.  RDFC_T3S2=0 switches it off (A/B), 1: 3x3 only,
 // 3: also the launches too small to fill the chip (tests).
 int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const void *w_bwd, const float *bias, void *res, hipStream_t st,
-                             const void *addend = nullptr, int ld_add = 0) {
+                             const void *addend = nullptr, int ld_add = 0, const void *addend2 = nullptr, int ld_add2 = 0) {
     static const int on = getenv("RDFC_T3S2") ? atoi(getenv("RDFC_T3S2")) : 2;
     if (!on || !rdfc_is16(d->dtype)) return 0;
     const int KS = d->KH;
@@ -319,10 +328,11 @@ int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const voi
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
     TParams p{d->N, d->Ho, d->Wo, d->Hi, d->Wi, d->Co, d->Ci, d->ldy, d->ldx, d->act, d->slope, d->out_f32, cdiv(d->Wo, TC), cdiv(d->Ho, TRS),
-              addend, ld_add, 0};
+              addend, ld_add, 0, addend2, ld_add2};
     static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
     p.row_store = rows_on && !d->out_f32 && p.Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(res) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
+                  (addend2 == nullptr || (ld_add2 % 4 == 0 && (reinterpret_cast<size_t>(addend2) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
     if (KS == 4) return d->dtype == RDFC_F16 ? launch<RDFC_F16, 4>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16, 4>(p, src, w_bwd, bias, res, zero, st);
     return d->dtype == RDFC_F16 ? launch<RDFC_F16, 3>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16, 3>(p, src, w_bwd, bias, res, zero, st);

@@ -298,7 +298,7 @@ class _ConvBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with=None, chain=None):
         dtype = x.dtype
-        ctx.chain = chain
+        ctx.chain, ctx.cat_chain = chain if chain is not None else (None, None)
         N, H, W, Cin = x.shape
         Cout, Ho, Wo = _geometry(spec, x, weight)
         wf, wb = _packed(weight, dtype, spec.wscale)
@@ -383,6 +383,8 @@ class _ConvBlock(torch.autograd.Function):
         if ctx.cat:                          # cotangent of [block output | cat_with]: two channel slices, read in place
             g_cat = dz[..., Cout:]
             dz = dz[..., :Cout]
+            if ctx.cat_chain is not None and ctx.needs_input_grad[11]:
+                g_cat = ctx.cat_chain.deposit(g_cat)      # a conv consumer of the same activation adds it in its epilogue (_Chain)
         if has_norm:
             x, weight, y, mean, rstd, gamma, beta, res, prelu = ctx.saved_tensors
             dz = dz if dz.dtype == x.dtype else dz.to(x.dtype)
@@ -443,10 +445,15 @@ class _ConvBlock(torch.autograd.Function):
                 g_x = torch.empty(N, H, W, Cin, dtype=x.dtype, device=x.device)
                 if d_alias is not None and d_alias.dtype != x.dtype:
                     d_alias = d_alias.to(x.dtype)
-                chain = ctx.chain if d_alias is None else None
-                hip.conv_dgrad(d, dy, wb, None, g_x, addend=d_alias if chain is None else chain.take(x.dtype))
-                if chain is not None:
-                    g_x = chain.put(g_x)
+                chain = ctx.chain
+                if chain is not None and (spec.passthrough or d_alias is not None):
+                    # the block also owns an alias of x (residual / downsample path): its result IS the activation's cotangent as far as
+                    # this consumer goes -- take what the chain holds as a second addend, hand the sum to autograd
+                    hip.conv_dgrad(d, dy, wb, None, g_x, addend=d_alias, addend2=chain.take(x.dtype))
+                else:
+                    hip.conv_dgrad(d, dy, wb, None, g_x, addend=d_alias if chain is None else chain.take(x.dtype))
+                    if chain is not None:
+                        g_x = chain.put(g_x)
             elif d_alias is not None:
                 g_x = d_alias
             if ctx.needs_input_grad[1]:
@@ -470,9 +477,10 @@ def conv_block(x, weight, bias=None, gamma=None, beta=None, res=None, prelu=None
     """cat_with (blocks with a normalisation layer): return cat((block output, cat_with), channels) -- the normalise pass writes the
     block's channels of the concatenation directly (no separate copy of them); same shape [N, Ho, Wo, *] required"""
     chain = getattr(x, '_rdfc_chain', None)
-    if chain is not None and (spec.transposed or spec.reflect or spec.passthrough):
+    if chain is not None and (spec.transposed or spec.reflect):
         chain = None                         # (those input-gradient paths take no addend: the sum falls back to _FanOut.backward)
-    return _ConvBlock.apply(x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with, chain)
+    cat_chain = getattr(cat_with, '_rdfc_chain', None) if cat_with is not None else None
+    return _ConvBlock.apply(x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with, (chain, cat_chain))
 
 
 def _out_for_cat(N, Ho, Wo, Cout, dtype, device, cat_with):
@@ -529,7 +537,8 @@ class _CropCat(torch.autograd.Function):
     """rdf_generator.py:244-260: fd loses trailing rows/cols beyond fe's size, then cat((fd, fe), C)."""
 
     @staticmethod
-    def forward(ctx, fd, fe):
+    def forward(ctx, fd, fe, chain=None):
+        ctx.chain = chain
         N, He, We, Ce = fe.shape
         Cd = fd.shape[3]
         out = torch.empty(N, He, We, Cd + Ce, dtype=fd.dtype, device=fd.device)
@@ -552,11 +561,13 @@ class _CropCat(torch.autograd.Function):
         else:
             g_fd = hip.zero_(torch.empty(N, Hd, Wd, Cd, dtype=dout.dtype, device=dout.device))
             hip.copy_window(dout[..., :Cd], g_fd)
-        return g_fd, g_fe
+        if ctx.chain is not None and ctx.needs_input_grad[1]:
+            g_fe = ctx.chain.deposit(g_fe)          # (a chained fan-out's skip connection: functional._Chain)
+        return g_fd, g_fe, None
 
 
 def crop_cat(fd, fe):
-    return _CropCat.apply(fd, fe)
+    return _CropCat.apply(fd, fe, getattr(fe, '_rdfc_chain', None))
 
 
 class _Cat(torch.autograd.Function):
@@ -609,6 +620,15 @@ class _Chain:
             self.partial, self.stream = total, torch.cuda.current_stream(total.device)
             return None
         return total
+
+    def deposit(self, g):
+        """a consumer that cannot add (the channel slice of a concatenation's cotangent): leave g for a conv consumer to take.
+        -> what the consumer returns to autograd (None: taken over by the chain)"""
+        self.seen += 1
+        if self.partial is not None or not g.is_cuda:
+            return g
+        self.partial, self.stream = g, torch.cuda.current_stream(g.device)
+        return None
 
     def drain(self):
         p, self.partial, self.seen, self.stream = self.partial, None, 0, None

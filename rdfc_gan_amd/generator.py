@@ -176,18 +176,25 @@ class RDFGenerator(nn.Module):
         marks = self.__dict__.get('bwd_marks')
 
         def mark(t, name):
-            return Fh.backward_marker(t, lambda: marks(name)) if marks is not None else t
+            if marks is None:
+                return t
+            m = Fh.backward_marker(t, lambda: marks(name))
+            if getattr(t, '_rdfc_chain', None) is not None:
+                m._rdfc_chain = t._rdfc_chain          # (the marker passes the cotangent through: the chained fan-out still applies)
+            return m
         for idx in range(2, 7):
             with on_side():
                 nxt = D.forward_encoder_layer(mark(d[-1], 'deep') if idx == 5 else d[-1], idx)
                 if idx < 6:                                  # en2..en5 feed the next stage and a decoder skip connection
-                    nxt, skip[idx] = Fh.fanout(nxt, 2)
+                    # (chained: the skip connection's cotangent -- a channel slice of the decoder's -- is added by the next stage's first
+                    #  input-gradient launch, which already adds the block's own alias cotangent: rdfc_conv2d_dgrad_add2)
+                    nxt, skip[idx] = Fh.fanout(nxt, 2, chained=True)
                 else:
                     nxt = mark(nxt, 'dec')
                 d.append(nxt)
             nxt = R.forward_encoder_layer(mark(r[-1], 'deep') if idx == 5 else r[-1], idx)
             if idx < 6:
-                nxt, rskip[idx] = Fh.fanout(nxt, 2)
+                nxt, rskip[idx] = Fh.fanout(nxt, 2, chained=True)
             else:
                 nxt = mark(nxt, 'dec')
             r.append(nxt)

@@ -371,11 +371,17 @@ def conv_forward_stats(d, x, w_fwd, bias, y, G, eps, run_mean=None, run_var=None
     return mean, rstd
 
 
-def conv_dgrad(d, dy, w_bwd, bias, dx, addend=None):
-    """addend: a map like dx (may be a channel slice) added to the input gradient in the same pass (rdfc_conv2d_dgrad_add)"""
+def conv_dgrad(d, dy, w_bwd, bias, dx, addend=None, addend2=None):
+    """addend (, addend2): maps like dx (may be channel slices) added to the input gradient in the same pass (rdfc_conv2d_dgrad_add / _add2)"""
+    if addend is None and addend2 is not None:
+        addend, addend2 = addend2, None
     with _Timed('igemm_kernel (conv fwd / dgrad)', d):
         if addend is None:
             _chk(lib().rdfc_conv2d_dgrad(C.byref(d), _p(dy), _p(w_bwd), _p(bias), _p(dx), _st()), 'rdfc_conv2d_dgrad')
+        elif addend2 is not None:
+            assert bias is None and addend.dtype == dx.dtype == addend2.dtype and addend.shape == dx.shape == addend2.shape
+            _chk(lib().rdfc_conv2d_dgrad_add2(C.byref(d), _p(dy), _p(w_bwd), _p(addend), ld(addend), _p(addend2), ld(addend2), _p(dx), _st()),
+                 'rdfc_conv2d_dgrad_add2')
         else:
             assert bias is None and addend.dtype == dx.dtype and addend.shape == dx.shape
             _chk(lib().rdfc_conv2d_dgrad_add(C.byref(d), _p(dy), _p(w_bwd), _p(addend), ld(addend), _p(dx), _st()), 'rdfc_conv2d_dgrad_add')

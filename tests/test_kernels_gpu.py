@@ -683,6 +683,68 @@ def test_chained_fanout_sums_inside_the_input_gradient_launches(dtype):
         Fh.set_compute_dtype(torch.bfloat16)
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize('order', ['skip_first', 'stage_first'])
+def test_chained_fanout_skip_connection_joins_the_next_stage_first_input_gradient(dtype, order):
+    """The encoder's pattern: an activation feeds the next stage's first block (3x3 / stride 2, which also hands out an alias of its input
+    to the 1x1 / stride-2 downsample path) and a decoder skip connection (the channel slice of a concatenation's cotangent).  Chained, the
+    slice is deposited and the stride-2 input-gradient launch adds it beside the alias cotangent (rdfc_conv2d_dgrad_add2): same gradients,
+    no rdfc_sum_maps; with the stage's backward first the deposit is summed by _FanOut.backward instead."""
+    h = hip()
+    from rdfc_gan_amd import functional as Fh
+    N, H, W, C = 16, 48, 64, 64           # (large enough for the transposed stride-2 kernel to take the launch)
+    x0 = to_pm(rnd(N, C, H, W, seed=3), dtype).contiguous()
+    w1 = rnd(128, C, 3, 3, seed=21, scale=0.1).to(DEV)
+    wd = rnd(128, C, 1, 1, seed=22, scale=0.3).to(DEV)
+    wc = rnd(32, 16, 3, 3, seed=23, scale=0.2).to(DEV)
+    y0 = to_pm(rnd(N, 16, H, W, seed=4), dtype).contiguous()
+    s1 = Fh.ConvSpec(3, 2, 1, act='relu', passthrough=True)
+    sd = Fh.ConvSpec(1, 2, 0)
+    sc = Fh.ConvSpec(3, 1, 1, norm='bn', act='relu')
+    gam, bet = torch.ones(32, device=DEV), torch.zeros(32, device=DEV)
+
+    def run(chained, via_crop_cat=False):
+        x = x0.clone().requires_grad_(True)
+        ws = [w.clone().requires_grad_(True) for w in (w1, wd, wc)]
+        nxt, skip = Fh.fanout(x, 2, chained=chained)
+
+        def stage():
+            y, xr = Fh.conv_block(nxt, ws[0], spec=s1)
+            return (y.float() * 1.25).sum() + (Fh.conv_block(xr, ws[1], spec=sd).float() * 0.5).sum()
+
+        def decoder():
+            if via_crop_cat:
+                z = Fh.crop_cat(Fh.conv_block(y0, ws[2], gamma=gam, beta=bet, spec=sc), skip)
+            else:
+                z = Fh.conv_block(y0, ws[2], gamma=gam, beta=bet, spec=sc, cat_with=skip)
+            return (z.float() * torch.linspace(0.5, 1.5, z.shape[-1], device=DEV)).sum()
+        # autograd runs the later-created branch's backward first
+        total = (stage() + decoder()) if order == 'skip_first' else (decoder() + stage())
+        calls = []
+        orig = h.sum_maps
+        h.sum_maps = lambda maps: (calls.append(len(maps)), orig(maps))[1]
+        try:
+            total.backward()
+        finally:
+            h.sum_maps = orig
+        torch.cuda.synchronize()
+        return x.grad.float(), [w.grad.float() for w in ws], calls
+
+    t = {torch.float32: 2e-6, torch.bfloat16: 1.2e-2, torch.float16: 2e-3}[dtype]
+    Fh.set_compute_dtype(dtype)
+    try:
+        for crop in (False, True):
+            g_ref, w_ref, c_ref = run(False, crop)
+            g, wg, calls = run(True, crop)
+            assert rel_err(g, g_ref) < t
+            for a, b in zip(wg, w_ref):
+                assert rel_err(a, b) < 1e-5
+            assert c_ref == [2]
+            assert calls == ([] if order == 'skip_first' else [2]), (order, crop, calls)
+    finally:
+        Fh.set_compute_dtype(torch.bfloat16)
+
+
 def test_small_elementwise_ops():
     h = hip()
     g = rnd(3, 3, 10, 12, seed=1).to(DEV)

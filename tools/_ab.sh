@@ -1,7 +1,9 @@
-for i in 1 2; do
-for f in 0 256 384 512 1024; do
-RDFC_WGRAD_SLOTS=$f python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events --no-as-worded 2>/dev/null | python -c "
+python -m pytest tests/test_kernels_gpu.py -x -q -k "fanout or dgrad_with_addend or conv_transpose or conv_fwd" 2>&1 | tail -3
+python -m pytest tests/test_modules_gpu.py -x -q 2>&1 | tail -3
+for i in 1 2 3; do
+for f in 0 1; do
+RDFC_FANOUT_CHAIN=$f python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events --no-as-worded 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('slots=$f', d['value'], d['ms_per_step'])"
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('chain=$f', d['value'], d['ms_per_step'])"
 done
 done
