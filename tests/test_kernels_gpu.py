@@ -25,7 +25,7 @@ def tol(dtype):
 
 
 def rel_err(got, ref):
-    got, ref = got.double().cpu(), ref.double().cpu()
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
     return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
 
 
