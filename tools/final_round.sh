@@ -19,7 +19,7 @@ python bench.py --steps 20 --warmup 3 --no-cpu-baseline --dtype bf16 > gpurun_ou
 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --dtype f16 --height 480 --width 640 --batch 4 > gpurun_out/${tag}_f16_480x640_bench.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --dtype f32 > gpurun_out/${tag}_f32_bench.json 2>/dev/null
 # every conv shape alone (one stream)
-RDFC_BRANCH_STREAMS=0 RDFC_NET_STREAMS=0 RDFC_WGRAD_STREAM=0 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-as-worded --event-every 1 --by-shape gpurun_out/${tag}_by_shape_one_stream.txt > gpurun_out/${tag}_bench_one_stream.json 2>/dev/null
+RDFC_BRANCH_STREAMS=0 RDFC_NET_STREAMS=0 RDFC_WGRAD_STREAM=0 RDFC_D_UNDER_G=0 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-as-worded --event-every 1 --by-shape gpurun_out/${tag}_by_shape_one_stream.txt > gpurun_out/${tag}_bench_one_stream.json 2>/dev/null
 for f in ${tag}_bench ${tag}_bench_under_rocprof ${tag}_rccl_one_rank_bench ${tag}_nlspn_bench ${tag}_bf16_bench ${tag}_f16_480x640_bench ${tag}_f32_bench ${tag}_bench_one_stream; do
 python3 - gpurun_out/$f.json <<'PY'
 import json,sys
