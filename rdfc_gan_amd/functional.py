@@ -590,10 +590,15 @@ def cat(a, b):
 
 
 class _Chain:
-    """Running sum of the cotangents of one activation whose consumers are conv blocks (fanout(..., chained=True)): each consumer's
-    input-gradient launch adds the sum so far in its epilogue (rdfc_conv2d_dgrad_add) and keeps the result here instead of
-    returning it; the last one to run hands the total to autograd.  No rdfc_sum_maps pass, whatever order the consumers' backward
-    nodes run in; a consumer that never runs (unused output) leaves the sum in `partial`, which _FanOut.backward picks up."""
+    """Running sum of the cotangents of one activation (fanout(..., chained=True)), kept out of autograd's hands so that no rdfc_sum_maps
+    pass is needed.  Three kinds of consumer:
+      * a conv block reading the alias (put): its input-gradient launch adds the sum so far in its epilogue (rdfc_conv2d_dgrad_add) and
+        leaves the result here instead of returning it; the last of the n hands the total to autograd;
+      * a concatenation's second operand (deposit): the channel slice of the concatenation's cotangent is left here for a conv consumer;
+      * a conv block that also owns an alias of its input (passthrough: the next encoder stage's first block): takes what is here as a SECOND
+        epilogue addend (rdfc_conv2d_dgrad_add2) and returns the sum to autograd itself.
+    Whatever order the backward nodes run in, and whichever of them never run: what is still here when _FanOut.backward runs is one more
+    cotangent for it to add."""
     __slots__ = ('n', 'seen', 'partial', 'stream')
 
     def __init__(self, n):
