@@ -446,6 +446,14 @@ def main():
                             out['roofline']['traffic'] = round(v['fetch_bytes'] + v['write_bytes'])
                             out['roofline']['traffic_note'] = (f"bytes per launch (read {v['fetch_bytes'] / 1e6:.1f} MB + write {v['write_bytes'] / 1e6:.1f} MB), "
                                                                f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_bench.sh over this command, kernel sources {meta.get('csrc_sha16')}")
+                            if v.get('mfma_busy_cycles'):
+                                # third --pmc pass of the same script: cycles the matrix pipes were busy, summed over the chip's 1 024 SIMDs, per launch,
+                                # against the SIMD-cycles of this run's average launch at the 2.4 GHz peak clock (an upper bound for the clock, so a
+                                # lower bound for the busy fraction)
+                                simd_cycles = out['roofline']['avg_launch_us'] * 2400.0 * 1024
+                                out['roofline']['mfma_busy'] = dict(cycles_per_launch=round(v['mfma_busy_cycles']), mfma_insts_per_launch=round(v['mfma_insts']),
+                                                                    frac_of_simd_cycles=round(v['mfma_busy_cycles'] / simd_cycles, 4),
+                                                                    note='SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/r04_pmc_traffic.json) / (avg_launch_us x 2.4 GHz x 1024 SIMDs)')
             if iso:
                 ifl = sum(r[1] for r in iso if r[5] == top)
                 isec = sum(r[2].elapsed_time(r[3]) * 1e-3 for r in iso if r[5] == top)
