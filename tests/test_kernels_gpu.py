@@ -867,6 +867,13 @@ def test_dgrad_with_addend_and_reflect_adjoint_with_addend(case, dtype):
     fused = h.conv_dgrad(d, gy, wb, None, torch.empty(N, H, W, Ci, dtype=dtype, device=DEV), addend=add)
     ref = plain.float() + add.float()
     assert rel_err(fused.float(), ref) < {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+    # two maps (rdfc_conv2d_dgrad_add2: both in the transposed stride-2 kernel's epilogue where it takes the launch -- RDFC_T3S2=3 in
+    # tests/test_variants_gpu.py sends the small shapes there too --, else the one-addend path + a sum pass); the second one a channel slice
+    add2 = to_pm(rnd(N, Ci + 8, H, W, seed=7), dtype)[..., 8:]
+    fused2 = h.conv_dgrad(d, gy, wb, None, torch.empty(N, H, W, Ci, dtype=dtype, device=DEV), addend=add, addend2=add2)
+    assert rel_err(fused2.float(), ref + add2.float()) < {torch.float32: 1e-6, torch.bfloat16: 1.2e-2, torch.float16: 1.5e-3}[dtype]
+    only2 = h.conv_dgrad(d, gy, wb, None, torch.empty(N, H, W, Ci, dtype=dtype, device=DEV), addend2=add2)
+    assert rel_err(only2.float(), plain.float() + add2.float()) < {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
     g = to_pm(rnd(N, Ci, H + 4, W + 4, seed=6), dtype)
     a = h.reflect_pad_adjoint(g, 2)
     b = h.reflect_pad_adjoint(g, 2, addend=add)

@@ -15,7 +15,7 @@ VARIANTS = [
     ('RDFC_WGRAD_RING', '3', '((test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32) or reflection_pad_folded'),   # the ring kernel also on launches the default leaves to the older kernels (small maps)
     ('RDFC_FUSED_STATS', '1', 'fused_statistics or stacked_batches'),               # conv-epilogue statistics (also under stacked-batch BatchNorm)
     ('RDFC_T3S2', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # transposed 3x3 / stride 2 on igemm_glds' parity classes instead of the patch kernel
-    ('RDFC_T3S2', '3', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # ... and the patch kernel also on the small launches the default leaves to igemm_glds
+    ('RDFC_T3S2', '3', '(test_conv_fwd_dgrad_wgrad or conv_transpose or dgrad_with_addend) and not f32'),   # ... and the patch kernel also on the small launches the default leaves to igemm_glds (its one- and two-addend epilogues included)
     ('RDFC_GLDS_STACK', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # per-image row tiles in the 3x3 kernel
     # round 4: the finalize of the two-stage reductions folded into the reduction launch (csrc/fold.h; opt-in, measured no faster)
     ('RDFC_NORM_FOLD', '1', 'test_norm_fwd_bwd or test_adain or stacked_batches or layout_window_pad_sum'),
