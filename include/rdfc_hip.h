@@ -41,6 +41,10 @@ const char *rdfc_last_error(void);
  * "conv3x3_slab_kernel<__bf16, 64, 128, 1, 256>"), matching the demangled symbol in a rocprofv3 kernel trace.
  * Measurement aid only (bench.py's per-kernel roofline); no upstream counterpart. */
 const char *rdfc_last_kernel(void);
+/* Measurement aid (tools/conv_tall_bench.py, tests): force the pixel-tile height of the 128-channel 3x3 / stride-1 kernel
+ * (rows of 16 pixels per wave: 4 | 6 | 8 | 10; 0 = chosen per launch, the default; same as RDFC_GLDS_JR in the environment).
+ * Results do not depend on it.  No upstream counterpart. */
+void rdfc_tune_glds_rows(int rows_per_wave);
 int rdfc_version(void);
 /* sha256 (first 16 hex digits) of the kernel sources this library was built from (rdfc_gan_amd/build.py: source_hash()): measurement
  * artefacts under profiles/ carry it, and bench.py refuses counters taken from another build.  No upstream counterpart. */

@@ -48,7 +48,22 @@ constexpr int BK = 32, TC = 16, PW = TC + 2;
 // kernel needs 168 registers): 256->256 @ 57x76 58.4 -> 52.7 us (its 640 workgroups now fit one round), 128->128 @ 114x152 60.2 -> 53.1,
 // 256->128 @ 114x152 98.2 -> 94.0.  The 64-co tiles (2 x 21 KB of patch) need a ring of TWO (weights fetched one phase ahead) to get
 // three workgroups on a CU (50 KB each): 64->64 @ 16x228x304 160 -> 134 us forward, 163 -> 136 input gradient, 128->64 244 -> 218.
-template <int TCO> constexpr int ring_of() { return TCO == 128 ? 3 : 2; }
+template <int TCO, int JR = 4> constexpr int ring_of() {
+#ifdef RDFC_GLDS_TALL_RING
+    return JR > 4 ? RDFC_GLDS_TALL_RING : (TCO == 128 ? 3 : 2);
+#else
+    return TCO == 128 ? 3 : 2;
+#endif
+}
+
+// LDS-DMA instructions a wave may still have in flight when it enters phase s of a slab (what it reads then -- the weights of this
+// phase, at s = 0 the slab's patch -- is older): the weights of the look - 1 phases after this one (nwp instructions each) and one
+// patch round for each of the phases s - 1 ... s - max(look - 1, 1) that issued one (phases 0 ... nr - 1 of a slab do).
+constexpr int glds_allow(int s, int look, int nwp, int nr) {
+    int n = (look - 1) * nwp;
+    for (int d = 1; d <= (look > 2 ? look - 1 : 1); ++d) n += ((s - d + 9) % 9) < nr ? 1 : 0;
+    return n;
+}
 
 __device__ inline int lay_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 2)) << 3); }
 
@@ -97,11 +112,22 @@ __device__ __forceinline__ void vrow(const GParams &p, int v, int &img, int &row
 // specialisation (4 consumer + 4 | 2 producer waves, fragment reads pipelined one phase ahead), 64 co x 128 px wave tiles, 8-wave
 // 128 co x 256 px and 2-wave workgroups, a fifth ring slot with fragment reads one phase ahead, and an 8-wave ping-pong schedule with
 // two barriers per tap (profiles/r03_pingpong_experiment.txt): none beat this one on the step's layer sizes.
-template <int TCO, int DT = RDFC_BF16>     // DT: RDFC_BF16 | RDFC_F16 (2-byte elements moved as opaque bits)
+//
+// Tall wave tiles (JR > 4, round 5).  A wave owns 64 co x (JR rows of 16 px), the workgroup 128 co x (2 JR x 16) px: the weight tile
+// of a tap (86 % of the staged bytes of the JR = 4 tile) now serves twice to two-and-a-half times the pixels, and the taps are walked
+// COLUMN by column (kx outer, ky inner): the B fragment of patch row r + ky at column shift kx is the same 16 x 32 block for every
+// (r, ky) with the same r + ky, so a wave reads the JR + 2 patch rows of a kernel column ONCE into registers and the three taps of that
+// column take their operands from there -- JR + 2 instead of 3 JR pixel-fragment reads per column.  Per 32-channel slab and wave:
+// 9 x 4 weight-fragment reads + 3 (JR + 2) pixel-fragment reads for 36 JR MFMAs (JR = 8: 66 reads per 288 MFMAs = 0.23 per MFMA;
+// the JR = 4 tile: 72 per 144 = 0.5), 8 KB + 2.3 KB of LDS-DMA per 4 x 32 MFMAs (83 B per MFMA against 148).  128 accumulator
+// registers + 40 resident B + 16 A: two workgroups per CU (the launch picks JR per shape so that the grid fills whole rounds of the
+// 512 slots: plan() below).
+template <int TCO, int DT = RDFC_BF16, int JR = 4>     // DT: RDFC_BF16 | RDFC_F16 (2-byte elements moved as opaque bits); JR: pixel rows (of 16) per wave
 __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
                                                               const float *__restrict__ bias, void *__restrict__ yout,
                                                               const bf16_t *__restrict__ zero, float *__restrict__ stats) {
-    constexpr int NW = 4, JR = 4;                              // waves per workgroup; pixel rows (of 16) per wave: a wave owns 64 co x 64 px
+    constexpr int NW = 4;                                      // waves per workgroup; a wave owns 64 co x (JR x 16) px
+    constexpr bool REUSE = JR > 4;                             // kernel-column order with the column's B fragments resident in registers
     constexpr int NT = NW * 64;
     constexpr int WCO = TCO / 64, WPX = NW / WCO;              // waves along co / along pixel rows
     constexpr int TR = JR * WPX, PH = TR + 2, NPATCH = PH * PW; // tile rows, patch rows, patch pixels (180 / 324)
@@ -110,10 +136,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     constexpr int NR = (NPIECE + NT - 1) / NT;                 // patch DMA rounds per slab (3 / 6)
     constexpr int NWP = TCO * 4 / NT;                          // weight DMAs per thread and tap (2 / 1)
     constexpr int WSLOT = TCO * BK * 2;                        // bytes per weight slot
-    constexpr int RING = ring_of<TCO>();
+    constexpr int RING = ring_of<TCO, JR>();
     constexpr int WLOOK = RING - 1;                            // phases between a weight block's DMA and its use
     constexpr int OFF_W = 2 * PATCH_BYTES, OFF_JUNK = OFF_W + RING * WSLOT;
-    static_assert(NR <= 6, "patch rounds must be issued at least three phases before the slab ends");
+    static_assert(NR <= 9 - WLOOK, "the patch rounds of a slab must be older than the weights of its first phase");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
@@ -138,19 +164,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     const int ncc = p.Cin / BK;
 
     // ---- per-thread DMA sources (computed once) -------------------------------------------------------------
-    const bf16_t *psrc[VPW][NR];
-    unsigned plive[VPW];                                         // bit r: round r reads the image (else the zero page)
-    unsigned pdst[VPW][NR];                                      // wave-uniform LDS offset inside a patch buffer, or junk
-    const bf16_t *wsrc[VPW][NWP];
-    unsigned wlive[VPW];                                         // bit k: weight row in range
-#pragma unroll
-    for (int v = 0; v < VPW; ++v) {
-        const int dw = dwave(v), dtid = dw * 64 + lane;
-        plive[v] = wlive[v] = 0;
+    // 32-bit element offsets from x / w (a map is < 2^31 elements): half the registers of pointers; a dead piece reads the zero page.
+    // The LDS image of a patch position (py, px) is 64 bytes at (py * PW + px) * 64 with its four 16-byte chunks XOR-swizzled by bit 2
+    // of px (LDS-DMA destinations are lane-linear, so the swizzle is applied to the SOURCE chunk): a fragment read of 16 neighbouring
+    // pixels x 4 chunks is conflict-free for every start column, and its address splits into a per-lane part that depends on the
+    // kernel column only (three registers) and a compile-time row offset.
+    unsigned poff[NR];
+    unsigned plive = 0;                                          // bit r: round r reads the image (else the zero page)
+    unsigned pdst[NR];                                           // wave-uniform LDS offset inside a patch buffer, or junk
+    unsigned woff;                                               // weight rows tid / 4 + 64 k, k < NWP
+    unsigned wlive = 0;                                          // bit k: weight row in range
+    {
+        const int dtid = wave * 64 + lane;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int e = r * NT + dtid, q = e >> 2, slot = e & 3;
-            psrc[v][r] = zero;
+            poff[r] = 0;
             if (q < NPATCH) {
                 const int py = q / PW, px = q - py * PW;
                 int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px, ni = n;
@@ -160,48 +189,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
                     ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
                 }                          // (what is still outside belongs to output pixels beyond the map: zero page)
                 if (ni < p.N && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
-                    psrc[v][r] = x + ((size_t)(ni * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
-                    plive[v] |= 1u << r;
+                    poff[r] = (unsigned)(((size_t)(ni * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((px >> 1) & 2)) << 3));
+                    plive |= 1u << r;
                 }
             }
-            const int wbase = (r * NT + dw * 64) * 16;           // this share's 1 KB of the patch image
-            pdst[v][r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
+            const int wbase = (r * NT + wave * 64) * 16;         // this wave's 1 KB of the patch image
+            pdst[r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
         }
+        const int row = dtid >> 2, slot = dtid & 3;              // (rows 64 k further on share the swizzle: bit 1 of row / 2 is the same)
+        woff = (unsigned)((size_t)(co0 + row) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3));
 #pragma unroll
-        for (int k = 0; k < NWP; ++k) {
-            const int e = k * NT + dtid, row = e >> 2, slot = e & 3;
-            wsrc[v][k] = zero;
-            if (co0 + row < p.Cout) {
-                wsrc[v][k] = w + (size_t)(co0 + row) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3);
-                wlive[v] |= 1u << k;
-            }
-        }
+        for (int k = 0; k < NWP; ++k)
+            if (co0 + row + 64 * k < p.Cout) wlive |= 1u << k;
     }
+    // Phase s of a slab multiplies the patch at shift (ky, kx) = (s % 3, s / 3) -- kernel column by kernel column, in EVERY variant, so
+    // that each output sums its 9 Cin / 32 partial products in one order whatever tile height the launch picked (same bits) -- with the
+    // weights of tap 3 ky + kx, or of the mirrored tap 8 - (3 ky + kx) in the transposed product.
     auto issue_w = [&](int it) {                                 // weights of global phase `it` -> ring slot it % RING
-        const int cc = it / 9, tap = it - cc * 9;
-        const int off = cc < ncc ? tap * p.Cin + cc * BK : 0;
+        const int cc = it / 9, s_ = it - cc * 9;
+        const int lin = (s_ % 3) * 3 + s_ / 3, tap = p.transposed ? 8 - lin : lin;
+        const bf16_t *wb = w + (size_t)(tap * p.Cin + cc * BK);  // (wave-uniform)
 #pragma unroll
-        for (int v = 0; v < VPW; ++v)
-#pragma unroll
-            for (int k = 0; k < NWP; ++k)
-                glds16((cc < ncc ? wsrc[v][k] : zero) + ((wlive[v] >> k) & 1 ? off : 0),
-                       lds0 + OFF_W + (it % RING) * WSLOT + (k * NT + dwave(v) * 64) * 16);
+        for (int k = 0; k < NWP; ++k)
+            glds16((cc < ncc && ((wlive >> k) & 1)) ? wb + woff + (size_t)k * 64 * 9 * p.Cin : zero,
+                   lds0 + OFF_W + (it % RING) * WSLOT + (k * NT + wave * 64) * 16);
     };
     auto issue_p = [&](int r, int cc) {                          // round r of slab cc -> patch buffer cc & 1
-        const bool live = cc < ncc;
-#pragma unroll
-        for (int v = 0; v < VPW; ++v) {
-            const unsigned dst = pdst[v][r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[v][r];
-            glds16(live ? psrc[v][r] + ((plive[v] >> r) & 1 ? cc * BK : 0) : zero, dst);
-        }
+        const unsigned dst = pdst[r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[r];
+        glds16((cc < ncc && ((plive >> r) & 1)) ? x + cc * BK + poff[r] : zero, dst);
     };
 
     // ---- fragment coordinates ---------------------------------------------------------------------------------
     const int wr = wave / WPX, wc = wave % WPX;
-    int bpp[JR];
+    constexpr int NB = REUSE ? JR + 2 : JR;                      // B fragments a wave holds: the patch rows of a kernel column | of one tap
+    const int kg = lane >> 4;
+    unsigned bcol[3];                                            // per-lane byte offset of the wave's first patch row at column shift kx
 #pragma unroll
-    for (int j = 0; j < JR; ++j) bpp[j] = (JR * wc + j) * PW + (lane & 15);
-    const int arow = wr * 64 + (lane & 15), kg = lane >> 4;
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = (lane & 15) + kx;
+        bcol[kx] = (unsigned)((JR * wc * PW + px) * 64 + ((kg ^ ((px >> 1) & 2)) << 4));
+    }
+    const int arow = wr * 64 + (lane & 15);
 
     f32x4 acc[4][JR];
 #pragma unroll
@@ -211,25 +239,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
 
     // byte address of (row, 16-byte chunk kg) in a swizzled 64-byte-row image: (row*64 + kg*16) ^ ((row & 4) << 3)
     const unsigned a_off = (unsigned)((arow << 6) | (kg << 4)) ^ (unsigned)((arow & 4) << 3);     // + i*1024: rows arow + 16 i share bit 2
-    auto read_frags = [&](int it, int cc, int tap, bf16x8 (&a)[4], bf16x8 (&b)[JR]) {
-        const int kh = tap / 3, kw = tap - kh * 3;
-        const int shift = p.transposed ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
+    auto read_a = [&](int it, bf16x8 (&a)[4]) {
         const unsigned char *Wt = smem + OFF_W + (it % RING) * WSLOT + a_off;
-        const unsigned char *Pt = smem + (cc & 1) * PATCH_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(Wt + i * 1024);
-#pragma unroll
-        for (int j = 0; j < JR; ++j) {
-            const int row = bpp[j] + shift;
-            b[j] = *reinterpret_cast<const bf16x8 *>(Pt + (((row << 6) | (kg << 4)) ^ ((row & 4) << 3)));
-        }
     };
-    auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[JR]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < JR; ++j) acc[i][j] = mma16<DT>(a[i], b[j], acc[i][j]);
+    auto read_b = [&](int cc, int kx, int row) -> bf16x8 {      // patch row `row` of the wave (0 ... JR + 1) at column shift kx
+        return *reinterpret_cast<const bf16x8 *>(smem + (cc & 1) * PATCH_BYTES + bcol[kx] + row * (PW * 64));
     };
+    bf16x8 bres[NB];                                             // REUSE: the B fragments of the current kernel column, patch row j in bres[j]
 #ifdef RDFC_GLDS_STAMPS
     unsigned long long sbuf[9][6];
     const bool stamp_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;
@@ -242,10 +260,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
 #pragma unroll
     for (int h = 0; h < WLOOK; ++h) issue_w(h);
 
-    // phase (cc, TAP): DMAs still allowed in flight at its wait = those issued in the two previous phases
+    // phase (cc, S): DMAs still allowed in flight at its wait = the weights of the WLOOK - 1 phases after this one and the patch rounds
+    // issued beside them (glds_allow)
 #define RDFC_GLDS_PHASE(TAP)                                                                                   \
     {                                                                                                          \
-        constexpr int ALLOW = (WLOOK - 1) * NWP + (WLOOK >= 3 && ((TAP + 7) % 9) < NR ? 1 : 0) + (((TAP + 8) % 9) < NR ? 1 : 0); \
+        constexpr int ALLOW = glds_allow(TAP, WLOOK, NWP, NR);                                                 \
         RDFC_STAMP(TAP, 0)                                                                                     \
         wait_vm_and_reads<ALLOW>();                                                                            \
         RDFC_STAMP(TAP, 1)                                                                                     \
@@ -255,10 +274,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
         if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
         RDFC_STAMP(TAP, 3)                                                                                     \
         {                                                                                                      \
-            bf16x8 a_[4], b_[JR];                                                                              \
-            read_frags(it0 + TAP, cc, TAP, a_, b_);                                                            \
+            bf16x8 a_[4];                                                                                      \
+            constexpr int KY = TAP % 3, KX = TAP / 3;                                                          \
+            if constexpr (REUSE) {           /* rows 0 ... JR - 1 with the column's first tap, one more row with each of the others */ \
+                if (KY == 0) {                                                                                 \
+                    _Pragma("unroll") for (int j = 0; j < JR; ++j) bres[j] = read_b(cc, KX, j);                \
+                } else                                                                                         \
+                    bres[JR - 1 + KY] = read_b(cc, KX, JR - 1 + KY);                                           \
+            } else {                                                                                           \
+                _Pragma("unroll") for (int j = 0; j < JR; ++j) bres[j] = read_b(cc, KX, j + KY);               \
+            }                                                                                                  \
+            read_a(it0 + TAP, a_);                                                                             \
             RDFC_STAMP(TAP, 4)                                                                                 \
-            mma(a_, b_);                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+                _Pragma("unroll") for (int j = 0; j < JR; ++j)                                                 \
+                    acc[i][j] = mma16<DT>(a_[i], bres[REUSE ? j + KY : j], acc[i][j]);                         \
         }                                                                                                      \
         RDFC_STAMP(TAP, 5)                                                                                     \
     }
@@ -423,30 +453,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
         __syncthreads();                                           // every wave is done with the operand tiles
         unsigned char *Ot = smem + wave * RS_TILE;
 #pragma unroll
-        for (int j = 0; j < JR; ++j)
+        for (int j0 = 0; j0 < JR; j0 += 4) {                       // 64 pixels (four tile rows) at a time through the wave's 9 KB
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v[4];
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j0 + jj < JR ? j0 + jj : JR - 1;     // (compile-time; a last group of fewer than four rows leaves its other rows unwritten and unread)
+                if (j0 + jj >= JR) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float u = acc[i][j][r] + bv[i][r];
-                    v[r] = u > 0.f ? u : u * ns;
+                for (int i = 0; i < 4; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = acc[i][j][r] + bv[i][r];
+                        v[r] = u > 0.f ? u : u * ns;
+                    }
+                    const int co = co0 + wr * 64 + 16 * i + q4, ox = x0 + (lane & 15);
+                    if (p.addend != nullptr && oyr[j] >= 0 && ox < p.W && co < p.Cout) {        // (the addend, in f32, from its 8-byte pieces)
+                        const size_t po = ((size_t)on[j] * p.H + oyr[j]) * p.W + ox;
+                        const bf16x4 t = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const bf16_t *>(p.addend) + po * p.ld_add + co);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t[r]);
+                    }
+                    rs_put<DT>(Ot, 16 * jj + (lane & 15), 16 * i + q4, v);
                 }
-                const int co = co0 + wr * 64 + 16 * i + q4, ox = x0 + (lane & 15);
-                if (p.addend != nullptr && oyr[j] >= 0 && ox < p.W && co < p.Cout) {        // (the addend, in f32, from its 8-byte pieces)
-                    const size_t po = ((size_t)on[j] * p.H + oyr[j]) * p.W + ox;
-                    const bf16x4 t = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const bf16_t *>(p.addend) + po * p.ld_add + co);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += f32of<DT>(t[r]);
-                }
-                rs_put<DT>(Ot, 16 * j + (lane & 15), 16 * i + q4, v);
             }
-        const int cow = co0 + wr * 64;
-        rs_flush(Ot, lane, reinterpret_cast<bf16_t *>(yout) + cow, p.Cout - cow, [&](int px) -> long {
-            const int j = px >> 4, ox = x0 + (px & 15);            // (j: compile-time after unrolling)
-            if (oyr[j] < 0 || ox >= p.W) return -1;
-            return (((long)on[j] * p.H + oyr[j]) * p.W + ox) * p.ld_out;
-        });
+            const int cow = co0 + wr * 64;
+            rs_flush(Ot, lane, reinterpret_cast<bf16_t *>(yout) + cow, p.Cout - cow, [&](int px) -> long {
+                const int jj = px >> 4, ox = x0 + (px & 15);       // (jj: compile-time after unrolling)
+                if (j0 + jj >= JR) return -1;
+                const int j = j0 + jj < JR ? j0 + jj : JR - 1;
+                if (oyr[j] < 0 || ox >= p.W) return -1;
+                return (((long)on[j] * p.H + oyr[j]) * p.W + ox) * p.ld_out;
+            });
+        }
         return;
     }
     if (p.act == RDFC_ACT_TANH) store_all([](float u) { return tanhf(u); });
@@ -471,19 +509,22 @@ const bf16_t *zero_page() {
     return (const bf16_t *)pages[dev];
 }
 
-template <int TCO, int DT = RDFC_BF16>
+template <int TCO, int DT = RDFC_BF16, int JR = 4>
 int launch(const GParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, float *stats, hipStream_t st) {
-    constexpr int NT = 256, TR = 4 * 4 / (TCO / 64);
+    constexpr int NT = 256, TR = JR * 4 / (TCO / 64);
     constexpr int NPIECE = (TR + 2) * PW * 4, PATCH = (NPIECE + 63) / 64 * 1024, NR = (NPIECE + NT - 1) / NT;
-    constexpr int SMEM = 2 * PATCH + ring_of<TCO>() * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
+    constexpr int OPER = 2 * PATCH + ring_of<TCO, JR>() * TCO * BK * 2 + (NR * NT * 16 > PATCH ? 1024 : 0);      // + scratch for the DMA rounds' overhang
+    constexpr int SMEM = OPER > (NT / 64) * RS_TILE ? OPER : (NT / 64) * RS_TILE;                                  // the whole-row epilogue reuses it: 9 KB per wave
+    static_assert(SMEM >= (NT / 64) * RS_TILE, "rs_put / rs_flush write wave * RS_TILE ... + RS_TILE");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)conv3x3_glds_kernel<TCO, DT, JR>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * (p.vstride ? 1 : p.N), cdiv(p.Cout, TCO));
-    rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, DT);         // the symbol as rocprofv3 prints it
-    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, DT>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
+    if (JR == 4) rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, DT);         // the symbol as rocprofv3 prints it (a default template argument is not printed)
+    else rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d>", TCO, DT, JR);
+    hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, DT, JR>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
     return 1;
 }
 
@@ -534,11 +575,58 @@ static int stack_groups(int N, int G, int H, int Hin, int oy0, int TR, int &tile
     return S;
 }
 
+// ---- which tile for which launch (round 5) ------------------------------------------------------------------------------------------
+// 128-co workgroups come as 128 co x (8 x 16) px at three per CU (JR = 4: 768 slots) or as tall tiles 128 co x (2 JR x 16) px at two per
+// CU (JR = 6 / 8 / 10: 512 slots; less staged and read per MFMA, see the kernel).  A grid is dealt to the slots in rounds and its last,
+// partly filled round costs nearly a whole one, so the choice is made per launch from the grid each tile height gives: estimated time =
+// rows per workgroup x (full rounds + what the partial round costs) / the tile's steady-state rate.  The rates are measured
+// (profiles/r05_experiments.txt); RDFC_GLDS_JR=4|6|8|10 forces one height.
+struct GPlan {
+    int jr, tiles_y, vstride, gstride;
+};
+static int g_glds_jr = getenv("RDFC_GLDS_JR") ? atoi(getenv("RDFC_GLDS_JR")) : 0;
+extern "C" void rdfc_tune_glds_rows(int jr) { g_glds_jr = jr; }    // measurement aid (tools/conv_tall_bench.py): A/B of the tile heights in one process
+static GPlan glds_plan(int N, int H, int W, int Hin, int oy0, int Cout, int G, bool reflect) {
+    const int forced = g_glds_jr;
+    static const double gain = getenv("RDFC_GLDS_TALL_GAIN") ? atof(getenv("RDFC_GLDS_TALL_GAIN")) : 1.2;
+    auto tiles = [&](int TR, GPlan &g) {
+        g.gstride = 0;
+        if (G > 0) g.vstride = stack_groups(N, G, H, Hin, oy0, TR, g.tiles_y, g.gstride);
+        else g.vstride = stack_rows(N, H, Hin, oy0, TR, !reflect, g.tiles_y);
+        return (long)cdiv(W, TC) * g.tiles_y * (g.vstride ? 1 : N) * cdiv(Cout, 128);
+    };
+    GPlan best{4, 0, 0, 0};
+    if (Cout <= 64) {                                            // 64 co x (16 x 16) px, four waves side by side in rows
+        tiles(16, best);
+        return best;
+    }
+    double best_cost = 0;
+    const int cand[4] = {4, 6, 8, 10};
+    for (int c = 0; c < 4; ++c) {
+        const int jr = cand[c];
+        if (forced ? jr != forced : false) continue;
+        GPlan g{jr, 0, 0, 0};
+        const long wgs = tiles(2 * jr, g);
+        const int per_cu = jr == 4 ? 3 : 2, slots = 256 * per_cu;
+        const long full = wgs / slots, rest = wgs - full * slots;
+        // a partly filled round: a CU with fewer resident workgroups finishes each sooner (one alone: ~0.45 / ~0.7 of the time it
+        // takes beside two / one other)
+        double part = 0;
+        if (rest > 0) part = per_cu == 3 ? (rest <= 256 ? 0.45 : (rest <= 512 ? 0.75 : 1.0)) : (rest <= 256 ? 0.7 : 1.0);
+        const double rate = jr == 4 ? 1.0 : gain * (jr == 6 ? 0.93 : 1.0);
+        const double cost = jr * (full + part) / (per_cu * rate);                  // ~ time: rows per workgroup x rounds / (workgroups per CU x rate)
+        if (best.tiles_y == 0 || cost < best_cost) {
+            best = g;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
 int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G) {
     if (!glds_shape_ok(d, 0) || G < 1 || d->N % G != 0) return 0;
-    int tiles_y, gstride;
-    stack_groups(d->N, G, d->Ho, d->Hi, -d->ph, d->Co > 64 ? 8 : 16, tiles_y, gstride);
-    return (tiles_y / G) * cdiv(d->Wo, TC);                     // rows per group
+    const GPlan g = glds_plan(d->N, d->Ho, d->Wo, d->Hi, -d->ph, d->Co, G, false);
+    return (g.tiles_y / G) * cdiv(d->Wo, TC);                   // rows per group
 }
 
 // Called by conv_igemm.hip's entry points before the register-staged 3x3 kernels. Returns 1 if it took the launch.
@@ -563,16 +651,28 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     p.row_store = rows_on && !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
-    p.tiles_x = cdiv(p.W, TC);                                 // 128 co x (8 x 16) px or 64 co x (16 x 16) px per workgroup
+    p.tiles_x = cdiv(p.W, TC);                                 // 128 co x (2 JR x 16) px or 64 co x (16 x 16) px per workgroup
     if (stats != nullptr) {
         if (G < 1 || p.N % G != 0 || transposed || reflect) return 0;
         p.npg = p.N / G;
-        p.vstride = stack_groups(p.N, G, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, p.tiles_y, p.gstride);
-    } else
-        p.vstride = stack_rows(p.N, p.H, p.Hin, p.oy0, Cout > 64 ? 8 : 16, !reflect, p.tiles_y);
-    if (d->dtype == RDFC_F16)
-        return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, stats, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, stats, st);
-    return Cout > 64 ? launch<128>(p, in, w, bias, out, zero, stats, st) : launch<64>(p, in, w, bias, out, zero, stats, st);
+    }
+    const GPlan g = glds_plan(p.N, p.H, p.W, p.Hin, p.oy0, Cout, stats != nullptr ? G : 0, reflect != 0);
+    p.tiles_y = g.tiles_y;
+    p.vstride = g.vstride;
+    p.gstride = g.gstride;
+#define RDFC_GLDS_LAUNCH(DT_)                                                                                        \
+    if (Cout <= 64) return launch<64, DT_>(p, in, w, bias, out, zero, stats, st);                                  \
+    switch (g.jr) {                                                                                                  \
+        case 6: return launch<128, DT_, 6>(p, in, w, bias, out, zero, stats, st);                                  \
+        case 8: return launch<128, DT_, 8>(p, in, w, bias, out, zero, stats, st);                                  \
+        case 10: return launch<128, DT_, 10>(p, in, w, bias, out, zero, stats, st);                                \
+        default: return launch<128, DT_>(p, in, w, bias, out, zero, stats, st);                                    \
+    }
+    if (d->dtype == RDFC_F16) {
+        RDFC_GLDS_LAUNCH(RDFC_F16)
+    }
+    RDFC_GLDS_LAUNCH(RDFC_BF16)
+#undef RDFC_GLDS_LAUNCH
 }
 
 #ifdef RDFC_GLDS_STAMPS
