@@ -22,6 +22,10 @@
 
 #include <stdlib.h>
 
+#ifndef RDFC_GLDS_REUSE_MIN
+#define RDFC_GLDS_REUSE_MIN 4
+#endif
+
 namespace {
 
 struct GParams {
@@ -41,6 +45,7 @@ struct GParams {
     int ld_add;                  // input gradient of a residual junction in one pass (rdfc_conv2d_dgrad_add)
     int reflect;                 // forward only: out-of-image patch pixels read their mirror image (ReflectionPad2d folded into the loader)
     int row_store;               // epilogue through LDS: whole 128-byte channel rows per store instruction (see the epilogue)
+    unsigned x_bytes, w_bytes;   // extents of the input map and of the packed weights (buffer descriptors of the LDS-DMA loads; < 2^31)
 };
 
 constexpr int BK = 32, TC = 16, PW = TC + 2;
@@ -50,7 +55,7 @@ constexpr int BK = 32, TC = 16, PW = TC + 2;
 // three workgroups on a CU (50 KB each): 64->64 @ 16x228x304 160 -> 134 us forward, 163 -> 136 input gradient, 128->64 244 -> 218.
 template <int TCO, int JR = 4> constexpr int ring_of() {
 #ifdef RDFC_GLDS_TALL_RING
-    return JR > 4 ? RDFC_GLDS_TALL_RING : (TCO == 128 ? 3 : 2);
+    return JR > 4 && JR <= 8 ? RDFC_GLDS_TALL_RING : (TCO == 128 ? 3 : 2);
 #else
     return TCO == 128 ? 3 : 2;
 #endif
@@ -74,6 +79,32 @@ __device__ inline void glds16(const void *gsrc, unsigned lds_base) {
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_base)
                  : "memory");
+}
+// The same through a buffer descriptor: lane l reads 16 bytes at base + soff + voff (voff per lane, soff wave-uniform) and lands at
+// lds_base + 16 l.  A lane whose voff is not below the descriptor's num_records is out of range and its 16 bytes arrive as ZEROS: the
+// padding around a map, the rows between two stacked images and the channel rows beyond Cout need no zero page and no select --
+// their voff is DEAD.  (soff is not part of the range check: a uniform offset that may run off the end -- a slab beyond the last --
+// goes with a descriptor of zero records instead.)  No vector instruction per DMA: offsets are 32-bit registers computed once.
+constexpr unsigned DEAD = 0x80000000u;
+__device__ inline void bdma16(unsigned voff, u32x4 rsrc, unsigned soff, unsigned lds_base) {
+#ifdef RDFC_GLDS_M0_CLOBBER      // experiment: m0 declared clobbered instead of saved and restored (clang warns that m0 is reserved)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "memory", "m0");
+    return;
+#endif
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
+                 : "memory");
+}
+__device__ inline u32x4 make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);      // stride 0: a raw buffer, offsets in bytes
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
 }
 template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -127,7 +158,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
                                                               const float *__restrict__ bias, void *__restrict__ yout,
                                                               const bf16_t *__restrict__ zero, float *__restrict__ stats) {
     constexpr int NW = 4;                                      // waves per workgroup; a wave owns 64 co x (JR x 16) px
-    constexpr bool REUSE = JR > 4;                             // kernel-column order with the column's B fragments resident in registers
+    constexpr bool REUSE = JR >= RDFC_GLDS_REUSE_MIN;                             // kernel-column order with the column's B fragments resident in registers
+#ifdef RDFC_GLDS_NOPIPE
+    constexpr bool PIPE = false;
+#else
+    constexpr bool PIPE = REUSE;                               // ... and every fragment read issued one phase ahead (the loop at the end of the K section)
+#endif
     constexpr int NT = NW * 64;
     constexpr int WCO = TCO / 64, WPX = NW / WCO;              // waves along co / along pixel rows
     constexpr int TR = JR * WPX, PH = TR + 2, NPATCH = PH * PW; // tile rows, patch rows, patch pixels (180 / 324)
@@ -164,22 +200,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     const int ncc = p.Cin / BK;
 
     // ---- per-thread DMA sources (computed once) -------------------------------------------------------------
-    // 32-bit element offsets from x / w (a map is < 2^31 elements): half the registers of pointers; a dead piece reads the zero page.
+    // 32-bit BYTE offsets from x / w through buffer descriptors (bdma16): a piece outside the image, in the rows between two stacked
+    // images or beyond Cout is DEAD and arrives as zeros.
     // The LDS image of a patch position (py, px) is 64 bytes at (py * PW + px) * 64 with its four 16-byte chunks XOR-swizzled by bit 2
     // of px (LDS-DMA destinations are lane-linear, so the swizzle is applied to the SOURCE chunk): a fragment read of 16 neighbouring
     // pixels x 4 chunks is conflict-free for every start column, and its address splits into a per-lane part that depends on the
     // kernel column only (three registers) and a compile-time row offset.
     unsigned poff[NR];
-    unsigned plive = 0;                                          // bit r: round r reads the image (else the zero page)
     unsigned pdst[NR];                                           // wave-uniform LDS offset inside a patch buffer, or junk
-    unsigned woff;                                               // weight rows tid / 4 + 64 k, k < NWP
-    unsigned wlive = 0;                                          // bit k: weight row in range
+    unsigned woff[NWP];                                          // weight rows tid / 4 + 64 k
+    const u32x4 xsrc = make_rsrc(x, (unsigned)p.x_bytes), wsrc = make_rsrc(w, (unsigned)p.w_bytes);
     {
         const int dtid = wave * 64 + lane;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int e = r * NT + dtid, q = e >> 2, slot = e & 3;
-            poff[r] = 0;
+            poff[r] = DEAD;
             if (q < NPATCH) {
                 const int py = q / PW, px = q - py * PW;
                 int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px, ni = n;
@@ -187,20 +223,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
                 if (p.reflect) {           // LDS-DMA sources are per lane: the halo of a reflection-padded map is just another address
                     iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);
                     ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
-                }                          // (what is still outside belongs to output pixels beyond the map: zero page)
-                if (ni < p.N && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
-                    poff[r] = (unsigned)(((size_t)(ni * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((px >> 1) & 2)) << 3));
-                    plive |= 1u << r;
-                }
+                }                          // (what is still outside belongs to output pixels beyond the map: zeros)
+                if (ni < p.N && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)
+                    poff[r] = 2u * (unsigned)(((size_t)(ni * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((px >> 1) & 2)) << 3));
             }
             const int wbase = (r * NT + wave * 64) * 16;         // this wave's 1 KB of the patch image
             pdst[r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
         }
         const int row = dtid >> 2, slot = dtid & 3;              // (rows 64 k further on share the swizzle: bit 1 of row / 2 is the same)
-        woff = (unsigned)((size_t)(co0 + row) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3));
 #pragma unroll
         for (int k = 0; k < NWP; ++k)
-            if (co0 + row + 64 * k < p.Cout) wlive |= 1u << k;
+            woff[k] = co0 + row + 64 * k < p.Cout ? 2u * (unsigned)((size_t)(co0 + row + 64 * k) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3)) : DEAD;
     }
     // Phase s of a slab multiplies the patch at shift (ky, kx) = (s % 3, s / 3) -- kernel column by kernel column, in EVERY variant, so
     // that each output sums its 9 Cin / 32 partial products in one order whatever tile height the launch picked (same bits) -- with the
@@ -208,15 +241,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     auto issue_w = [&](int it) {                                 // weights of global phase `it` -> ring slot it % RING
         const int cc = it / 9, s_ = it - cc * 9;
         const int lin = (s_ % 3) * 3 + s_ / 3, tap = p.transposed ? 8 - lin : lin;
-        const bf16_t *wb = w + (size_t)(tap * p.Cin + cc * BK);  // (wave-uniform)
+        u32x4 rs = wsrc;
+        if (cc >= ncc) rs[2] = 0;                                // (a phase beyond the last slab: zeros)
+        const unsigned soff = 2u * (unsigned)(tap * p.Cin + cc * BK);
 #pragma unroll
-        for (int k = 0; k < NWP; ++k)
-            glds16((cc < ncc && ((wlive >> k) & 1)) ? wb + woff + (size_t)k * 64 * 9 * p.Cin : zero,
-                   lds0 + OFF_W + (it % RING) * WSLOT + (k * NT + wave * 64) * 16);
+        for (int k = 0; k < NWP; ++k) bdma16(woff[k], rs, soff, lds0 + OFF_W + (it % RING) * WSLOT + (k * NT + wave * 64) * 16);
     };
     auto issue_p = [&](int r, int cc) {                          // round r of slab cc -> patch buffer cc & 1
         const unsigned dst = pdst[r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[r];
-        glds16((cc < ncc && ((plive >> r) & 1)) ? x + cc * BK + poff[r] : zero, dst);
+        u32x4 rs = xsrc;
+        if (cc >= ncc) rs[2] = 0;
+        bdma16(poff[r], rs, 2u * (unsigned)(cc * BK), dst);
     };
 
     // ---- fragment coordinates ---------------------------------------------------------------------------------
@@ -254,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     const int wave_all = wave;
 #endif
 
+    if constexpr (!PIPE) {
     // ---- prologue: slab 0 patch, weights of the first RING-1 phases --------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < NR; ++r) issue_p(r, 0);
@@ -305,6 +341,73 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
         RDFC_GLDS_PHASE(8)
     }
 #undef RDFC_GLDS_PHASE
+    } else {
+    // ---- the tall tiles' loop: every fragment read is issued a phase ahead, between the MFMAs of the phase before ----------------------
+    // Two waves share a SIMD here (not three), so a phase that runs wait -> barrier -> DMA issue -> fragment reads -> MFMAs one after the
+    // other leaves the matrix pipe idle whenever both are in the front part (stamps of round 5: 56 % busy).  Now a phase's MFMAs take all
+    // their operands from registers that were filled during the phase before, IN PLACE (no second register set):
+    //   * the MFMAs run channel block by channel block (i outer, rows inner): weight fragment i is dead after its JR MFMAs, and the
+    //     fragment i of the NEXT phase is read into its registers (that ring slot landed a phase earlier than it used to: the waits
+    //     below cover the next phase's weights);
+    //   * the pixel fragments roll: a column's second and third tap need one more patch row each, read a phase ahead into the registers
+    //     of a row that is dead; during a column's last tap the next column's rows (at the slab's last tap: the next slab's patch, which
+    //     therefore must have landed one phase before the slab ends) replace the rows as their last MFMA is issued.
+    bf16x8 aa[4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) issue_p(r, 0);
+#pragma unroll
+    for (int h = 0; h <= WLOOK; ++h) issue_w(h);
+    wait_vm<WLOOK * NWP>();                                      // patch 0 and the weights of phase 0
+    __builtin_amdgcn_s_barrier();
+    read_a(0, aa);
+#pragma unroll
+    for (int j = 0; j < JR; ++j) bres[j] = read_b(0, 0, j);
+#ifndef RDFC_GLDS_SCHED
+#define RDFC_GLDS_SCHED __builtin_amdgcn_sched_barrier(0);
+#endif
+#define RDFC_GLDS_PHASE(TAP)                                                                                   \
+    {                                                                                                          \
+        constexpr int ALLOW = glds_allow(TAP, WLOOK, NWP, NR);    /* the weights of phase it + 1 were issued WLOOK phases ago */ \
+        constexpr int KY = TAP % 3, KX = TAP / 3;                                                              \
+        constexpr int NKX = (KX + 1) % 3;                         /* KY == 2: the column the prefetched rows belong to */ \
+        const int ncc_ = (TAP == 8) ? cc + 1 : cc;                                                             \
+        RDFC_STAMP(TAP, 0)                                                                                     \
+        wait_vm_and_reads<ALLOW>();                                                                            \
+        RDFC_STAMP(TAP, 1)                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        RDFC_STAMP(TAP, 2)                                                                                     \
+        issue_w(it0 + TAP + 1 + WLOOK);                                                                        \
+        if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
+        RDFC_STAMP(TAP, 3)                                                                                     \
+        if (KY == 2) {                                                                                         \
+            bres[0] = read_b(ncc_, NKX, 0);                                                                    \
+            bres[1] = read_b(ncc_, NKX, 1);                                                                    \
+        } else                                                                                                 \
+            bres[JR + KY] = read_b(cc, KX, JR + KY);                                                           \
+        RDFC_STAMP(TAP, 4)                                                                                     \
+        RDFC_GLDS_SCHED                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+            _Pragma("unroll") for (int j = 0; j < JR; ++j) {                                                   \
+                acc[i][j] = mma16<DT>(aa[i], bres[j + KY], acc[i][j]);                                         \
+                if (KY == 2 && i == 3 && j + 2 < JR) {                                                         \
+                    RDFC_GLDS_SCHED                                                                            \
+                    bres[j + 2] = read_b(ncc_, NKX, j + 2);                                                    \
+                    RDFC_GLDS_SCHED                                                                            \
+                }                                                                                              \
+            }                                                                                                  \
+            RDFC_GLDS_SCHED                                                                                    \
+            aa[i] = *reinterpret_cast<const bf16x8 *>(smem + OFF_W + ((it0 + TAP + 1) % RING) * WSLOT + a_off + i * 1024); \
+            RDFC_GLDS_SCHED                                                                                    \
+        }                                                                                                      \
+        RDFC_STAMP(TAP, 5)                                                                                     \
+    }
+    for (int cc = 0; cc < ncc; ++cc) {
+        const int it0 = cc * 9;
+        RDFC_GLDS_PHASE(0) RDFC_GLDS_PHASE(1) RDFC_GLDS_PHASE(2) RDFC_GLDS_PHASE(3) RDFC_GLDS_PHASE(4)
+        RDFC_GLDS_PHASE(5) RDFC_GLDS_PHASE(6) RDFC_GLDS_PHASE(7) RDFC_GLDS_PHASE(8)
+    }
+#undef RDFC_GLDS_PHASE
+    }
     wait_vm<0>();
 #ifdef RDFC_GLDS_STAMPS
     if (stamp_on && lane == 0 && ncc > 2)
@@ -537,6 +640,8 @@ static bool glds_shape_ok(const rdfc_conv_desc *d, int transposed) {
     if (!(d->KH == 3 && d->KW == 3 && d->sh == 1 && d->sw == 1 && d->ph == d->pw && d->ph <= 1 && d->dh == 1 && d->dw == 1)) return false;
     if (Cin % BK != 0 || d->Ho != d->Hi + 2 * d->ph - 2 || d->Wo != d->Wi + 2 * d->pw - 2) return false;
     const int ld_in = transposed ? d->ldy : d->ldx;
+    const size_t in_bytes = 2 * (size_t)d->N * (transposed ? d->Ho : d->Hi) * (transposed ? d->Wo : d->Wi) * ld_in;
+    if (in_bytes >= 0x7ffffff0u || 2 * (size_t)Cout * 9 * Cin >= 0x7ffffff0u) return false;     // the loaders address both through 32-bit byte offsets
     return ld_in % 8 == 0 && Cout >= 64;
 }
 
@@ -579,16 +684,19 @@ static int stack_groups(int N, int G, int H, int Hin, int oy0, int TR, int &tile
 // 128-co workgroups come as 128 co x (8 x 16) px at three per CU (JR = 4: 768 slots) or as tall tiles 128 co x (2 JR x 16) px at two per
 // CU (JR = 6 / 8 / 10: 512 slots; less staged and read per MFMA, see the kernel).  A grid is dealt to the slots in rounds and its last,
 // partly filled round costs nearly a whole one, so the choice is made per launch from the grid each tile height gives: estimated time =
-// rows per workgroup x (full rounds + what the partial round costs) / the tile's steady-state rate.  The rates are measured
-// (profiles/r05_experiments.txt); RDFC_GLDS_JR=4|6|8|10 forces one height.
+// rounds x rows per workgroup x workgroups per CU / the tile's steady-state rate, a partly filled round counted by how many workgroups
+// its CUs hold.  Calibrated on tools/conv_tall_bench.py (profiles/r05_experiments.txt): the tall tiles run 1.13 x the JR = 4 rate when
+// the K loop is long enough (Cin >= 128; with two slabs the prologue and the stores are what a workgroup spends its time on), e.g.
+// 256 -> 256 @ 16 x 57 x 76: 1160 workgroups of JR = 4 are 1.5 rounds of 768 slots, 470 of JR = 10 one round of 512 (82 -> 73 us);
+// 512 -> 512 @ 16 x 29 x 38: JR = 6 gives 480 (91 -> 81 us); 128 -> 128 @ 16 x 114 x 152 stays at JR = 4 (2300 = 2.99 rounds).
+// RDFC_GLDS_JR=4|6|8|10 / rdfc_tune_glds_rows force one height.
 struct GPlan {
     int jr, tiles_y, vstride, gstride;
 };
 static int g_glds_jr = getenv("RDFC_GLDS_JR") ? atoi(getenv("RDFC_GLDS_JR")) : 0;
 extern "C" void rdfc_tune_glds_rows(int jr) { g_glds_jr = jr; }    // measurement aid (tools/conv_tall_bench.py): A/B of the tile heights in one process
-static GPlan glds_plan(int N, int H, int W, int Hin, int oy0, int Cout, int G, bool reflect) {
+static GPlan glds_plan(int N, int H, int W, int Hin, int oy0, int Cin, int Cout, int G, bool reflect) {
     const int forced = g_glds_jr;
-    static const double gain = getenv("RDFC_GLDS_TALL_GAIN") ? atof(getenv("RDFC_GLDS_TALL_GAIN")) : 1.2;
     auto tiles = [&](int TR, GPlan &g) {
         g.gstride = 0;
         if (G > 0) g.vstride = stack_groups(N, G, H, Hin, oy0, TR, g.tiles_y, g.gstride);
@@ -609,12 +717,11 @@ static GPlan glds_plan(int N, int H, int W, int Hin, int oy0, int Cout, int G, b
         const long wgs = tiles(2 * jr, g);
         const int per_cu = jr == 4 ? 3 : 2, slots = 256 * per_cu;
         const long full = wgs / slots, rest = wgs - full * slots;
-        // a partly filled round: a CU with fewer resident workgroups finishes each sooner (one alone: ~0.45 / ~0.7 of the time it
-        // takes beside two / one other)
+        // a partly filled round: a CU with fewer resident workgroups finishes each of them sooner
         double part = 0;
         if (rest > 0) part = per_cu == 3 ? (rest <= 256 ? 0.45 : (rest <= 512 ? 0.75 : 1.0)) : (rest <= 256 ? 0.7 : 1.0);
-        const double rate = jr == 4 ? 1.0 : gain * (jr == 6 ? 0.93 : 1.0);
-        const double cost = jr * (full + part) / (per_cu * rate);                  // ~ time: rows per workgroup x rounds / (workgroups per CU x rate)
+        const double rate = (jr == 4 || Cin < 128) ? 1.0 : 1.13;
+        const double cost = (full + part) * jr * per_cu / rate;
         if (best.tiles_y == 0 || cost < best_cost) {
             best = g;
             best_cost = cost;
@@ -625,7 +732,7 @@ static GPlan glds_plan(int N, int H, int W, int Hin, int oy0, int Cout, int G, b
 
 int rdfc_conv3x3_glds_stats_nchunk(const rdfc_conv_desc *d, int G) {
     if (!glds_shape_ok(d, 0) || G < 1 || d->N % G != 0) return 0;
-    const GPlan g = glds_plan(d->N, d->Ho, d->Wo, d->Hi, -d->ph, d->Co, G, false);
+    const GPlan g = glds_plan(d->N, d->Ho, d->Wo, d->Hi, -d->ph, d->Ci, d->Co, G, false);
     return (g.tiles_y / G) * cdiv(d->Wo, TC);                   // rows per group
 }
 
@@ -644,7 +751,9 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     const int pad = d->ph;
     GParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo,
               Cin, Cout, ld_in, transposed ? d->ldx : d->ldy, transposed, transposed ? pad - 2 : -pad, transposed ? pad - 2 : -pad,
-              d->act, d->slope, d->out_f32, 0, 0, 0, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect, 0};
+              d->act, d->slope, d->out_f32, 0, 0, 0, 0, 0, stats != nullptr ? G : 0, addend, ld_add, reflect, 0, 0, 0};
+    p.x_bytes = (unsigned)(2 * (size_t)p.N * p.Hin * p.Win * p.ld_in);      // (< 2^31: glds_shape_ok; a channel slice's last pixel ends before that, and no live offset points there)
+    p.w_bytes = (unsigned)(2 * (size_t)Cout * 9 * Cin);
     // whole-row stores: 2-byte results without an addend, channel rows of whole 16-byte chunks at 16-byte aligned addresses, a
     // piecewise-linear epilogue (RDFC_GLDS_ROWSTORE=0: the direct 8-byte stores, for A/B runs)
     static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
@@ -656,7 +765,7 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
         if (G < 1 || p.N % G != 0 || transposed || reflect) return 0;
         p.npg = p.N / G;
     }
-    const GPlan g = glds_plan(p.N, p.H, p.W, p.Hin, p.oy0, Cout, stats != nullptr ? G : 0, reflect != 0);
+    const GPlan g = glds_plan(p.N, p.H, p.W, p.Hin, p.oy0, Cin, Cout, stats != nullptr ? G : 0, reflect != 0);
     p.tiles_y = g.tiles_y;
     p.vstride = g.vstride;
     p.gstride = g.gstride;

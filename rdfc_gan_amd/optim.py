@@ -215,7 +215,7 @@ class FlatAdam(torch.optim.Optimizer):
     def _distributed():
         return dp_active()
 
-    def all_reduce_bucket_async(self, i, helpers=True):
+    def all_reduce_bucket_async(self, i, helpers=True, after=()):
         """start the all-reduce of bucket i (idempotent within a step).  Nothing on the compute streams waits here: the
         collective is issued (async_op) from the weight-gradient stream after that stream has been made to wait for the
         current one and the other helper streams -- its later launches wait for the current stream anyway -- so the process
@@ -226,7 +226,11 @@ class FlatAdam(torch.optim.Optimizer):
         queues first -- functional.reserve_streams -- with either scheme)
         RDFC_DP_COMM=stream keeps the round-1 scheme (a communication stream per optimizer) for A/B runs.
         helpers=False: the bucket's gradients come from the current stream and the weight-gradient stream only (the
-        discriminators' step beside G's backward): do not wait for what the other helper streams are still running."""
+        discriminators' step beside G's backward): do not wait for what the other helper streams are still running.
+        after: events the collective must also follow -- a bucket started from inside a backward is started by the LAST of several
+        markers, each of which fired on its own stream; the marker that fired first recorded an event there (round-4 advice: the
+        issue stream otherwise follows only the last marker's stream, and gradients that autograd accumulates on the first
+        marker's stream -- W-AdaIN's style weights on the main stream -- could still be in flight when the collective reads them)."""
         if not self._distributed() or i in self._started:
             return
         self._started.add(i)
@@ -243,6 +247,8 @@ class FlatAdam(torch.optim.Optimizer):
                 self._comm_stream = torch.cuda.Stream()
             cs = self._comm_stream
             cs.wait_stream(cur)
+            for e_ in after:
+                cs.wait_event(e_)
             for s_ in (Fh.helper_streams(dev) if helpers else [Fh.wgrad_stream(dev)]):
                 if s_ is not None:
                     cs.wait_stream(s_)
@@ -256,6 +262,8 @@ class FlatAdam(torch.optim.Optimizer):
         issue = Fh.wgrad_stream(dev) or cur
         if issue != cur:
             issue.wait_stream(cur)
+        for e_ in after:
+            issue.wait_event(e_)
         for s_ in (Fh.helper_streams(dev) if helpers else []):
             if s_ != issue and s_ != cur:
                 issue.wait_stream(s_)

@@ -457,6 +457,7 @@ class RDFCGAN:
         # (under data parallelism G_A2B's backward starts its own gradient buckets: markers at the decoder / encoder boundary and
         #  in front of the deep encoder stages of both branches, init_optimizer)
         self._G_marks = dict(dec=0, deep=0)
+        self._G_mark_events = {}
         self.G_A2B.__dict__['bwd_marks'] = self._on_G_mark if (dp_active() and self.is_train and not getattr(self, '_graph_mode', False)) else None
         try:
             with layers.bn_groups((1, 2)):
@@ -480,8 +481,13 @@ class RDFCGAN:
         point, the bucket whose gradients are final by then starts its all-reduce (the weight-gradient stream, from which it is
         issued, has the layers' weight gradients in front of it; the other branch's stream is waited for: helpers=True)"""
         self._G_marks[name] += 1
+        # every marker leaves an event on the stream it fired on: the bucket follows BOTH branches' streams, not only the one whose
+        # marker happens to fire last (the gradients autograd accumulates behind the other branch's last node are on that stream)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._G_mark_events.setdefault(name, []).append(ev)
         if self._G_marks[name] == 2 and name in self._G_bucket:
-            self.optimizer_G.all_reduce_bucket_async(self._G_bucket[name])
+            self.optimizer_G.all_reduce_bucket_async(self._G_bucket[name], after=self._G_mark_events.pop(name))
 
     def _start_G_B2A_bucket(self):
         if self.is_train and not getattr(self, '_graph_mode', False):

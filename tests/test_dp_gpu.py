@@ -24,6 +24,27 @@ def test_two_ranks_stay_identical(full):
         assert "optimizers ['D', 'G', 'Nor', 'label']" in out, out[-3000:]
 
 
+@pytest.mark.parametrize('wgrad_stream', ['1', '0'], ids=['default_streams', 'no_wgrad_stream'])
+def test_in_backward_buckets_follow_both_branches_streams(wgrad_stream):
+    """round-4 advice: G_A2B's decoder-side / deep-encoder buckets are started from inside its backward by the LAST of two markers (one per
+    branch, each on its branch's stream: the RGB branch's on the main stream first, the depth branch's second).  The gradients autograd
+    accumulates behind the RGB branch's last decoder-side node (fuse_layer1's style weights) are on the main stream, so the collective
+    must follow it too: every marker records an event and the issue stream waits for all of them (rdfc_gan._on_G_mark,
+    FlatAdam.all_reduce_bucket_async(after=...)).  tools/dp_smoke.py with DP_SMOKE_DELAY_MAIN puts a 20 ms spin kernel between the
+    event the depth branch waits for and those accumulations; replicas must stay bit-identical.  Measured on MI355X (round 5,
+    profiles/r05_experiments.txt): with RDFC_WGRAD_STREAM=0 and the events dropped (DP_SMOKE_NO_MARK_EVENTS=1) the replicas differ by
+    8.2e-3 after two steps; with the weight-gradient stream on, the next layer's weight-gradient fork happens to order the issue
+    stream behind the main one, so only the second configuration depends on the events."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_SMOKE_FULL='0', DP_SMOKE_DELAY_MAIN='1',
+               RDFC_WGRAD_STREAM=wgrad_stream)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29524' if wgrad_stream == '1' else '29525', os.path.join(ROOT, 'tools', 'dp_smoke.py')]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert 'max parameter difference between replicas after 2 steps = 0.000e+00' in out, out[-3000:]
+
+
 def test_two_ranks_stay_identical_under_graph_replay():
     """HIP-graph mode under data parallelism: a replay runs no Python, so the buckets' per-step state has to be reset outside
     zero_grad() (FlatAdam.begin_step) -- otherwise every bucket counts as started from the capture on, no collective is issued

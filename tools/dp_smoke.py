@@ -39,11 +39,45 @@ if full:
     kw = dict(use_label_net=True, normal_net=NNET(64, 80, encoder=StandInEncoder()), out_height=64, out_width=80)
 
 
+# DP_SMOKE_DELAY_MAIN=1 (round-4 advice): G_A2B's decoder-side bucket is started by whichever branch's backward marker fires last --
+# from the depth branch's stream -- while the RGB branch's last decoder-side node (fuse_layer1's W-AdaIN) hands its weight gradients
+# to autograd, which accumulates them on the MAIN stream after the event the depth branch waits for.  A gradient hook on the fusion
+# layers' parameters puts a long spin kernel exactly there (between that event and the accumulation): without the event that the RGB
+# marker records on its own stream the collective reads the range before the add has landed, the add then lands on the reduced
+# values, and the replicas drift apart (DP_SMOKE_NO_MARK_EVENTS=1 drops the events: the run must then FAIL the comparison below).
+def delay_fusion_grads(m):
+    if os.environ.get('DP_SMOKE_DELAY_MAIN') != '1':
+        return
+    def slow(g):
+        torch.cuda._sleep(int(4e7))          # ~20 ms
+        return g
+    n = 0
+    for name, p_ in m.G_A2B.named_parameters():
+        if 'fuse_layer' in name:
+            p_.register_hook(slow)
+            n += 1
+    if rank == 0 and os.environ.get('DP_SMOKE_TRACE') == '1':          # which stream each marker fires on, in host order
+        print(f'dp_smoke: {n} fusion-layer parameters delayed; main stream {torch.cuda.current_stream(dev).cuda_stream:#x}')
+        orig = m._on_G_mark
+
+        def traced(name):
+            print(f'dp_smoke: marker {name} fires on stream {torch.cuda.current_stream(dev).cuda_stream:#x}', flush=True)
+            return orig(name)
+        m._on_G_mark = traced
+
+
+if os.environ.get('DP_SMOKE_NO_MARK_EVENTS') == '1':
+    from rdfc_gan_amd import optim as _optim
+    _orig_ar = _optim.FlatAdam.all_reduce_bucket_async
+    _optim.FlatAdam.all_reduce_bucket_async = lambda self, i, helpers=True, after=(): _orig_ar(self, i, helpers)
+
+
 def two_steps(distributed):
     torch.manual_seed(100 + rank)
     random.seed(rank); np.random.seed(rank)
     m = RDFCGAN(dev, distributed, bench.model_cfg(False), is_train=True, **kw)
     m.train()
+    delay_fusion_grads(m)
     trace = []
     for it in range(nsteps):
         if graph and it == 1:

@@ -23,5 +23,5 @@ for si, s in enumerate(starts):
     def cnt(pat): return sum(bool(re.search(pat, x)) for x in best)
     ins = [x for x in best if re.match(r'^\s+[a-z]', x) and not x.strip().startswith(('.', ';'))]
     print(name[:100])
-    print(f'   loop: {len(ins)} instr | mfma {cnt("v_mfma")} | ds_read {cnt("ds_read")} | glds {cnt("global_load_lds")} | valu {sum(bool(re.match(chr(92)+"s+v_", x)) and "v_mfma" not in x for x in best)} '
+    print(f'   loop: {len(ins)} instr | mfma {cnt("v_mfma")} | ds_read {cnt("ds_read")} | glds {cnt("global_load_lds|buffer_load.* lds")} | valu {sum(bool(re.match(chr(92)+"s+v_", x)) and "v_mfma" not in x for x in best)} '
           f'| salu {sum(bool(re.match(chr(92)+"s+s_", x)) for x in best)} | waitcnt {cnt("s_waitcnt")} | barrier {cnt("s_barrier")} | scratch {cnt("scratch_")} | accvgpr {cnt("v_accvgpr")} || whole kernel: {tot}')
