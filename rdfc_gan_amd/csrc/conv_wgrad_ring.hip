@@ -36,6 +36,7 @@ struct RParams {
     int tiles, tiles_ci, xcd_group;
     int reflect;
     int xoff;                    // input column of flat column 0 of plane 0: -pad (stride 1), -2 (stride 2, pad 1: column 2 (j - 1))
+    unsigned x_bytes, y_bytes;   // extents of the two maps (wgrad_ring2_kernel's buffer descriptors; < 2^31)
 };
 
 constexpr int SEG = 32, NT = 256;
@@ -256,6 +257,282 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
             }
 }
 
+// ---- round 5: the same walk with (almost) no vector or scalar address arithmetic in the loop -------------------------------------------
+// The loop above spends 94 vector and 138 scalar instructions on a k-step of 24 MFMAs (hipcc -S, tools/isa_loop.py): per-piece source
+// pointers with a zero-page select per lane, the swizzled address of every transposing read recomputed from the step's ring position, the
+// cursors' wrap logic as branches.  Two waves per SIMD cannot issue that beside 2 x 24 MFMAs: the kernel is issue-bound at 0.24 of the
+// matrix peak.  wgrad_ring2_kernel keeps the geometry (flat pixel walk, dY slots, X' ring, slab output: same bits) and changes how it
+// is addressed:
+//   * LDS-DMA through buffer descriptors (conv_glds.hip: bdma16): a piece lies in ONE row of its map, so its descriptor is that row --
+//     base = the row's first byte (dY: the piece's first column), num_records = the row's extent -- and every lane's offset is a
+//     CONSTANT (dY) or a constant plus one wave-uniform column term (X': one v_add; a column left of the row wraps to a huge offset).
+//     Lanes beyond the row, rows outside the image and blocks beyond the slice are out of range and arrive as zeros: no zero page, no
+//     per-lane compare / select, no 64-bit vector address.
+//   * the k loop is unrolled over the X' ring (8 | 4 steps), so slot and block of every read are immediates and each transposing read's
+//     per-lane address is one of 20 registers computed once (the reads of the ring's last block that run over its end have their own).
+//   * PIPE (stride 1): the fragments of step s + 1 are read during the MFMAs of step s -- B fragments in place, right after the four
+//     MFMAs that end their use, A fragments into the other half of a register pair (the unrolled loop makes its parity static) -- so
+//     the reads are off the critical path of a step as in conv3x3_glds.
+constexpr unsigned DEAD_OFF = 0x80000000u;
+__device__ inline void bdma16(unsigned voff, u32x4 rsrc, unsigned lds_base) {
+#ifndef RDFC_WRING_KEEP_M0       // m0 declared clobbered (the compiler uses it for nothing else in this kernel; clang warns that m0 is reserved): two
+    // scalar instructions fewer per DMA in a loop that is bound by scalar issue
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_base) : "memory", "m0");
+#else
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_base)
+                 : "memory");
+#endif
+}
+__device__ inline u32x4 row_rsrc(const void *base, unsigned bytes) {          // base and bytes wave-uniform
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ inline bf16x8 tr_pair(const unsigned char *a0, int half_off) {     // one MFMA fragment = two transposing reads, `half_off` bytes apart
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a0 + half_off));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    const u32x4 r = {l2[0], l2[1], h2[0], h2[1]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ inline bf16x8 tr_pair2(const unsigned char *a0, const unsigned char *a1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a1);
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    const u32x4 r = {l2[0], l2[1], h2[0], h2[1]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int TCO, int DT, int S = 1, int K = 3, bool REFL = false>
+__global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring2_kernel(RParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
+                                                                           float *__restrict__ slab) {
+    constexpr int TCI = 64, NPL = S;
+    constexpr bool PIPE = S == 1;
+    constexpr int LOOK = S == 1 ? 3 : 2, RY = 4, XR = S == 1 ? 8 : 4, U = XR;      // U: steps per trip of the unrolled loop (a multiple of RY)
+    constexpr int YROW = TCO * 2, XROW = TCI * 2;
+    constexpr int YB = SEG * YROW, XBLK = SEG * XROW;
+    constexpr int NY = YB / (NT * 16), NX = XBLK / (NT * 16);
+    static_assert(NX == 1, "one X' piece per wave, plane and step");
+    constexpr int PER_STEP = NY + NPL * NX;
+    constexpr int CPY = TCO / 8, CPX = TCI / 8;
+    constexpr int OFF_X = RY * YB, XRING = XR * XBLK;
+    constexpr int WCO = TCO / 64, WCI = 4 / WCO;
+    constexpr int WTCO = TCO / WCO, WTCI = TCI / WCI;
+    constexpr int MT = WTCO / 16, NTF = WTCI / 16;
+    constexpr int NSH = S == 1 ? K : K / 2 + 1;                 // distinct shifts within a plane: 3 | 4 (stride 1), 2 | 3 (stride 2)
+    static_assert(XR >= LOOK + 2 && U % RY == 0, "ring sizes");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.y, slice = blockIdx.x;
+    if (p.xcd_group) {
+        const int k = blockIdx.x >> 3;
+        tile = k % p.tiles;
+        slice = (k / p.tiles) * 8 + (blockIdx.x & 7);
+    }
+    if (slice >= p.nslices) return;
+    const int ky = tile % K;
+    tile /= K;
+    const int ci0 = (tile % p.tiles_ci) * TCI, co0 = (tile / p.tiles_ci) * TCO;
+    const int seg0 = slice * p.steps_per_slice;
+    int nseg = p.total_steps - seg0;
+    if (nseg > p.steps_per_slice) nseg = p.steps_per_slice;
+
+    // ---- DMA sources: ONE descriptor per map; per lane a 32-bit byte offset that advances by a wave-uniform increment per step ---------
+    // Wave w stages positions 8 w ... 8 w + 7 of every 32-position block, of dY (one or two instructions: 64 / CPY positions each) and
+    // of X' (one instruction per plane).  L is a multiple of 8, so these eight positions lie in ONE row of the padded walk: where the
+    // wave is -- column j of its first position, output row yy, image img -- is ONE wave-uniform cursor, advanced with scalar adds and
+    // selects only (no multiply, no 64-bit arithmetic, no branch in the loop).  A lane adds the step's increment to its offsets and
+    // is switched to DEAD (beyond num_records: zeros) while its column is outside the row or the row outside the map.  dY's block is
+    // the one the cursor stood on a step earlier (X' is staged a block ahead): its column / image are the saved previous values.
+    constexpr int PY = 64 / CPY;                                 // positions per dY instruction (4 | 8)
+    const int ylp = lane / CPY, xlp = lane / CPX;
+    const u32x4 ysrc = row_rsrc(dy, (unsigned)p.y_bytes), xsrc = row_rsrc(x, (unsigned)p.x_bytes);
+    int cj, cy, ci;                                              // the cursor: position 8 w of the next X' block
+    {
+        const long f = (long)seg0 * SEG + 8 * wave;
+        const int row = (int)(f / p.L);
+        cj = (int)(f - (long)row * p.L);
+        ci = row / p.Ho;
+        cy = row - ci * p.Ho;
+    }
+    unsigned yoff[NY], xoffv[NPL];
+    int ycol[NY];                                                // the lane's position inside the wave's eight
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+        const int pos = 8 * wave + PY * k + ylp, slot = lane % CPY;
+        ycol[k] = PY * k + ylp;
+        yoff[k] = 2u * (unsigned)(((long)(ci * p.Ho + cy) * p.Wo + cj + ycol[k]) * p.ldy + co0 + ((slot ^ (2 * pair_swz<YROW>(pos))) << 3));
+        if (co0 + (slot << 3) >= p.Co) yoff[k] = DEAD_OFF;       // (a 128-co tile's second half beyond Co: stays beyond num_records whatever is added)
+    }
+    const int xslot = lane % CPX, xpos = 8 * wave + xlp;
+    const int xchunk = ci0 + ((xslot ^ (2 * pair_swz<XROW>(xpos))) << 3);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)                             // (may be "negative" -- a row above the image, a column left of it -- while the lane is DEAD)
+        xoffv[pl] = 2u * (unsigned)(((long)(ci * p.Hi + S * cy + ky - p.pad) * p.Wi + S * (cj + xlp) + p.xoff + pl) * p.ldx + xchunk);
+    const unsigned ystep = 2u * (unsigned)(SEG * p.ldy), ywrap = 2u * (unsigned)((p.Wo - p.L) * p.ldy);       // + ywrap (mod 2^32) when the column wraps into the next row
+    const unsigned xstep = 2u * (unsigned)(SEG * S * p.ldx), xwrap = 2u * (unsigned)(S * (p.Wi - p.L) * p.ldx),
+                   ximg = 2u * (unsigned)((p.Hi - S * p.Ho) * p.Wi * p.ldx);
+    int pj = cj, pi = ci;                                        // where the cursor stood a block earlier (the next dY block)
+    unsigned yinc = 0;                                           // what takes yoff from that block to the one after it
+    auto advance = [&]() {                                       // the cursor moves on by one block; -> the X' offsets follow, dY's increment is kept for later
+        pj = cj;
+        pi = ci;
+        cj += SEG;
+        const bool w = cj >= p.L;                                // (SEG <= L: at most one wrap per step)
+        cj -= w ? p.L : 0;
+        cy += w ? 1 : 0;
+        const bool wi_ = cy == p.Ho;                             // (cy reaches Ho only by the increment above)
+        cy = wi_ ? 0 : cy;
+        ci += wi_ ? 1 : 0;
+        yinc = ystep + (w ? ywrap : 0u);
+        const unsigned xinc = xstep + (w ? xwrap : 0u) + (wi_ ? ximg : 0u);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) xoffv[pl] += xinc;
+    };
+    auto issue_x = [&](int bx, int blk_) {                       // X' block `bx` of the slice (the cursor's block, every plane) -> ring block blk_; the cursor moves on
+        int yin = S * cy + ky - p.pad;
+        if (REFL) yin = yin < 0 ? -yin : (yin >= p.Hi ? 2 * p.Hi - 2 - yin : yin);
+        const bool rowok = bx <= nseg && ci < p.N && (unsigned)yin < (unsigned)p.Hi;       // (one block beyond the last dY block: its first positions are read)
+        const int xcol = S * cj + p.xoff;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            int xin = xcol + S * xlp + pl;                       // the lane's input column
+            unsigned v = xoffv[pl];
+            if (REFL) {                                          // mirrored halo: the source follows the reflection (its row part is wave-uniform)
+                xin = xin < 0 ? -xin : (xin >= p.Wi ? 2 * p.Wi - 2 - xin : xin);
+                v = 2u * (unsigned)(((ci * p.Hi + yin) * p.Wi + xin) * p.ldx + xchunk);
+            }
+            bdma16((rowok && (unsigned)xin < (unsigned)p.Wi) ? v : DEAD_OFF, xsrc, lds0 + OFF_X + pl * XRING + blk_ * XBLK + wave * 1024);
+        }
+        advance();
+    };
+    auto issue_y = [&](int by, int slot_) {                      // dY block `by` (where the cursor stood before its last move) -> slot slot_
+        const bool rowok = by < nseg && pi < p.N;
+        const int left = p.Wo - pj;                              // lanes at positions below it are inside the row
+#pragma unroll
+        for (int k = 0; k < NY; ++k) {
+            bdma16((rowok && ycol[k] < left) ? yoff[k] : DEAD_OFF, ysrc, lds0 + slot_ * YB + (8 * wave + PY * k) * YROW);
+            yoff[k] += yinc;
+        }
+    };
+
+    // ---- per-lane LDS offsets of the transposing reads (computed once) ----------------------------------------------------------------
+    const int wr = wave / WCI, wc = wave % WCI;
+    const int g_ = lane >> 4, li = lane & 15, q_ = li >> 2, pp = li & 3;
+    unsigned aoff[MT];                                           // dY slot: rows 8 g + q (second half: + 4 rows, same swizzle)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r0 = 8 * g_ + q_, cp = (wr * WTCO + 16 * i) >> 4;
+        aoff[i] = (unsigned)(r0 * YROW + ((cp ^ pair_swz<YROW>(r0)) << 5) + pp * 8);
+    }
+    unsigned boff[NSH][NTF][2], bwrap[NSH][NTF];                 // X' block: rows 8 g + q + shift (+ 4); bwrap: the second half in the ring's last block
+#pragma unroll
+    for (int sh = 0; sh < NSH; ++sh)
+#pragma unroll
+        for (int j = 0; j < NTF; ++j) {
+            const int cp = (wc * WTCI + 16 * j) >> 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 8 * g_ + q_ + sh + 4 * h;
+                boff[sh][j][h] = (unsigned)(r * XROW + ((cp ^ pair_swz<XROW>(r)) << 5) + pp * 8);
+            }
+            const int r1 = 8 * g_ + q_ + sh + 4;
+            bwrap[sh][j] = boff[sh][j][1] - (r1 >= SEG ? (unsigned)XRING : 0u);
+        }
+
+    f32x4 acc[K][MT][NTF];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTF; ++j) acc[t][i][j] = f32x4{0, 0, 0, 0};
+
+    auto read_a = [&](int slot_, int i) -> bf16x8 { return tr_pair(smem + slot_ * YB + aoff[i], 4 * YROW); };
+    auto read_b = [&](int blk_, int t, int j) -> bf16x8 {       // tap t of the block at ring position blk_ (compile-time after unrolling)
+        const int sh = tap_shift<S>(t);
+        const unsigned char *Xp = smem + OFF_X + tap_plane<S>(t) * XRING + blk_ * XBLK;
+        return tr_pair2(Xp + boff[sh][j][0], Xp + ((blk_ == XR - 1 && sh > 0) ? bwrap[sh][j] : boff[sh][j][1]));
+    };
+
+    if (nseg > 0) {
+        issue_x(0, 0);                                           // (issue_y(b) follows issue_x(b): it stages the block the cursor has just left)
+#pragma unroll
+        for (int h = 0; h < LOOK; ++h) {
+            issue_y(h, h % RY);
+            issue_x(h + 1, (h + 1) % XR);
+        }
+        bf16x8 a[2][MT], b[K][NTF];
+        if constexpr (PIPE) {
+            wait_vm<(LOOK - 1) * PER_STEP>();                   // dY(0), X'(0), X'(1)
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[0][i] = read_a(0, i);
+#pragma unroll
+            for (int t = 0; t < K; ++t)
+#pragma unroll
+                for (int j = 0; j < NTF; ++j) b[t][j] = read_b(0, t, j);
+        }
+#define RDFC_WR_STEP(UU)                                                                                                   \
+        if (s0 + UU < nseg) {                                                                                              \
+            constexpr int CUR = UU & 1;                                                                                    \
+            if constexpr (PIPE) wait_vm_and_reads<(LOOK - 2) * PER_STEP>();       /* dY(s + 1), X'(s + 1), X'(s + 2) have landed */ \
+            else wait_vm_and_reads<(LOOK - 1) * PER_STEP>();                      /* dY(s), X'(s), X'(s + 1) */          \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+            issue_y(s0 + UU + LOOK, (UU + LOOK) % RY);                                                                     \
+            issue_x(s0 + UU + LOOK + 1, (UU + LOOK + 1) % XR);                                                             \
+            if constexpr (!PIPE) {                                                                                         \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i) a[0][i] = read_a(UU % RY, i);                             \
+                _Pragma("unroll") for (int t = 0; t < K; ++t) {                                                            \
+                    _Pragma("unroll") for (int j = 0; j < NTF; ++j) b[t][j] = read_b(UU % XR, t, j);                     \
+                    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                         \
+                        _Pragma("unroll") for (int j = 0; j < NTF; ++j) acc[t][i][j] = mma16<DT>(a[0][i], b[t][j], acc[t][i][j]); \
+                }                                                                                                          \
+            } else {                                                                                                       \
+                _Pragma("unroll") for (int t = 0; t < K; ++t)                                                              \
+                    _Pragma("unroll") for (int j = 0; j < NTF; ++j) {                                                      \
+                        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[t][i][j] = mma16<DT>(a[CUR][i], b[t][j], acc[t][i][j]); \
+                        __builtin_amdgcn_sched_barrier(0);                                                                 \
+                        b[t][j] = read_b((UU + 1) % XR, t, j);                   /* next step's fragment, in place */     \
+                        _Pragma("unroll") for (int i = 0; i < MT; ++i)          /* ... and the next step's A fragments, spread over the groups */ \
+                            if (i % (K * NTF) == t * NTF + j) a[CUR ^ 1][i] = read_a((UU + 1) % RY, i);                    \
+                        __builtin_amdgcn_sched_barrier(0);                                                                 \
+                    }                                                                                                      \
+            }                                                                                                              \
+        }
+        for (int s0 = 0; s0 < nseg; s0 += U) {
+            RDFC_WR_STEP(0) RDFC_WR_STEP(1) RDFC_WR_STEP(2) RDFC_WR_STEP(3)
+            if constexpr (U == 8) { RDFC_WR_STEP(4) RDFC_WR_STEP(5) RDFC_WR_STEP(6) RDFC_WR_STEP(7) }
+        }
+#undef RDFC_WR_STEP
+        wait_vm<0>();
+    }
+
+    float *out = slab + (size_t)slice * p.Co * (K * K) * p.Ci;
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTF; ++j) {
+                const int ci = ci0 + wc * WTCI + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wr * WTCO + 16 * i + 4 * (lane >> 4) + r;
+                    if (co < p.Co && ci < p.Ci) out[((size_t)co * (K * K) + ky * K + t) * p.Ci + ci] = acc[t][i][j][r];
+                }
+            }
+}
+
 // dW[i] += slab[0][i] + slab[1][i] + ... in a FIXED order, whatever order the workgroups finished in.  A workgroup owns 16
 // consecutive f32x4 columns; its 256 threads are 16 slice groups x 16 columns: group g adds slices g, g + 16, ... (in that order,
 // four loads in flight), then the 16 group sums are added in group order through LDS.  (One thread per column summing every slice
@@ -359,10 +636,16 @@ float *slab_for(hipStream_t st, size_t bytes, bool reserve_only = false) {
 template <int TCO, int DT, int S, int K>
 int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
     constexpr int RY = (S == 1 ? 3 : 2) + 1, XR = S == 1 ? 8 : 4;
-    constexpr int SMEM = RY * (SEG * TCO * 2) + S * XR * (SEG * 64 * 2);
+    constexpr int SMEM1 = RY * (SEG * TCO * 2) + S * XR * (SEG * 64 * 2), SMEM2 = 4 * (SEG * TCO * 2) + S * XR * (SEG * 64 * 2);
+    const char *env2 = getenv("RDFC_WGRAD_RING2");              // (read per call, like RDFC_WGRAD_RING: tools/wgrad_ring_bench.py switches it between launches)
+    const bool ring2 = (env2 == nullptr || atoi(env2) != 0) && p.x_bytes != 0 && p.y_bytes != 0;
+    const int SMEM = ring2 ? SMEM2 : SMEM1;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wgrad_ring_kernel<TCO, DT, S, K>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)wgrad_ring_kernel<TCO, DT, S, K>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM1) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)wgrad_ring2_kernel<TCO, DT, S, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2) != hipSuccess) return 0;
+        if constexpr (S == 1 && K == 3)
+            if (hipFuncSetAttribute((const void *)wgrad_ring2_kernel<TCO, DT, S, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2) != hipSuccess) return 0;
         attr_set = true;
     }
     p.tiles_ci = cdiv(p.Ci, 64);
@@ -387,8 +670,17 @@ int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *ze
     static const bool xcd_group = !(getenv("RDFC_WGRAD_XCD") && atoi(getenv("RDFC_WGRAD_XCD")) == 0);
     p.xcd_group = xcd_group && tiles <= 4 && slices >= 8;
     const dim3 grid = p.xcd_group ? dim3(cdiv(slices, 8) * 8 * tiles, 1) : dim3(slices, tiles);
-    rdfc_note_kernel("wgrad_ring_kernel<%d, %d, %d, %d>", TCO, DT, S, K);
-    hipLaunchKernelGGL((wgrad_ring_kernel<TCO, DT, S, K>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab, zero);
+    if (ring2) {
+        rdfc_note_kernel("wgrad_ring2_kernel<%d, %d, %d, %d, %s>", TCO, DT, S, K, p.reflect ? "true" : "false");
+        if constexpr (S == 1 && K == 3) {
+            if (p.reflect) hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, true>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
+            else hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, false>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
+        } else
+            hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, false>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
+    } else {
+        rdfc_note_kernel("wgrad_ring_kernel<%d, %d, %d, %d>", TCO, DT, S, K);
+        hipLaunchKernelGGL((wgrad_ring_kernel<TCO, DT, S, K>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab, zero);
+    }
     const size_t n4 = dw_bytes / 16;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float *)slab, dw, n4, slices);
     return 1;
@@ -451,7 +743,10 @@ int rdfc_try_wgrad_ring(const rdfc_conv_desc *d, const void *x, const void *dy, 
     const int S = d->sh, K = d->KH;
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
-    RParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, L, d->N * d->Ho, 0, 0, 0, 0, 0, 0, reflect, S == 1 ? -d->ph : -2};
+    RParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, L, d->N * d->Ho, 0, 0, 0, 0, 0, 0, reflect, S == 1 ? -d->ph : -2, 0, 0};
+    const size_t xb = 2 * (size_t)d->N * d->Hi * d->Wi * d->ldx, yb = 2 * (size_t)d->N * d->Ho * d->Wo * d->ldy;
+    p.x_bytes = xb < 0x7ffffff0u ? (unsigned)xb : 0;            // (0: a map too large for 32-bit offsets -> the round-3 kernel takes the launch)
+    p.y_bytes = yb < 0x7ffffff0u ? (unsigned)yb : 0;
     p.total_steps = cdiv((long)p.nrows * p.L, SEG);
     if (S == 1 && K == 3) return launch_sk<1, 3>(d, p, x, dy, dw, zero, st);
     if (S == 2 && K == 3) return launch_sk<2, 3>(d, p, x, dy, dw, zero, st);

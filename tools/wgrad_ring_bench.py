@@ -1,4 +1,6 @@
-"""A/B of the ring weight-gradient kernel (conv_wgrad_ring.hip, RDFC_WGRAD_RING=1) against conv_wgrad_glds.hip (=0) on the step's
+"""MODE=ring2: A/B of round 5's wgrad_ring2_kernel (RDFC_WGRAD_RING2=1) against round 3's wgrad_ring_kernel (=0), same shapes, same
+checks (the two must agree bit for bit: same walk, same order of the f32 adds).  Default:
+A/B of the ring weight-gradient kernel (conv_wgrad_ring.hip, RDFC_WGRAD_RING=1) against conv_wgrad_glds.hip (=0) on the step's
 3x3 / stride-1 layers: interleaved rounds in ONE process (the switch is read per launch), random operands; the ring kernel's result
 must repeat bit for bit (fixed-order slab reduction) and agree with the other kernel to f32 summation-order accuracy.
 python tools/wgrad_ring_bench.py [rounds] [iters]"""
@@ -20,6 +22,11 @@ SHAPES = [  # N, H, W, Ci, Co, pad, reflect, kernel, stride
     (16, 28, 38, 256, 512, 1, 0, 4, 1), (3, 31, 61, 64, 128, 1, 0, 4, 2), (2, 33, 59, 128, 64, 1, 0, 3, 2)]
 if len(sys.argv) > 3:
     SHAPES = [sh for sh in SHAPES if (sh[7], sh[8]) == tuple(int(v) for v in sys.argv[3].split(','))]
+RING2 = os.environ.get('MODE') == 'ring2'
+VAR = 'RDFC_WGRAD_RING2' if RING2 else 'RDFC_WGRAD_RING'
+MODES = ('0', '1') if RING2 else ('0', '3')
+if RING2:
+    os.environ['RDFC_WGRAD_RING'] = '3'
 dtn = os.environ.get('PP_DTYPE', 'bf16')
 dt = dict(bf16=torch.bfloat16, f16=torch.float16)[dtn]
 
@@ -42,8 +49,8 @@ for (N, H, W, Ci, Co, pad, reflect, ksz, st) in SHAPES:
     gy = torch.randn(N, Ho, Wo, Co, device='cuda', generator=g).to(dt)
     d = hip.conv_desc(x.shape, Co, ksz, st, pad, ldx=Ci, ldy=Co, dtype=hip.dt(x))
     outs, kern = {}, {}
-    for m in ('0', '3'):
-        os.environ['RDFC_WGRAD_RING'] = m
+    for m in MODES:
+        os.environ[VAR] = m
         bad = 0
         for rep in range(4):
             dw = hip.conv_wgrad(d, x, gy, reflect=bool(reflect))
@@ -52,20 +59,20 @@ for (N, H, W, Ci, Co, pad, reflect, ksz, st) in SHAPES:
                 outs[m] = dw
             elif not torch.equal(outs[m], dw):
                 bad += 1
-        print(f'  RDFC_WGRAD_RING={m} ({kern[m]}): {bad} of 3 repeats differ from the first run')
-    a, b = outs['0'].double(), outs['3'].double()
+        print(f'  {VAR}={m} ({kern[m]}): {bad} of 3 repeats differ from the first run')
+    a, b = outs[MODES[0]].double(), outs[MODES[1]].double()
     rel = float((a - b).abs().max() / a.abs().max())
-    print(f'wgrad N{N} {H}x{W} {Ci}->{Co} k{ksz}s{st} pad{pad} reflect{reflect} [{dtn}]: max|ring - glds| / max|glds| = {rel:.2e} nan={int(torch.isnan(b).sum())}', flush=True)
+    print(f'wgrad N{N} {H}x{W} {Ci}->{Co} k{ksz}s{st} pad{pad} reflect{reflect} [{dtn}]: max|{MODES[1]} - {MODES[0]}| / max = {rel:.2e} nan={int(torch.isnan(b).sum())} bit-equal={torch.equal(outs[MODES[0]], outs[MODES[1]])}', flush=True)
     fl = 2.0 * N * Ho * Wo * Co * Ci * ksz * ksz
     buf = torch.zeros(Co, ksz * ksz, Ci, device='cuda')
-    res = {m: [] for m in ('0', '3')}
+    res = {m: [] for m in MODES}
     for r in range(rounds):
-        for m in ('0', '3'):
-            os.environ['RDFC_WGRAD_RING'] = m
+        for m in MODES:
+            os.environ[VAR] = m
             res[m].append(timed(lambda: hip.conv_wgrad(d, x, gy, into=buf, reflect=bool(reflect))))
     line = '  '
-    for m in ('0', '3'):
+    for m in MODES:
         v = sorted(res[m])
         med = v[len(v) // 2]
-        line += f'  RING={m}: median {med:7.1f} us (min {v[0]:7.1f}) {fl / med / 1e6:6.0f} TFLOP/s'
+        line += f'  {VAR[5:]}={m}: median {med:7.1f} us (min {v[0]:7.1f}) {fl / med / 1e6:6.0f} TFLOP/s'
     print(line, flush=True)
