@@ -213,10 +213,11 @@ def main():
     ap.add_argument('--full-objective', action='store_true', help="--label-net plus G_normal (decoder on HIP behind the tests' stock-PyTorch "
                     'stand-in encoder): every term of upstream loss_G, six networks, four optimizers (not the headline workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=0, help='timed steps of the CPU baseline (BASELINE.md section 4: 3, ~6 minutes of host time); '
-                    'default 0 = as many as fit a 150 s budget, at least one -- the line says which')
-    ap.add_argument('--no-as-worded', action='store_true', help='skip the extra (untimed by the contract) run of the same workload in bf16 '
-                    '(BASELINE configs[1] as worded) that the default f16 run appends as `as_worded_bf16`')
+    ap.add_argument('--cpu-steps', type=int, default=3, help='timed steps of the CPU baseline (default 3 = BASELINE.md section 4: 1 warm-up + 3 timed steps, '
+                    '~6 minutes of host time on the GPU box); 0 = as many as fit a 150 s budget, at least one -- the line says which')
+    ap.add_argument('--no-as-worded', action='store_true', help='skip the extra legs (untimed by the contract) that the default f16 run appends: the same '
+                    'workload in bf16 (BASELINE configs[1] as worded: `as_worded_bf16`, with its own roofline block) and `configs` = configs[2] (NLSPN) '
+                    "and configs[4]'s per-GPU shape (480x640, batch 4, f16)")
     ap.add_argument('--rccl-self-test', action='store_true', help='N = 1 only: initialise a one-rank RCCL process group and send the step '
                     'through every collective of the data-parallel path (bucketed all-reduces, loss all-reduces); adds the comm block')
     ap.add_argument('--no-sync-losses', action='store_true', help='do not read the losses back every step (the host then runs ahead '
@@ -224,7 +225,6 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the step into HIP graphs and replay them (single stream; on ROCm 7.2 the '
                     'replay costs about as much per node as an eager launch, so the multi-stream eager step is faster)')
-    ap.add_argument('--graph-multi-stream', action='store_true', help='with --graph: capture the helper streams fork/join too (experimental: segfaults in hipStreamEndCapture on ROCm 7.2)')
     ap.add_argument('--event-every', type=int, default=20, help='per-kernel HIP events on every n-th timed step, the first one included (eager mode; such a step takes ~8 % longer: ~1 000 event pairs and the normalisation layers as one call per kernel)')
     ap.add_argument('--by-shape', default=None, help='write a per-conv-shape time / TFLOP/s table (debug aid) to this file')
     a = ap.parse_args()
@@ -242,9 +242,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     from rdfc_gan_amd import functional as Fh
-    if os.environ.get('RDFC_RESERVE_STREAMS', '1') != '0':
-        # the compute streams take their hardware queues before RCCL's stream exists (three under data parallelism, four without)
-        Fh.reserve_streams(dev, with_net=not (world > 1 or a.rccl_self_test))
+    # the compute streams take their hardware queues before RCCL's stream exists (three under data parallelism, four without)
+    Fh.reserve_streams(dev, with_net=not (world > 1 or a.rccl_self_test))
     if world > 1 or a.rccl_self_test:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if a.rccl_self_test:          # one rank, every collective of the step through RCCL all the same (rdfc_gan_amd/optim.py dp_active)
@@ -285,7 +284,7 @@ def main():
     graphed = a.graph
     for i in range(a.warmup):
         if graphed and i == 1:
-            model.enable_graph(True, multi_stream=a.graph_multi_stream)
+            model.enable_graph(True)
         # the last warm-up step carries kernel events like every --event-every-th timed step: the runtime grows its event /
         # signal pools on first use, which would otherwise land in the first timed step (seen as rare 40 ms outliers)
         warm_ev = not graphed and not a.no_kernel_events and i == a.warmup - 1
@@ -294,7 +293,7 @@ def main():
         one_step(i)
         hip.PROFILE = hip.PROFILE_HBM = None
     if graphed and a.warmup < 2:
-        model.enable_graph(True, multi_stream=a.graph_multi_stream)
+        model.enable_graph(True)
         one_step(a.warmup)                 # capture + first replay (untimed)
     torch.cuda.synchronize()
     if world > 1:
@@ -400,7 +399,7 @@ def main():
                                step_gflop_per_pair=round(gflop_pair, 1)),
                    loss_readback='every step (reference API)' if not a.no_sync_losses else 'none in the timed region',
                    host_enqueue_ms_per_step=round(1e3 * host_one, 3),
-                   unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 4 streams (main | depth branch, then the discriminators\' step | weight gradients | D_B\'s G-loss pass), batched calls' if not graphed else ('hip graphs (3 per step), ' + ('fork/join over the helper streams captured' if a.graph_multi_stream else 'one stream')),
+                   unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 4 streams (main | depth branch, then the discriminators\' step | weight gradients | D_B\'s G-loss pass), batched calls' if not graphed else 'hip graphs (3 per step), one stream',
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
         out['rmse_dev_m'] = round(rmse_dev, 6)        # eval-path dense-depth RMSE of this dtype against the f32 parity mode, metres (north star: <= 1e-3)
@@ -504,27 +503,76 @@ def main():
                 f.write('kernel N Hi Wi Ci Ho Wo Co K s | launches ms_total us_avg TFLOP/s\n')
                 for k, v in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                     f.write(' '.join(map(str, k)) + f' | {v[2]} {1e3 * v[1]:.2f} {1e6 * v[1] / v[2]:.1f} {v[0] / v[1] / 1e12:.1f}\n')
-        if a.dtype == 'f16' and world == 1 and not a.no_as_worded and not graphed and not a.label_net:
-            # BASELINE configs[1] words bf16: the same workload, same kernels, in bf16 on the same box (an extra, untimed by the contract)
+        if a.dtype == 'f16' and world == 1 and not a.no_as_worded and not graphed and not a.label_net and not a.nlspn:
+            # The other single-GPU configurations of BASELINE.json, measured in the same process on the same box after the headline
+            # (extras, untimed by the contract): configs[1] AS WORDED (bf16 conv operands) with its own roofline block, configs[2]
+            # (= the headline + NLSPN propagation) and configs[4]'s per-GPU shape (480 x 640, batch 4, f16).  Same protocol as the
+            # headline (the same warm-up count, losses read back every step), min(steps, 10) timed steps each.
             del model
             torch.cuda.empty_cache()
-            Fh.set_compute_dtype(torch.bfloat16)
-            Fh.invalidate_packed_weights()
-            torch.manual_seed(0)
-            mb = RDFCGAN(dev, False, model_cfg(a.nlspn), is_train=True, exact_schedule=a.exact_schedule)
-            mb.train()
-            for i in range(3 + a.steps):
-                if i == 3:
-                    torch.cuda.synchronize()
-                    tb = time.perf_counter()
-                mb.set_input(batches[i % len(batches)])
-                lb = mb.optimize_parameters()
-            torch.cuda.synchronize()
-            eb = time.perf_counter() - tb
-            assert all(np.isfinite(v) for v in lb.values()), f'non-finite bf16 losses: {lb}'
-            out['as_worded_bf16'] = dict(value=round(a.batch * a.steps / eb, 3), unit='pairs/s', ms_per_step=round(1e3 * eb / a.steps, 3), steps=a.steps, warmup=3,
-                                         step_frac_of_mfma_peak=round(a.batch * a.steps / eb * gflop_pair / 1e3 / PEAK_TFLOPS['bf16'], 4),
-                                         note='BASELINE configs[1] as worded (bf16 conv operands): same process, same box, same schedule, after the f16 measurement')
+
+            def leg(dtype, nlspn, batch, H, W, tag):
+                Fh.set_compute_dtype(dict(bf16=torch.bfloat16, f16=torch.float16)[dtype])
+                Fh.invalidate_packed_weights()
+                torch.manual_seed(0)
+                m = RDFCGAN(dev, False, model_cfg(nlspn), is_train=True, exact_schedule=a.exact_schedule)
+                m.train()
+                bl = batches if (batch, H, W) == (a.batch, a.height, a.width) else [synth_batch(batch, H, W, 4321 + i, dev) for i in range(2)]
+                nst = min(a.steps, 10)
+                for i in range(a.warmup):
+                    m.set_input(bl[i % 2])
+                    m.optimize_parameters()
+                torch.cuda.synchronize()
+                lprof, liso = [], []
+                tb = time.perf_counter()
+                for i in range(nst):
+                    hip.PROFILE = lprof if i == 0 else None          # per-kernel HIP events on the first timed step (as the headline)
+                    m.set_input(bl[i % 2])
+                    ll = m.optimize_parameters()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - tb
+                hip.PROFILE = None
+                assert all(np.isfinite(v) for v in ll.values()), f'non-finite losses in leg {tag}: {ll}'
+                Fh.set_multi_stream(False)                           # one extra untimed step on ONE stream: every kernel alone on the chip
+                hip.PROFILE = liso
+                m.set_input(bl[0])
+                m.optimize_parameters()
+                torch.cuda.synchronize()
+                hip.PROFILE = None
+                Fh.set_multi_stream(True)
+                sc = (H * W) / (228.0 * 304.0)
+                gf = step_gflop_per_pair(a.exact_schedule, sc, False)
+                r = dict(value=round(batch * nst / el, 3), unit='pairs/s', ms_per_step=round(1e3 * el / nst, 3), steps=nst, warmup=a.warmup, dtype=dtype,
+                         config=dict(workload=tag, batch=batch, height=H, width=W, nlspn=bool(nlspn), step_gflop_per_pair=round(gf, 1)),
+                         step_frac_of_mfma_peak=round(batch * nst / el * gf / 1e3 / PEAK_TFLOPS[dtype], 4))
+                sym = {}
+                for _n, fl_, e0, e1, _s, kern in lprof:
+                    d_ = sym.setdefault(kern, [0.0, 0.0, 0])
+                    d_[0] += fl_
+                    d_[1] += e0.elapsed_time(e1) * 1e-3
+                    d_[2] += 1
+                if sym:
+                    top_ = max(sym, key=lambda k: sym[k][1])
+                    fl_, sec_, n_ = sym[top_]
+                    r['roofline'] = dict(bound='mfma', kernel=top_, achieved=round(fl_ / sec_ / 1e12, 2), peak=PEAK_TFLOPS[dtype], unit='TFLOP/s',
+                                         frac=round(fl_ / sec_ / 1e12 / PEAK_TFLOPS[dtype], 4), traffic=None, launches=n_,
+                                         avg_launch_us=round(1e6 * sec_ / n_, 2), share_of_step=round(sec_ / (el / nst), 4), event_steps=1)
+                    ifl = sum(x[1] for x in liso if x[5] == top_)
+                    isec = sum(x[2].elapsed_time(x[3]) * 1e-3 for x in liso if x[5] == top_)
+                    inum = sum(1 for x in liso if x[5] == top_)
+                    if inum:
+                        r['roofline']['isolated'] = dict(achieved=round(ifl / isec / 1e12, 2), frac=round(ifl / isec / 1e12 / PEAK_TFLOPS[dtype], 4),
+                                                         avg_launch_us=round(1e6 * isec / inum, 2), launches=inum)
+                del m
+                torch.cuda.empty_cache()
+                return r
+            out['as_worded_bf16'] = leg('bf16', False, a.batch, a.height, a.width, 'BASELINE configs[1] as worded: the headline workload with bf16 conv operands')
+            out['as_worded_bf16']['note'] = 'same process, same box, same schedule and protocol as the headline, after the f16 measurement'
+            if (a.batch, a.height, a.width) == (8, 228, 304):
+                out['configs'] = {
+                    '#3_nlspn': leg('f16', True, 8, 228, 304, 'BASELINE configs[2]: configs[1] + NLSPN propagation (18 steps, TGASS, confidence propagation; f32 gather kernels)'),
+                    '#5_480x640_b4_f16': leg('f16', False, 4, 480, 640, "BASELINE configs[4]'s per-GPU shape: SUN RGB-D 640x480 inputs, batch 4, f16 activations, f32 loss accumulation"),
+                }
             Fh.set_compute_dtype(torch.float16)
         if not a.no_cpu_baseline and world == 1:    # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(a.batch, a.height, a.width, True, steps=a.cpu_steps)

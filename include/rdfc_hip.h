@@ -221,12 +221,12 @@ int rdfc_norm_bwd_apply_acc(const void *dz, const void *x, const float *mean, co
                             const float *beta, const void *res, const float *sums, void *dx, void *dres,
                             int G, int P, int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype,
                             int act, float slope, const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream);
-/* One layer's launches behind one call.  Round 4: the finalize of every two-stage reduction is done by the reduction launch's
- * LAST-ARRIVING workgroup (csrc/fold.h: write-through partial rows, one agent-scope ticket per workgroup, two levels of fixed-order
- * f64 sums -- bitwise reproducible like the separate finalize launches these calls used to make, which the three-call sequences
- * above still do).  scratch: f32 [rdfc_fold_scratch_floats(G, rdfc_norm_nchunk(P, C, dtype), K, C)], K = 2 (forward) / 3 (backward):
- * the partial rows + the level-2 rows. */
-int rdfc_fold_scratch_floats(int G, int nchunk, int K, int C);
+/* One layer's launches behind one call (the same kernels, in the same order, on the same stream as the three-call sequences above:
+ * reduction launch -> fixed-order f64 finalize launch -> apply pass; bitwise reproducible).  scratch: f32
+ * [rdfc_norm_scratch_floats(G, rdfc_norm_nchunk(P, C, dtype), K, C)], K = 2 (forward) / 3 (backward): the partial rows + the f64
+ * per-group statistics a stacked-batch BatchNorm hands from its finalize to its normalise pass.  (Round 4's in-launch finalize by the
+ * last-arriving workgroup measured slower than the finalize launch and was removed in round 5: profiles/r04_experiments.txt item 1.) */
+int rdfc_norm_scratch_floats(int G, int nchunk, int K, int C);
 /* statistics only (W-AdaIN's instance norm of the content map, model_utils.py:86): mean / rstd [G][C] (+ running statistics, G == 1) */
 int rdfc_norm_stats_final(const void *x, float *scratch, float *mean, float *rstd, int G, int P, int C, int ld, int dtype, float eps,
                           float *run_mean, float *run_var, float momentum, void *stream);
@@ -260,7 +260,7 @@ int rdfc_adain_bwd_apply(const void *dout, const void *x, const float *mean, con
                          const float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx,
                          int ldgb, int lddx, int lddgb, int dtype, void *stream);
 
-/* sums + apply of the W-AdaIN backward in one call; scratch: f32 [rdfc_fold_scratch_floats(N, rdfc_norm_nchunk(P, C, dtype), 3, C)], sums f32 [N][3][C] */
+/* sums + apply of the W-AdaIN backward in one call; scratch: f32 [rdfc_norm_scratch_floats(N, rdfc_norm_nchunk(P, C, dtype), 3, C)], sums f32 [N][3][C] */
 int rdfc_adain_backward(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb, float *scratch,
                         float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx, int ldgb, int lddx, int lddgb,
                         int dtype, void *stream);

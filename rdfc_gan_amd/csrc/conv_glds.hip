@@ -1,30 +1,24 @@
-// conv_glds.hip -- 3x3 / stride-1 convolution (forward and input-gradient), bf16, staged by LDS-DMA.
+// conv_glds.hip -- 3x3 / stride-1 convolution (forward and input-gradient), 2-byte elements, staged by LDS-DMA.
 //
-// Same decomposition as conv_patch.hip (a 16x16 pixel tile per workgroup, the 18x18 halo patch of a 32-channel
-// slab in LDS, nine taps = nine LDS offsets) with a different pipeline.  PMC on the register-staged kernel
-// (256->256 @ 57x76, profiles/): 3 SALU + 2 VALU per MFMA (address generation, bounds tests, the ds_write pass),
-// SQ_WAIT_ANY 55 % of wave-cycles, matrix pipe busy 26 %.  Here
-//   * both operands go global -> LDS with global_load_lds_dwordx4: no staging registers, no ds_write pass;
-//     per-lane source pointers are computed once per workgroup, the per-step update is one uniform offset;
+// Same decomposition as conv_patch.hip (a pixel tile per workgroup, the halo patch of a 32-channel slab in LDS, nine taps = nine
+// LDS offsets) with a different pipeline.  PMC on the register-staged kernel (256->256 @ 57x76, profiles/): 3 SALU + 2 VALU per
+// MFMA (address generation, bounds tests, the ds_write pass), SQ_WAIT_ANY 55 % of wave-cycles, matrix pipe busy 26 %.  Here
+//   * both operands go global -> LDS by LDS-DMA through buffer descriptors (round 5: bdma16): a lane's source is a 32-bit byte offset
+//     computed once per workgroup plus a wave-uniform per-phase offset in a scalar register; out-of-image pixels, the rows between
+//     stacked images and channel rows beyond Cout are offsets beyond the descriptor's extent and arrive as ZEROS -- no zero page, no
+//     select, no vector instruction per DMA; every wave issues the same number of DMAs, so the vmcnt arithmetic stays static;
 //     the XOR bank swizzle of the LDS image is applied on the SOURCE side (LDS-DMA destinations are lane-linear);
-//     out-of-image and out-of-range pieces read a 64-byte zero page, so every wave issues the same number of
-//     DMAs and the vmcnt arithmetic below stays static;
-//   * the weights run through a ring of 3 (128-co tiles) or 2 (64-co tiles) tap slots filled two / one taps ahead, the patch is
-//     double buffered and its DMAs are spread over the first taps of the previous slab; loads stay in flight across the (raw)
-//     barrier: each phase waits with a counted s_waitcnt vmcnt(N) for exactly the DMAs it is about to read;
-//   * a wave owns 64 co x 64 px (16 MFMAs per phase against 8 fragment reads, half the LDS traffic per MFMA
-//     of the 64x32 wave tile).
-// One barrier per tap.  Workgroups are 4 waves: 128 co x (8x16) px or 64 co x (16x16) px; LDS 2 x 12 KB patch +
-// 3 x 8 KB weights = 48 KB, or 2 x 21 KB + 2 x 4 KB + 1 KB = 51 KB (ring_of below): three workgroups per CU, 3 waves per
-// SIMD at 154-158 registers (64 accumulators + 32 fragment registers per lane; at the 128-register cap of a
-// 4-waves-per-SIMD build the compiler spilled, and a scratch reload is a vmcnt(0) that drains the DMA queue).
+//   * the weights run through a ring of 3 (128-co tiles) or 2 (64-co tiles) tap slots, the patch is double buffered and its DMAs are
+//     spread over the first taps of the previous slab; loads stay in flight across the (raw) barrier: each phase waits with a counted
+//     s_waitcnt vmcnt(N) for exactly the DMAs the NEXT phase's fragment reads need;
+//   * a wave owns 64 co x (JR rows of 16 px); the taps are walked kernel column by kernel column with the column's pixel fragments
+//     resident in registers, and every fragment read is issued a phase ahead, in place (see the kernel).
+// One barrier per tap.  Workgroups are 4 waves: 128 co x (2 JR x 16) px, JR = 4 | 6 | 8 | 10 (glds_plan picks per launch), or
+// 64 co x (16 x 16) px.  JR = 4 and the 64-co tile: 48 / 51 KB of LDS, 160 registers, three workgroups per CU; JR = 6 / 8 / 10:
+// 186 / 219 / 253 registers and 57 / 67 / 75 KB, two per CU.
 #include "common.h"
 
 #include <stdlib.h>
-
-#ifndef RDFC_GLDS_REUSE_MIN
-#define RDFC_GLDS_REUSE_MIN 4
-#endif
 
 namespace {
 
@@ -53,13 +47,7 @@ constexpr int BK = 32, TC = 16, PW = TC + 2;
 // kernel needs 168 registers): 256->256 @ 57x76 58.4 -> 52.7 us (its 640 workgroups now fit one round), 128->128 @ 114x152 60.2 -> 53.1,
 // 256->128 @ 114x152 98.2 -> 94.0.  The 64-co tiles (2 x 21 KB of patch) need a ring of TWO (weights fetched one phase ahead) to get
 // three workgroups on a CU (50 KB each): 64->64 @ 16x228x304 160 -> 134 us forward, 163 -> 136 input gradient, 128->64 244 -> 218.
-template <int TCO, int JR = 4> constexpr int ring_of() {
-#ifdef RDFC_GLDS_TALL_RING
-    return JR > 4 && JR <= 8 ? RDFC_GLDS_TALL_RING : (TCO == 128 ? 3 : 2);
-#else
-    return TCO == 128 ? 3 : 2;
-#endif
-}
+template <int TCO, int JR = 4> constexpr int ring_of() { return TCO == 128 ? 3 : 2; }       // (a ring of 4 for the tall tiles measured 1-3 % slower: r05_experiments)
 
 // LDS-DMA instructions a wave may still have in flight when it enters phase s of a slab (what it reads then -- the weights of this
 // phase, at s = 0 the slab's patch -- is older): the weights of the look - 1 phases after this one (nwp instructions each) and one
@@ -87,10 +75,6 @@ __device__ inline void glds16(const void *gsrc, unsigned lds_base) {
 // goes with a descriptor of zero records instead.)  No vector instruction per DMA: offsets are 32-bit registers computed once.
 constexpr unsigned DEAD = 0x80000000u;
 __device__ inline void bdma16(unsigned voff, u32x4 rsrc, unsigned soff, unsigned lds_base) {
-#ifdef RDFC_GLDS_M0_CLOBBER      // experiment: m0 declared clobbered instead of saved and restored (clang warns that m0 is reserved)
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "memory", "m0");
-    return;
-#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
@@ -158,12 +142,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
                                                               const float *__restrict__ bias, void *__restrict__ yout,
                                                               const bf16_t *__restrict__ zero, float *__restrict__ stats) {
     constexpr int NW = 4;                                      // waves per workgroup; a wave owns 64 co x (JR x 16) px
-    constexpr bool REUSE = JR >= RDFC_GLDS_REUSE_MIN;                             // kernel-column order with the column's B fragments resident in registers
-#ifdef RDFC_GLDS_NOPIPE
-    constexpr bool PIPE = false;
-#else
-    constexpr bool PIPE = REUSE;                               // ... and every fragment read issued one phase ahead (the loop at the end of the K section)
-#endif
     constexpr int NT = NW * 64;
     constexpr int WCO = TCO / 64, WPX = NW / WCO;              // waves along co / along pixel rows
     constexpr int TR = JR * WPX, PH = TR + 2, NPATCH = PH * PW; // tile rows, patch rows, patch pixels (180 / 324)
@@ -256,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
 
     // ---- fragment coordinates ---------------------------------------------------------------------------------
     const int wr = wave / WPX, wc = wave % WPX;
-    constexpr int NB = REUSE ? JR + 2 : JR;                      // B fragments a wave holds: the patch rows of a kernel column | of one tap
+    constexpr int NB = JR + 2;                                   // B fragments a wave holds: the patch rows of a kernel column
     const int kg = lane >> 4;
     unsigned bcol[3];                                            // per-lane byte offset of the wave's first patch row at column shift kx
 #pragma unroll
@@ -282,69 +260,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     auto read_b = [&](int cc, int kx, int row) -> bf16x8 {      // patch row `row` of the wave (0 ... JR + 1) at column shift kx
         return *reinterpret_cast<const bf16x8 *>(smem + (cc & 1) * PATCH_BYTES + bcol[kx] + row * (PW * 64));
     };
-    bf16x8 bres[NB];                                             // REUSE: the B fragments of the current kernel column, patch row j in bres[j]
+    bf16x8 bres[NB];                                             // the B fragments of the current kernel column, patch row j in bres[j]
 #ifdef RDFC_GLDS_STAMPS
     unsigned long long sbuf[9][6];
     const bool stamp_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;
     const int wave_all = wave;
 #endif
 
-    if constexpr (!PIPE) {
-    // ---- prologue: slab 0 patch, weights of the first RING-1 phases --------------------------------------------------------
-#pragma unroll
-    for (int r = 0; r < NR; ++r) issue_p(r, 0);
-#pragma unroll
-    for (int h = 0; h < WLOOK; ++h) issue_w(h);
-
-    // phase (cc, S): DMAs still allowed in flight at its wait = the weights of the WLOOK - 1 phases after this one and the patch rounds
-    // issued beside them (glds_allow)
-#define RDFC_GLDS_PHASE(TAP)                                                                                   \
-    {                                                                                                          \
-        constexpr int ALLOW = glds_allow(TAP, WLOOK, NWP, NR);                                                 \
-        RDFC_STAMP(TAP, 0)                                                                                     \
-        wait_vm_and_reads<ALLOW>();                                                                            \
-        RDFC_STAMP(TAP, 1)                                                                                     \
-        __builtin_amdgcn_s_barrier();                                                                          \
-        RDFC_STAMP(TAP, 2)                                                                                     \
-        issue_w(it0 + TAP + WLOOK);                                                                            \
-        if (TAP < NR) issue_p(TAP < NR ? TAP : 0, cc + 1);                                                     \
-        RDFC_STAMP(TAP, 3)                                                                                     \
-        {                                                                                                      \
-            bf16x8 a_[4];                                                                                      \
-            constexpr int KY = TAP % 3, KX = TAP / 3;                                                          \
-            if constexpr (REUSE) {           /* rows 0 ... JR - 1 with the column's first tap, one more row with each of the others */ \
-                if (KY == 0) {                                                                                 \
-                    _Pragma("unroll") for (int j = 0; j < JR; ++j) bres[j] = read_b(cc, KX, j);                \
-                } else                                                                                         \
-                    bres[JR - 1 + KY] = read_b(cc, KX, JR - 1 + KY);                                           \
-            } else {                                                                                           \
-                _Pragma("unroll") for (int j = 0; j < JR; ++j) bres[j] = read_b(cc, KX, j + KY);               \
-            }                                                                                                  \
-            read_a(it0 + TAP, a_);                                                                             \
-            RDFC_STAMP(TAP, 4)                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
-                _Pragma("unroll") for (int j = 0; j < JR; ++j)                                                 \
-                    acc[i][j] = mma16<DT>(a_[i], bres[REUSE ? j + KY : j], acc[i][j]);                         \
-        }                                                                                                      \
-        RDFC_STAMP(TAP, 5)                                                                                     \
-    }
-    for (int cc = 0; cc < ncc; ++cc) {
-        const int it0 = cc * 9;
-        RDFC_GLDS_PHASE(0)
-        RDFC_GLDS_PHASE(1)
-        RDFC_GLDS_PHASE(2)
-        RDFC_GLDS_PHASE(3)
-        RDFC_GLDS_PHASE(4)
-        RDFC_GLDS_PHASE(5)
-        RDFC_GLDS_PHASE(6)
-        RDFC_GLDS_PHASE(7)
-        RDFC_GLDS_PHASE(8)
-    }
-#undef RDFC_GLDS_PHASE
-    } else {
-    // ---- the tall tiles' loop: every fragment read is issued a phase ahead, between the MFMAs of the phase before ----------------------
-    // Two waves share a SIMD here (not three), so a phase that runs wait -> barrier -> DMA issue -> fragment reads -> MFMAs one after the
-    // other leaves the matrix pipe idle whenever both are in the front part (stamps of round 5: 56 % busy).  Now a phase's MFMAs take all
+    // ---- the K loop: every fragment read is issued a phase ahead, between the MFMAs of the phase before ----------------------------------
+    // With two waves on a SIMD (the tall tiles), a phase that runs wait -> barrier -> DMA issue -> fragment reads -> MFMAs one after the
+    // other leaves the matrix pipe idle whenever both are in the front part (stamps of round 5: 56 % busy).  A phase's MFMAs take all
     // their operands from registers that were filled during the phase before, IN PLACE (no second register set):
     //   * the MFMAs run channel block by channel block (i outer, rows inner): weight fragment i is dead after its JR MFMAs, and the
     //     fragment i of the NEXT phase is read into its registers (that ring slot landed a phase earlier than it used to: the waits
@@ -362,9 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     read_a(0, aa);
 #pragma unroll
     for (int j = 0; j < JR; ++j) bres[j] = read_b(0, 0, j);
-#ifndef RDFC_GLDS_SCHED
-#define RDFC_GLDS_SCHED __builtin_amdgcn_sched_barrier(0);
-#endif
+#define RDFC_GLDS_SCHED __builtin_amdgcn_sched_barrier(0);      // (pins the order written here: left alone, hipcc hoists the reads and the registers run out)
 #define RDFC_GLDS_PHASE(TAP)                                                                                   \
     {                                                                                                          \
         constexpr int ALLOW = glds_allow(TAP, WLOOK, NWP, NR);    /* the weights of phase it + 1 were issued WLOOK phases ago */ \
@@ -407,7 +330,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
         RDFC_GLDS_PHASE(5) RDFC_GLDS_PHASE(6) RDFC_GLDS_PHASE(7) RDFC_GLDS_PHASE(8)
     }
 #undef RDFC_GLDS_PHASE
-    }
     wait_vm<0>();
 #ifdef RDFC_GLDS_STAMPS
     if (stamp_on && lane == 0 && ncc > 2)
@@ -502,13 +424,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
         }
     }
     auto store_all = [&](auto actf) {
-#ifdef RDFC_EXP_NOSTORE          // timing-only experiment build (tools/build_variant.sh): what the epilogue's stores cost -- results are wrong
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < JR; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
-        return;
-#endif
 #pragma unroll
         for (int j = 0; j < JR; ++j) {
             const int oy = oyr[j], ox = x0 + (lane & 15);
@@ -755,9 +670,8 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     p.x_bytes = (unsigned)(2 * (size_t)p.N * p.Hin * p.Win * p.ld_in);      // (< 2^31: glds_shape_ok; a channel slice's last pixel ends before that, and no live offset points there)
     p.w_bytes = (unsigned)(2 * (size_t)Cout * 9 * Cin);
     // whole-row stores: 2-byte results without an addend, channel rows of whole 16-byte chunks at 16-byte aligned addresses, a
-    // piecewise-linear epilogue (RDFC_GLDS_ROWSTORE=0: the direct 8-byte stores, for A/B runs)
-    static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
-    p.row_store = rows_on && !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+    // piecewise-linear epilogue
+    p.row_store = !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
     p.tiles_x = cdiv(p.W, TC);                                 // 128 co x (2 JR x 16) px or 64 co x (16 x 16) px per workgroup

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NT) void head_dgrad_kernel(HDParams p, const bf16_t
 
 // Called by rdfc_conv2d_dgrad (conv_igemm.hip) first; returns 1 if it took the launch.
 int rdfc_try_head_dgrad(const rdfc_conv_desc *d, const void *dy, const void *w_bwd, const float *bias, void *dx, hipStream_t st) {
-    static const bool off = getenv("RDFC_NO_HEAD_DGRAD") != nullptr;
+    constexpr bool off = false;
     if (off || !rdfc_is16(d->dtype) || bias != nullptr || d->act != RDFC_ACT_NONE || d->out_f32) return 0;
     if (d->Co != 1 || d->ldy != 1 || d->KH != 3 || d->KW != 3 || d->sh != 1 || d->sw != 1 || d->dh != 1 || d->dw != 1) return 0;
     if (d->ph != d->pw || d->ph > 2) return 0;

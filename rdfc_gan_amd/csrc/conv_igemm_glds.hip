@@ -46,13 +46,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
     constexpr int WCO = TCO / 64, WPX = 4 / WCO;                // waves along co / px: each 64 co x 64 px
     constexpr int NA = TCO * 4 / NT, NB = TPX * 4 / NT;         // DMAs per thread and K-step: weights (2 / 1), pixels (2 / 4)
     constexpr int AB = TCO * BK * 2, SLOT = AB + TPX * BK * 2;  // 16 KB / 20 KB
-#ifdef RDFC_IGEMM_GLDS_RING
-    constexpr int RING = RDFC_IGEMM_GLDS_RING, LOOK = RING - 1;
-#else
     // three slots either way: 48 KB (three workgroups per CU; with four slots and two workgroups 4x4/s2 64->128 @ 228x304 ran 80.9 us,
     // now 68.5; 128->256 @ 114x152 81.1 -> 74.6) / 60 KB
     constexpr int RING = 3, LOOK = RING - 1;
-#endif
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     __shared__ int tap_w[MAXTAPS], tap_dy[MAXTAPS], tap_dx[MAXTAPS], ntaps_s;
     __shared__ int pxo[TPX];
@@ -302,11 +298,9 @@ const bf16_t *zero_page() {
 template <int TCO, int DT = RDFC_BF16>
 int launch(const IGParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, hipStream_t st) {
     constexpr int TPX = TCO == 128 ? 128 : 256;
-#ifdef RDFC_IGEMM_GLDS_RING
-    constexpr int SMEM = RDFC_IGEMM_GLDS_RING * (TCO + TPX) * BK * 2;
-#else
-    constexpr int SMEM = 3 * (TCO + TPX) * BK * 2;
-#endif
+    constexpr int OPER = 3 * (TCO + TPX) * BK * 2;
+    constexpr int SMEM = OPER > (NT / 64) * RS_TILE ? OPER : (NT / 64) * RS_TILE;          // the whole-row epilogue reuses it: 9 KB per wave
+    static_assert(SMEM >= (NT / 64) * RS_TILE, "rs_put / rs_flush write wave * RS_TILE ... + RS_TILE");
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)igemm_glds_kernel<TCO, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
@@ -330,8 +324,7 @@ int launch(const IGParams &p, const void *x, const void *w, const float *bias, v
 // Called by conv_igemm.hip's entry points after the 3x3 / stride-1 kernels. Returns 1 if it took the launch.
 int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                         hipStream_t st, const void *addend = nullptr, int ld_add = 0) {
-    static const int mode = getenv("RDFC_IGEMM_GLDS") ? atoi(getenv("RDFC_IGEMM_GLDS")) : 1;
-    if (!mode || !rdfc_is16(d->dtype)) return 0;
+    if (!rdfc_is16(d->dtype)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     const int ld_in = transposed ? d->ldy : d->ldx;
     if (Cin % BK != 0 || ld_in % 8 != 0 || Cout < 64 || d->KH * d->KW > MAXTAPS) return 0;
@@ -339,19 +332,18 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
     // kernel (1x1 192->384, 6 steps: 83 vs 69 us); with three slots and three workgroups per CU this kernel wins from 6 steps up
     // (1x1 192->384 67 -> 63 us forward, 67 -> 57 input gradient; 1x1 384->768 57 -> 49 / 56 -> 47; 1x1 768->1536 60 -> 46;
     // 3x3/s2 64->128 54 -> 46); 3-step reductions (1x1 96->192) stay where they were.
-    static const int min_steps = getenv("RDFC_IGEMM_GLDS_MINSTEPS") ? atoi(getenv("RDFC_IGEMM_GLDS_MINSTEPS")) : 6;
+    constexpr int min_steps = 6;
     if (d->KH * d->KW * (Cin / BK) < min_steps) return 0;
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
     IGParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, Cin, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo, Cout,
                d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw, ld_in, transposed ? d->ldx : d->ldy, transposed,
                d->act, d->slope, d->out_f32, addend, ld_add, 0};
-    static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
-    p.row_store = rows_on && !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+    p.row_store = !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
     if (d->dtype == RDFC_F16)
         return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, st);
-    if (Cout > 64 || mode == 3) return launch<128>(p, in, w, bias, out, zero, st);
+    if (Cout > 64) return launch<128>(p, in, w, bias, out, zero, st);
     return launch<64>(p, in, w, bias, out, zero, st);
 }

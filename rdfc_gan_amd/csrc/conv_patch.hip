@@ -446,7 +446,7 @@ void launch_T(const PatchParams &p, const void *x, const void *w, const float *b
     // Variant choice from interleaved A/B runs on one device (tools/ab_env.sh): the slab-resident kernel wins for
     // Cout <= 64 (+7..13 %, 1-channel heads +68 %) and for the 512-channel layers (+13 %); the per-tap kernel with
     // 8-wave workgroups (2 workgroups / CU) wins for 128- and 256-channel outputs (+6..9 %).
-    static const int slab_env = getenv("RDFC_SLAB") ? atoi(getenv("RDFC_SLAB")) : -1;
+    constexpr int slab_env = -1;
     const bool slab = slab_env >= 0 ? slab_env != 0 : (p.Cout <= 64 || p.Cin >= 512);
     if constexpr (sizeof(T) == 2) if (slab) {
         if (p.Cout > 64) launch_slab<T, 128, 256, 2, 512>(p, x, w, bias, y, st);

@@ -329,8 +329,7 @@ int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const voi
     if (zero == nullptr) return 0;
     TParams p{d->N, d->Ho, d->Wo, d->Hi, d->Wi, d->Co, d->Ci, d->ldy, d->ldx, d->act, d->slope, d->out_f32, cdiv(d->Wo, TC), cdiv(d->Ho, TRS),
               addend, ld_add, 0, addend2, ld_add2};
-    static const bool rows_on = !(getenv("RDFC_GLDS_ROWSTORE") && atoi(getenv("RDFC_GLDS_ROWSTORE")) == 0);
-    p.row_store = rows_on && !d->out_f32 && p.Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(res) & 15) == 0 &&
+    p.row_store = !d->out_f32 && p.Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(res) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   (addend2 == nullptr || (ld_add2 % 4 == 0 && (reinterpret_cast<size_t>(addend2) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;

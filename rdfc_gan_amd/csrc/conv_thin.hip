@@ -225,7 +225,7 @@ int rdfc_try_conv_thin_row(const rdfc_conv_desc *d, const void *in, const void *
 
 int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                        hipStream_t st) {
-    static const bool off = getenv("RDFC_NO_THIN") != nullptr;
+    constexpr bool off = false;
     if (off || !rdfc_is16(d->dtype)) return 0;
     if (!transposed && rdfc_try_conv_thin_row(d, in, w, bias, out, st)) return 1;      // wide kernels (7x7 -> 3 channels): row GEMM + shift-add
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
@@ -258,11 +258,11 @@ int rdfc_try_conv_thin(const rdfc_conv_desc *d, int transposed, const void *in, 
     p.items_pad = (p.items + 63) / 64 * 64;
     p.P = d->N * p.Hout * p.Wout;
     const int co_t = Cout <= 1 ? 1 : (Cout <= 2 ? 2 : 4);
-    static const long tile_min = getenv("RDFC_THIN_TILE_MINPX") ? atol(getenv("RDFC_THIN_TILE_MINPX")) : 65536;
+    constexpr long tile_min = 65536;
     // A/B on one device (tools/thin_bench.sh): the tile kernel wins on the 7x7 layers (64->3 fwd 215 vs 309 us, 1<-64 dgrad
     // 99 vs 315 us) and on narrow inputs (1<-16 dgrad 12 vs 129 us); the 3x3 layers with >= 64 input channels stay on the
     // padded MFMA tiles (128->1: 46 vs 62 us)
-    static const bool tile_all = getenv("RDFC_THIN_TILE_ALL") != nullptr;
+    constexpr bool tile_all = false;
     const bool tile_pays = tile_all || d->KH * d->KW > 9 || Cin < 64;
     if (p.P >= tile_min && !tile_pays) return 0;
     if (p.P >= tile_min && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && Cin % 16 == 0) {

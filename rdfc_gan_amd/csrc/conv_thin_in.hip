@@ -224,7 +224,7 @@ int launch(const TIParams &p, const void *t, const void *w, const float *bias, v
 // Called by conv_igemm.hip's entry points. Returns 1 if it took the launch.
 int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st) {
-    static const bool off = getenv("RDFC_NO_THIN_IN") != nullptr;
+    constexpr bool off = false;
     if (off || !rdfc_is16(d->dtype)) return 0;
     const int Cin = transposed ? d->Co : d->Ci, Cout = transposed ? d->Ci : d->Co;
     if (Cin > 4 || Cout < 16 || Cout > 128) return 0;

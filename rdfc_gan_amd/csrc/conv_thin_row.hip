@@ -82,7 +82,6 @@ __global__ __launch_bounds__(256) void thin_row_kernel(RowParams p, const bf16_t
                 a[ky][m] = __builtin_bit_cast(bf16x8, v);
             }
         __syncthreads();                                              // (the previous chunk's last T reads / patch reads are done)
-#if !defined(RDFC_ROW_EXP) || RDFC_ROW_EXP != 2   /* timing experiments (wrong results): 1 = staging only, 2 = compute only */
         // patch of this chunk: every 16-byte piece (pixel, 8-channel vector) is one load; all of a thread's loads are issued before
         // the first LDS store (a load -> store chain per row costs a memory latency per row)
         {
@@ -108,12 +107,7 @@ __global__ __launch_bounds__(256) void thin_row_kernel(RowParams p, const bf16_t
                 }
             }
         }
-#endif
         __syncthreads();
-#if defined(RDFC_ROW_EXP) && RDFC_ROW_EXP == 1
-        acc[0] += reinterpret_cast<float *>(smem)[tid];
-        continue;
-#endif
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
             // T[(co, kx)][pos] for the 16 x PW positions of patch rows ky .. ky+15
@@ -181,7 +175,7 @@ int launch_row(const RowParams &p, int dtype, const void *in, const void *w, con
 
 // Called by rdfc_try_conv_thin (conv_thin.hip) ahead of its tile kernel.  Forward form only (stride 1, dilation 1, square kernel).
 int rdfc_try_conv_thin_row(const rdfc_conv_desc *d, const void *in, const void *w, const float *bias, void *out, hipStream_t st) {
-    static const bool off = getenv("RDFC_NO_THIN_ROW") != nullptr;
+    constexpr bool off = false;
     if (off || !rdfc_is16(d->dtype)) return 0;
     if (d->KH != d->KW || d->Co > 4 || d->Ci % CH != 0 || d->ldx % 8 != 0) return 0;
     if (d->sh != 1 || d->sw != 1 || d->dh != 1 || d->dw != 1) return 0;

@@ -280,7 +280,7 @@ extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const v
     WgradParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw,
                   d->ldx, d->ldy, d->N * d->Ho * d->Wo, 0};
     hipStream_t st = (hipStream_t)stream;
-    static const bool w9 = getenv("RDFC_NO_WGRAD9") == nullptr;
+    constexpr bool w9 = true;
     if (rdfc_try_wgrad_thin(d, x, dy, dw_packed, st)) {
     } else if (rdfc_try_wgrad_glds(d, x, dy, dw_packed, st)) {
     } else if (rdfc_try_wgrad_gather_glds(d, x, dy, dw_packed, st)) {

@@ -191,7 +191,7 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     }
     p.tiles_ci = cdiv(p.Ci, 64);
     const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * p.KH;
-    static const double cap_mb = getenv("RDFC_WGRAD_ATOMIC_MB") ? atof(getenv("RDFC_WGRAD_ATOMIC_MB")) : 48.0;
+    constexpr double cap_mb = 48.0;
     int slices = 512 / tiles;                                  // one round of workgroups (see conv_wgrad_glds.hip)
     const int atomic_cap = (int)(cap_mb * 1.0e6 / (4.0 * p.Co * p.Ci * p.KH * p.KW));
     if (slices > atomic_cap) slices = atomic_cap;
@@ -217,8 +217,7 @@ int launch_kw(const WGParams &p, const void *x, const void *dy, float *dw, const
 
 // Called by rdfc_conv2d_wgrad (conv_wgrad.hip) after the stride-1 3x3 kernel; returns 1 if it took the launch.
 int rdfc_try_wgrad_gather_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st) {
-    static const int mode = getenv("RDFC_WGRAD_GATHER_GLDS") ? atoi(getenv("RDFC_WGRAD_GATHER_GLDS")) : 1;
-    if (!mode || !rdfc_is16(d->dtype)) return 0;
+    if (!rdfc_is16(d->dtype)) return 0;
     if (d->sh != d->sw || d->dh != d->dw || d->ph != d->pw || d->KH != d->KW) return 0;
     if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8) return 0;
     const int spr = cdiv(d->Wo, SEG);
@@ -226,11 +225,11 @@ int rdfc_try_wgrad_gather_glds(const rdfc_conv_desc *d, const void *x, const voi
     // A/B on one device (tools/wgrad2_bench.sh): wins on wide maps with <= 3 taps per kernel row (3x3/s2 64->128 @ 228x304:
     // 62 vs 82 us, 64->192: 70 vs 108 us, 1x1 192->384 @ 114x152: 57 vs 74 us); on the narrower maps and the 4x4 layers the
     // register-staged kernel's flat pixel tiles win (4x4/s1 256->512 @ 27x37: 124 vs 90 us)
-    if (mode == 1 && (d->Wo < 96 || d->KW > 3)) return 0;
+    if (d->Wo < 96 || d->KW > 3) return 0;
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
     WGParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->KH, d->KW, d->sh, d->ph, d->dh, d->ldx, d->ldy, spr,
                d->N * d->Ho * spr, 0, 0};
-    if (d->Co % 128 == 0 && (mode == 3 || (mode == 1 && d->Co >= 256))) return d->dtype == RDFC_F16 ? launch_kw<128, RDFC_F16>(p, x, dy, dw, zero, st) : launch_kw<128>(p, x, dy, dw, zero, st);
+    if (d->Co % 128 == 0 && d->Co >= 256) return d->dtype == RDFC_F16 ? launch_kw<128, RDFC_F16>(p, x, dy, dw, zero, st) : launch_kw<128>(p, x, dy, dw, zero, st);
     return d->dtype == RDFC_F16 ? launch_kw<64, RDFC_F16>(p, x, dy, dw, zero, st) : launch_kw<64>(p, x, dy, dw, zero, st);
 }

@@ -64,10 +64,7 @@ template <int ROWB> __device__ inline bf16x8 tr_frag(const unsigned char *img, i
 }
 
 // k-step ring (slots of dY + X rows filled WG_RING-1 steps ahead)
-#ifndef RDFC_WGRAD_GLDS_RING
-#define RDFC_WGRAD_GLDS_RING 4
-#endif
-constexpr int WG_RING = RDFC_WGRAD_GLDS_RING;
+constexpr int WG_RING = 4;
 
 // TCI = 128 (8 waves, 128 co x 128 ci; experiment, see rdfc_try_wgrad_glds): per k-step the workgroup stages 8 KB of dY + 8.7 KB of X
 // for 192 MFMAs instead of 8 + 4.4 KB for 96.
@@ -194,12 +191,6 @@ __global__ __launch_bounds__(256 * (TCI / 64), 2) void wgrad_glds_kernel(WGParam
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NTF; ++j) acc[t][i][j] = mma16<DT>(a[i], b[j], acc[t][i][j]);
-#ifdef RDFC_WGRAD_EXP_DUP   /* timing experiment only (wrong results): every MFMA twice -> how much of a k-step is not MFMA time */
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTF; ++j) acc[t][i][j] = mma16<DT>(a[i], b[j], acc[t][i][j]);
-#endif
         }
     }
     wait_vm<0>();
@@ -247,10 +238,10 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     // Split-K factor: fill the chip's workgroup slots in ONE round -- 528 workgroups measured 1.3x slower
     // than 480 -- within an atomic budget of 48 MB per launch (sweep on one device, 256->256 @ 57x76: 24 MB / 240
     // workgroups 108 us, 48 MB / 480 workgroups 91 us; under-filling the chip costs more than the extra atomics).
-    static const double cap_mb = getenv("RDFC_WGRAD_ATOMIC_MB") ? atof(getenv("RDFC_WGRAD_ATOMIC_MB")) : 48.0;
+    constexpr double cap_mb = 48.0;
     // workgroups the chip holds at once: the 64-co kernel (48 KB of LDS, 104 registers) fits three per CU, the 128-co one two.
     // Sizing the 64-co launches for 768 instead of 512: 64->64 @ 228x304 87 -> 80 us, 256->128 @ 114x152 154 -> 132, 128->64 @ 228x304 158 -> 141
-    static const int slots_env = getenv("RDFC_WGRAD_SLOTS") ? atoi(getenv("RDFC_WGRAD_SLOTS")) : 0;
+    constexpr int slots_env = 0;
     const int slots = slots_env ? slots_env : (TCO == 64 && NKY == 1 ? 768 : 512);
     int slices = slots / tiles;
     const int atomic_cap = (int)(cap_mb * 1.0e6 / (4.0 * p.Co * p.Ci * 9));
@@ -260,7 +251,7 @@ int launch(WGParams p, const void *x, const void *dy, float *dw, const bf16_t *z
     p.segs_per_slice = cdiv(p.total_segs, slices);
     slices = cdiv(p.total_segs, p.segs_per_slice);
     rdfc_note_kernel("wgrad_glds_kernel<%d, %d, %d, %d>", TCO, NKY, DT, TCI);
-    static const bool xcd_group = !(getenv("RDFC_WGRAD_XCD") && atoi(getenv("RDFC_WGRAD_XCD")) == 0);
+    constexpr bool xcd_group = true;
     p.tiles = tiles;
     // measured (tools/wgrad_xcd_ab.sh): 64->64 @ 228x304 (3 tiles) 95 -> 89 us; with 12-24 tiles per slice the slice count
     // (512 / tiles) is no multiple of 8 and the XCDs end up unevenly loaded: 256->256 @ 57x76 88 -> 123 us.  FETCH_SIZE

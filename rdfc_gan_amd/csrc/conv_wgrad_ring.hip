@@ -275,16 +275,9 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RPar
 //     the reads are off the critical path of a step as in conv3x3_glds.
 constexpr unsigned DEAD_OFF = 0x80000000u;
 __device__ inline void bdma16(unsigned voff, u32x4 rsrc, unsigned lds_base) {
-#ifndef RDFC_WRING_KEEP_M0       // m0 declared clobbered (the compiler uses it for nothing else in this kernel; clang warns that m0 is reserved): two
-    // scalar instructions fewer per DMA in a loop that is bound by scalar issue
+    // m0 is declared clobbered, not saved and restored (the compiler uses it for nothing else in this kernel; clang warns that m0 is
+    // reserved): two scalar instructions fewer per DMA in a loop that was bound by scalar issue
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_base) : "memory", "m0");
-#else
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(lds_base)
-                 : "memory");
-#endif
 }
 __device__ inline u32x4 row_rsrc(const void *base, unsigned bytes) {          // base and bytes wave-uniform
     const unsigned long long b = reinterpret_cast<unsigned long long>(base);
@@ -652,8 +645,8 @@ int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *ze
     const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * K;
     // one round of the chip's workgroup slots (2 per CU with the 128-co tile, 3 with the 64-co one) within a slab budget: every
     // workgroup writes its tile once (plain stores) and the reduction reads it once
-    static const int slots_env = getenv("RDFC_WGRAD_SLOTS") ? atoi(getenv("RDFC_WGRAD_SLOTS")) : 0;
-    static const double cap_mb = getenv("RDFC_WGRAD_SLAB_MB") ? atof(getenv("RDFC_WGRAD_SLAB_MB")) : 64.0;
+    constexpr int slots_env = 0;
+    constexpr double cap_mb = 64.0;
     const int slots = slots_env ? slots_env : (TCO == 64 ? 768 : 512);
     int slices = slots / tiles;
     const size_t dw_bytes = (size_t)4 * p.Co * p.Ci * K * K;
@@ -667,7 +660,7 @@ int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *ze
     p.tiles = tiles;
     float *slab = slab_for(st, dw_bytes * slices);
     if (slab == nullptr) return 0;
-    static const bool xcd_group = !(getenv("RDFC_WGRAD_XCD") && atoi(getenv("RDFC_WGRAD_XCD")) == 0);
+    constexpr bool xcd_group = true;
     p.xcd_group = xcd_group && tiles <= 4 && slices >= 8;
     const dim3 grid = p.xcd_group ? dim3(cdiv(slices, 8) * 8 * tiles, 1) : dim3(slices, tiles);
     if (ring2) {

@@ -237,7 +237,7 @@ void launch_M(const ThinWParams &p, int nfrag, const void *wide, const void *thi
 
 // Called by rdfc_conv2d_wgrad (conv_wgrad.hip) before the MFMA tile kernels; returns 1 if it took the launch.
 int rdfc_try_wgrad_thin(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st) {
-    static const bool off = getenv("RDFC_NO_WGRAD_THIN") != nullptr;
+    constexpr bool off = false;
     if (off || !rdfc_is16(d->dtype)) return 0;
     if (d->sh != 1 || d->sw != 1 || d->dh != 1 || d->dw != 1) return 0;
     const bool thin_x = d->Ci <= 4 && d->Co % 16 == 0 && d->ldy % 8 == 0 && d->Co <= 128;

@@ -9,7 +9,6 @@
 // Reductions are two-stage (per-chunk partials, then a fixed-order finalize in f64):
 // deterministic, no atomics.
 #include "common.h"
-#include "fold.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -17,11 +16,6 @@
 namespace {
 
 constexpr int NT = 256;
-#ifdef RDFC_NORM_FOLD_OFF
-constexpr bool FOLD_COMPILED = false;
-#else
-constexpr bool FOLD_COMPILED = true;
-#endif
 
 struct Map {       // geometry shared by the kernels
     int G, P, C;   // groups, pixels per group, channels
@@ -36,8 +30,7 @@ struct Map {       // geometry shared by the kernels
 inline int chunk_pixels(int P, int C, int vec) {
     const int cvt = C / vec < NT ? (C / vec > 0 ? C / vec : 1) : NT;
     const int rpb = NT / cvt;
-    static const int min_rows = getenv("RDFC_NORM_MIN_ROWS") ? atoi(getenv("RDFC_NORM_MIN_ROWS")) : 8;   // A/B knob
-    static const int want_wg = getenv("RDFC_NORM_WANT_WG") ? atoi(getenv("RDFC_NORM_WANT_WG")) : 512;
+    constexpr int min_rows = 8, want_wg = 512;
     int rows = 32;
     while (rows > min_rows && P / (rows * rpb) < want_wg) rows >>= 1;
     int chunk = rows * rpb;
@@ -58,19 +51,11 @@ inline Map make_map_stream(int G, int P, int C, int vec) {
 
 // body(p) for p = begin + r0, +RPB, ... < end, four rows per trip so four independent loads are in flight
 // streamed outputs are written once and read by a later kernel: non-temporal stores measured +1..5 % (A/B on one
-// device); non-temporal LOADS measured 10-15 % slower (RDFC_NORM_NT_LOAD) and stay off
+// device); non-temporal LOADS measured 10-15 % slower and stay off
 // (round 4: plain stores again -- inside the step the consumer of a streamed map is the next kernel, and with plain stores it finds more
-//  of it in the Infinity Cache: 241.0 vs 240.0 pairs/s, two interleaved pairs on one box; -DRDFC_NORM_NT_STORE for the other arm)
-#ifdef RDFC_NORM_NT_STORE
-#define ST store_nt
-#else
+//  of it in the Infinity Cache: 241.0 vs 240.0 pairs/s, two interleaved pairs on one box; non-temporal stores were the other arm)
 #define ST store
-#endif
-#ifdef RDFC_NORM_NT_LOAD
-#define LD load_nt
-#else
 #define LD load
-#endif
 #define ROW_LOOP(cx, body)                                                          \
     {                                                                                \
         int p_ = (cx).p_begin + (cx).r0;                                             \
@@ -158,15 +143,6 @@ inline dim3 grid_for(const Map &m, int vec) {
 // handful of threads serially adding up to 64 rows out of LDS (that tail used to cost more than the streaming part).
 template <typename T, int K>
 __device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K][Elem<T>::VEC], float *partial) {
-#ifdef RDFC_EXP_NOTAIL              // timing-only (results are wrong): what the in-block reduction costs
-    {
-        float t = 0.f;
-        for (int k = 0; k < K; ++k)
-            for (int v = 0; v < Elem<T>::VEC; ++v) t += s[k][v];
-        if (t == 12345.f) partial[threadIdx.x] = t;
-        return;
-    }
-#endif
     // Every thread deposits its K x VEC sums in LDS ([k][thread][v], 16-byte stores), then the K * CVT * VEC outputs are dealt to
     // ALL 256 threads: output o = (k, channel vector, v) sums its RPB rows (fixed order r = 0 .. RPB-1: reproducible) and is stored
     // with its neighbours in one coalesced line.  (Before: a butterfly of 24 runtime-offset shuffles plus a tail in which CVT
@@ -190,7 +166,7 @@ __device__ void block_reduce_store(const Ctx<T> &cx, const Map &m, float (&s)[K]
         float a = 0.f;
         for (int r = 0; r < RPB; ++r) a += red[(k * NT + r * CVT + cvt) * VEC + v];
         const int c = cbase + cvv;
-        fold::st_f32(&partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + c], a);      // write-through: read by the last-arriving workgroup (fold.h)
+        partial[(((size_t)cx.g * cx.nchunk + cx.chunk) * K + k) * m.C + c] = a;
     }
 }
 
@@ -216,57 +192,8 @@ __device__ __forceinline__ void load_consts(const float *__restrict__ p, int idx
 constexpr int MAXSEQ = 8;
 struct Moms { float m[MAXSEQ]; };
 
-// what the last-arriving workgroup of a statistics launch does with the totals (fold.h): mean / rstd per (group, channel), and the
-// running statistics -- one group (nn.BatchNorm2d) or `seq` stacked groups advanced in group order by the workgroup that finishes last
-struct FinStats {
-    float *mean, *rstd;
-    float eps;
-    float *run_mean, *run_var;
-    float momentum;
-    int seq;
-    Moms moms;
-    double *muvar;          // seq with running statistics: [G][2][C] (mean, biased variance) handed to the last group's finisher
-    unsigned *cnt_all;      // ... and its arrival counter
-};
-
-__device__ inline void finish_stats(const fold::Args &fa, const FinStats &fs, int G, int P, int C, int g, int chunk, const float *partial) {
-    const bool want_run = fs.run_mean != nullptr;
-    const bool last = fold::arrive<2>(fa, g, chunk, C, partial + (size_t)g * fa.nchunk * 2 * C, [&](int c, const double (&s)[2]) {
-        const double mu = s[0] / P;
-        double var = s[1] / P - mu * mu;
-        if (var < 0) var = 0;
-        fs.mean[g * C + c] = (float)mu;
-        fs.rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)fs.eps));
-        if (!want_run) return;
-        if (!fs.seq) {                 // batch norm, one group: nn.BatchNorm2d running statistics
-            const double unb = P > 1 ? var * P / (P - 1) : var;
-            fs.run_mean[c] = (float)((1.0 - fs.momentum) * fs.run_mean[c] + fs.momentum * mu);
-            fs.run_var[c] = (float)((1.0 - fs.momentum) * fs.run_var[c] + fs.momentum * unb);
-        } else {
-            fold::st_f64(fs.muvar + ((size_t)g * 2 + 0) * C + c, mu);
-            fold::st_f64(fs.muvar + ((size_t)g * 2 + 1) * C + c, var);
-        }
-    });
-    if (!last || !fs.seq || !want_run) return;
-    __shared__ unsigned s_word;
-    if (fold::arrive_ticket(fs.cnt_all, &s_word) != (unsigned)(G - 1)) return;
-    fold::acquire_all();
-    if (threadIdx.x == 0) __hip_atomic_store(fs.cnt_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double rm = fs.run_mean[c], rv = fs.run_var[c];
-        for (int q = 0; q < G; ++q) {
-            const double mu = fold::ld_f64(fs.muvar + ((size_t)q * 2 + 0) * C + c), var = fold::ld_f64(fs.muvar + ((size_t)q * 2 + 1) * C + c);
-            const double unb = P > 1 ? var * P / (P - 1) : var, mom = fs.moms.m[q];
-            rm = (double)(float)((1.0 - mom) * rm + mom * mu);          // rounded to f32 per update, like G separate launches
-            rv = (double)(float)((1.0 - mom) * rv + mom * unb);
-        }
-        fs.run_mean[c] = (float)rm;
-        fs.run_var[c] = (float)rv;
-    }
-}
-
 template <typename T>
-__global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ x, int ld, float *__restrict__ partial, fold::Args fa, FinStats fs) {
+__global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ x, int ld, float *__restrict__ partial) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[2][VEC];
@@ -287,15 +214,9 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
                 s[1][v] += f * f;
             }
         };
-#ifdef RDFC_NORM_NO_PF
-        auto body = [&](int p) { add(fetch(p)); };
-        ROW_LOOP(cx, body);
-#else
         row_loop_pf<4>(cx, fetch, add);
-#endif
     }
     block_reduce_store<T, 2>(cx, m, s, partial);
-    if (FOLD_COMPILED && fa.cnt != nullptr) finish_stats(fa, fs, m.G, m.P, m.C, cx.g, cx.chunk, partial);
 }
 
 // fixed-order sum over the chunk partials of one (group, k, channel): FC channels x FLn lanes per workgroup,
@@ -304,10 +225,7 @@ __global__ __launch_bounds__(NT) void stats_kernel(Map m, const T *__restrict__ 
 // threads + 1.5 % on the step.  Then by row count: the conv epilogues' fused statistics leave one row per TILE (4332 on a full-resolution
 // map), i.e. 135 dependent-latency rows per lane at 32 x 16 -- 256 threads as 8 x 32 or 4 x 64 (pick_fc) give 4-8 x the workgroups
 // and a quarter of the rows per lane.
-#ifndef RDFC_NORM_FL
-#define RDFC_NORM_FL 16
-#endif
-constexpr int FL = RDFC_NORM_FL, FNT = 32 * FL;
+constexpr int FL = 16, FNT = 32 * FL;
 constexpr int FNT2 = 256;                       // threads of the <FC> kernels: FC channels x (256 / FC) lanes
 template <int FC = 32, int FLn = FL>
 __device__ inline double chunk_sum(const float *__restrict__ partial, int g, int K, int k, int C, int c, int nchunk,
@@ -337,8 +255,6 @@ __device__ inline double chunk_sum(const float *__restrict__ partial, int g, int
 }
 // channels per workgroup of the <FC> finalize kernels by the number of rows to add
 inline int pick_fc(int nchunk) {
-    static const int force = getenv("RDFC_NORM_FC") ? atoi(getenv("RDFC_NORM_FC")) : 0;      // A/B knob: 4 | 8 | 32
-    if (force == 4 || force == 8 || force == 32) return force;
     return nchunk <= 256 ? 32 : (nchunk <= 1024 ? 8 : 4);
 }
 #define RDFC_FC_DISPATCH(fc, ...)                                   \
@@ -490,31 +406,13 @@ __global__ __launch_bounds__(NT) void apply_kernel(Map m, ApplyArgs a, const T *
         ROW_LOOP(cx, body);
 }
 
-// the last-arriving workgroup of a per-channel sum launch (fold.h): sums[g][k][c] = totals; optionally acc[c] += total of k = 0 (one
-// group: a bias gradient straight into its .grad; atomic because a parameter's two uses per step may run their backward on
-// different streams)
-template <int K>
-__device__ inline void finish_sums(const fold::Args &fa, int C, int g, int chunk, const float *partial, float *sums, float *acc0) {
-    fold::arrive<K>(fa, g, chunk, C, partial + (size_t)g * fa.nchunk * K * C, [&](int c, const double (&s)[K]) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) sums[((size_t)g * K + k) * C + c] = (float)s[k];
-        if (acc0 != nullptr) atomicAdd(&acc0[c], (float)s[0]);
-    });
-}
-
 // backward pass 1: sums of du, du*xhat, dz*min(u,0)
-#ifndef RDFC_NORM_BR_WAVES
-#define RDFC_NORM_BR_WAVES 3
-#endif
-#ifndef RDFC_NORM_BR_ROWS
-#define RDFC_NORM_BR_ROWS 2
-#endif
 // RES: a residual map joins the pre-activation; PRELU: the slope's gradient (third sum) is wanted -- compile-time, so the common
 // layer (neither) carries no registers for them: 4 waves per SIMD with two trips of rows in flight
 template <typename T, bool RES, bool PRELU>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RDFC_NORM_BR_WAVES))) void bwd_reduce_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void bwd_reduce_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
                                                         const T *__restrict__ res, float *__restrict__ partial, int lddz,
-                                                        int ldx, int ldr, fold::Args fa, float *__restrict__ sums) {
+                                                        int ldx, int ldr) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[3][VEC];
@@ -564,19 +462,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RDFC_NORM_BR
                 if constexpr (PRELU) s[2][v] += d * fminf(u, 0.f);
             }
         };
-#ifdef RDFC_NORM_NO_PF
-        auto body = [&](int p) { add(fetch(p)); };
-        ROW_LOOP(cx, body);
-#else
-        row_loop_pf<RDFC_NORM_BR_ROWS>(cx, fetch, add);
-#endif
+        row_loop_pf<2>(cx, fetch, add);
         float rs[VEC];                                        // (loaded here, not held across the loop: registers)
         load_consts<VEC>(a.rstd, cx.g * m.C + cx.c0, 1.f, rs);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) s[1][v] *= rs[v];
     }
     block_reduce_store<T, 3>(cx, m, s, partial);
-    if (FOLD_COMPILED && fa.cnt != nullptr) finish_sums<3>(fa, m.C, cx.g, cx.chunk, partial, sums, nullptr);
 }
 
 template <int FC>
@@ -687,7 +579,7 @@ template <typename T>
 __global__ __launch_bounds__(NT) void adain_bwd_reduce_kernel(Map m, const float *__restrict__ mean, const float *__restrict__ rstd,
                                                               const T *__restrict__ dout, const T *__restrict__ x,
                                                               const T *__restrict__ gbm, float *__restrict__ partial, int lddo,
-                                                              int ldx, int ldgb, fold::Args fa, float *__restrict__ sums) {
+                                                              int ldx, int ldgb) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[3][VEC];
@@ -714,7 +606,6 @@ __global__ __launch_bounds__(NT) void adain_bwd_reduce_kernel(Map m, const float
         ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 3>(cx, m, s, partial);
-    if (FOLD_COMPILED && fa.cnt != nullptr) finish_sums<3>(fa, m.C, cx.g, cx.chunk, partial, sums, nullptr);
 }
 
 template <typename T>
@@ -762,8 +653,7 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(Map m, const float 
 // ------------------------------------------------------------------------------------------
 // per-channel sum.  Vector path (C a multiple of the 16-byte vector): the common Ctx mapping, K = 1.
 template <typename T>
-__global__ __launch_bounds__(NT) void chsum_vec_kernel(Map m, int ld, const T *__restrict__ x, float *__restrict__ partial, fold::Args fa,
-                                                       float *__restrict__ out, float *__restrict__ acc) {
+__global__ __launch_bounds__(NT) void chsum_vec_kernel(Map m, int ld, const T *__restrict__ x, float *__restrict__ partial) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
     float s[1][VEC];
@@ -780,12 +670,10 @@ __global__ __launch_bounds__(NT) void chsum_vec_kernel(Map m, int ld, const T *_
         ROW_LOOP(cx, body);
     }
     block_reduce_store<T, 1>(cx, m, s, partial);
-    if (FOLD_COMPILED && fa.cnt != nullptr) finish_sums<1>(fa, m.C, 0, cx.chunk, partial, out, acc);
 }
 // scalar path (C = 1, 3, ...): thread t -> channel t % Cb, rows t / Cb
 template <typename T>
-__global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, int chunk, const T *__restrict__ x, float *__restrict__ partial,
-                                                   fold::Args fa, float *__restrict__ out, float *__restrict__ acc) {
+__global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, int chunk, const T *__restrict__ x, float *__restrict__ partial) {
     const int slab0 = blockIdx.z * NT, Cb = min(C - slab0, NT), RPB = NT / Cb;
     const int t = threadIdx.x, c = slab0 + t % Cb, r0 = t / Cb;
     const bool active = t < RPB * Cb;
@@ -799,9 +687,8 @@ __global__ __launch_bounds__(NT) void chsum_kernel(int P, int C, int ld, int chu
     if (active && r0 == 0) {
         float a = 0.f;
         for (int r = 0; r < RPB; ++r) a += red[r * Cb + t];
-        fold::st_f32(&partial[(size_t)blockIdx.x * C + c], a);
+        partial[(size_t)blockIdx.x * C + c] = a;
     }
-    if (FOLD_COMPILED && fa.cnt != nullptr) finish_sums<1>(fa, C, 0, blockIdx.x, partial, out, acc);
 }
 
 template <typename T>
@@ -828,35 +715,14 @@ int check_map(const char *who, int G, int P, int C, int dtype, std::initializer_
 
 #define DISPATCH(dtype, ...) RDFC_DISPATCH(dtype, __VA_ARGS__)
 
-// ---- folded second stage (fold.h): scratch layout [partials f32: G * nchunk * K * C | pad to 8 bytes | level-2 rows f64 | f64 [G][2][C]]
+// scratch of a two-stage reduction: [partials f32: G * nchunk * K * C | pad to 8 bytes | f64 [G][2][C] (stacked-batch BatchNorm: mean /
+// variance per group, handed from the finalize launch to the normalise pass)]
 namespace {
-const fold::Args NO_FOLD{nullptr, nullptr, 0, 1, 1};
-// Opt-in (RDFC_NORM_FOLD=1).  Measured on MI355X (profiles/r04_fold_experiment.txt): the folded tail is a chain of dependent memory round
-// trips (write-through drain, ticket, row loads; twice for two levels) of ~15 us alone against 5-14 us for the finalize launch it
-// replaces, and the step is no faster with it (36.7 vs 36.3 ms): the separate launches stay the default.
-const bool g_fold_on = getenv("RDFC_NORM_FOLD") != nullptr && atoi(getenv("RDFC_NORM_FOLD")) != 0;
-
 inline size_t part_floats(int G, int nchunk, int K, int C) { return ((size_t)G * nchunk * K * C + 1) & ~(size_t)1; }
-// -> false (and fa.cnt == nullptr) when this launch keeps its finalize launch: more than one channel slab per workgroup row, the switch off
-bool plan_fold(int G, int nchunk, int K, int C, int nslab, float *scratch, int extra_counters, hipStream_t st, fold::Args &fa, double *&tail, unsigned *&extra) {
-    fa = NO_FOLD;
-    tail = nullptr;
-    extra = nullptr;
-    if (!g_fold_on || nslab != 1) return false;
-    int gs, ng;
-    fold::shape(nchunk, gs, ng);
-    unsigned *cnt = rdfc_fold_counters(G * (1 + ng) + extra_counters, st);
-    if (cnt == nullptr) return false;
-    double *l2 = reinterpret_cast<double *>(scratch + part_floats(G, nchunk, K, C));
-    fa = fold::Args{cnt, l2, nchunk, gs, ng};
-    tail = l2 + fold::l2_doubles(G, nchunk, K * C);
-    extra = cnt + G * (1 + ng);
-    return true;
-}
 }  // namespace
 
-extern "C" int rdfc_fold_scratch_floats(int G, int nchunk, int K, int C) {
-    return (int)(part_floats(G, nchunk, K, C) + 2 * (fold::l2_doubles(G, nchunk, K * C) + (size_t)G * 2 * C));
+extern "C" int rdfc_norm_scratch_floats(int G, int nchunk, int K, int C) {
+    return (int)(part_floats(G, nchunk, K, C) + 2 * ((size_t)G * 2 * C));
 }
 
 extern "C" int rdfc_norm_nchunk(int pixels_per_group, int C, int dtype) {
@@ -866,8 +732,7 @@ extern "C" int rdfc_norm_nchunk(int pixels_per_group, int C, int dtype) {
 extern "C" int rdfc_norm_stats(const void *x, float *partial, int G, int P, int C, int ld, int dtype, void *stream) {
     if (int e = check_map("rdfc_norm_stats", G, P, C, dtype, {ld})) return e;
     Map m = make_map(G, P, C, rdfc_vec(dtype));
-    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld, partial,
-                                       NO_FOLD, FinStats{}));
+    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ld, partial));
     RDFC_LAUNCH_CHECK("rdfc_norm_stats");
     return 0;
 }
@@ -954,10 +819,10 @@ extern "C" int rdfc_norm_finalize_apply_seq(const float *partial, int nchunk, do
 
 template <typename T>
 static void launch_bwd_reduce_t(const Map &m, const ApplyArgs &a, const void *dz, const void *x, const void *res, float *partial, int lddz,
-                                int ldx, int ldr, const fold::Args &fa, float *sums, hipStream_t st) {
+                                int ldx, int ldr, hipStream_t st) {
     const dim3 grid = grid_for(m, Elem<T>::VEC);
     const bool pr = a.act == RDFC_ACT_PRELU;
-#define RDFC_BR(R, P_) hipLaunchKernelGGL((bwd_reduce_kernel<T, R, P_>), grid, dim3(NT), 0, st, m, a, (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr, fa, sums)
+#define RDFC_BR(R, P_) hipLaunchKernelGGL((bwd_reduce_kernel<T, R, P_>), grid, dim3(NT), 0, st, m, a, (const T *)dz, (const T *)x, (const T *)res, partial, lddz, ldx, ldr)
     if (res != nullptr) {
         if (pr) RDFC_BR(true, true); else RDFC_BR(true, false);
     } else {
@@ -966,8 +831,8 @@ static void launch_bwd_reduce_t(const Map &m, const ApplyArgs &a, const void *dz
 #undef RDFC_BR
 }
 static void launch_bwd_reduce(int dtype, const Map &m, const ApplyArgs &a, const void *dz, const void *x, const void *res, float *partial,
-                              int lddz, int ldx, int ldr, const fold::Args &fa, float *sums, void *stream) {
-    DISPATCH(dtype, launch_bwd_reduce_t<T>(m, a, dz, x, res, partial, lddz, ldx, ldr, fa, sums, (hipStream_t)stream));
+                              int lddz, int ldx, int ldr, void *stream) {
+    DISPATCH(dtype, launch_bwd_reduce_t<T>(m, a, dz, x, res, partial, lddz, ldx, ldr, (hipStream_t)stream));
 }
 
 extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
@@ -976,7 +841,7 @@ extern "C" int rdfc_norm_bwd_reduce(const void *dz, const void *x, const float *
     if (int e = check_map("rdfc_norm_bwd_reduce", G, P, C, dtype, {lddz, ldx})) return e;
     Map m = make_map(G, P, C, rdfc_vec(dtype));
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
-    launch_bwd_reduce(dtype, m, a, dz, x, res, partial, lddz, ldx, ldr, NO_FOLD, nullptr, stream);
+    launch_bwd_reduce(dtype, m, a, dz, x, res, partial, lddz, ldx, ldr, stream);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_reduce");
     return 0;
 }
@@ -1023,40 +888,25 @@ extern "C" int rdfc_norm_bwd_apply(const void *dz, const void *x, const float *m
 // ---- composites: the launches of one layer's forward / backward behind ONE call (the step makes ~360 of them and is partly
 //      launch-bound; a ctypes call costs the host ~4-5 us).  Same kernels, same order, same stream.
 //      scratch (f32): forward [G * nchunk * 2 * C] partials; backward [G * nchunk * 3 * C] partials.
-// statistics with the finalize folded into the launch (fold.h) -> mean / rstd (+ running statistics); scratch: rdfc_fold_scratch_floats(G, nchunk, 2, C)
-static int stats_folded(const void *x, float *scratch, float *mean, float *rstd, int G, int P, int C, int ldx, int dtype, float eps, float *run_mean,
-                        float *run_var, float momentum, const float *group_momentum, void *stream) {
+// statistics + finalize -> mean / rstd (+ running statistics); scratch: rdfc_norm_scratch_floats(G, nchunk, 2, C)
+static int stats_final(const void *x, float *scratch, float *mean, float *rstd, int G, int P, int C, int ldx, int dtype, float eps, float *run_mean,
+                       float *run_var, float momentum, void *stream) {
     if (int e = check_map("rdfc_norm_forward", G, P, C, dtype, {ldx})) return e;
-    const bool seq = group_momentum != nullptr;
-    RDFC_REQUIRE(!seq || G <= MAXSEQ, "rdfc_norm_forward_seq: 1 <= G <= %d groups", MAXSEQ);
-    RDFC_REQUIRE(run_mean == nullptr || seq || G == 1, "rdfc_norm_forward: running statistics need G == 1 (batch norm)");
-    Map m = make_map(G, P, C, rdfc_vec(dtype));
-    const int nchunk = cdiv(P, m.chunk);
-    fold::Args fa;
-    double *muvar;
-    unsigned *cnt_all;
-    if (!plan_fold(G, nchunk, 2, C, cdiv(C / rdfc_vec(dtype), NT), scratch, 1, (hipStream_t)stream, fa, muvar, cnt_all)) {
-        if (int e = rdfc_norm_stats(x, scratch, G, P, C, ldx, dtype, stream)) return e;
-        if (seq) return rdfc_norm_finalize_seq(scratch, 0, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, group_momentum, stream);
-        return rdfc_norm_finalize(scratch, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, momentum, stream);
-    }
-    FinStats fs{mean, rstd, eps, run_mean, run_var, momentum, seq ? 1 : 0, Moms{}, muvar, cnt_all};
-    for (int g = 0; seq && g < G; ++g) fs.moms.m[g] = group_momentum[g];
-    DISPATCH(dtype, hipLaunchKernelGGL(stats_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, (const T *)x, ldx, scratch, fa, fs));
-    RDFC_LAUNCH_CHECK("rdfc_norm_forward (statistics)");
-    return 0;
+    RDFC_REQUIRE(run_mean == nullptr || G == 1, "rdfc_norm_forward: running statistics need G == 1 (batch norm)");
+    if (int e = rdfc_norm_stats(x, scratch, G, P, C, ldx, dtype, stream)) return e;
+    return rdfc_norm_finalize(scratch, mean, rstd, G, P, C, dtype, eps, run_mean, run_var, momentum, stream);
 }
 
 extern "C" int rdfc_norm_stats_final(const void *x, float *scratch, float *mean, float *rstd, int G, int P, int C, int ld, int dtype, float eps,
                                      float *run_mean, float *run_var, float momentum, void *stream) {
-    return stats_folded(x, scratch, mean, rstd, G, P, C, ld, dtype, eps, run_mean, run_var, momentum, nullptr, stream);
+    return stats_final(x, scratch, mean, rstd, G, P, C, ld, dtype, eps, run_mean, run_var, momentum, stream);
 }
 
 extern "C" int rdfc_norm_forward(const void *x, float *scratch, float *mean, float *rstd, const float *gamma, const float *beta,
                                  const void *res, void *z, int G, int P, int C, int ldx, int ldr, int ldz, int dtype, float eps,
                                  float *run_mean, float *run_var, float momentum, int act, float slope, const float *prelu,
                                  void *stream) {
-    if (int e = stats_folded(x, scratch, mean, rstd, G, P, C, ldx, dtype, eps, run_mean, run_var, momentum, nullptr, stream)) return e;
+    if (int e = stats_final(x, scratch, mean, rstd, G, P, C, ldx, dtype, eps, run_mean, run_var, momentum, stream)) return e;
     return rdfc_norm_apply(x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, act, slope, prelu, stream);
 }
 
@@ -1065,14 +915,9 @@ extern "C" int rdfc_norm_forward_seq(const void *x, float *scratch, float *mean,
                                      float *run_mean, float *run_var, const float *group_momentum, int act, float slope,
                                      const float *prelu, void *stream) {
     static const float zeros[MAXSEQ] = {0};
-    if (g_fold_on) {
-        if (int e = stats_folded(x, scratch, mean, rstd, G, P, C, ldx, dtype, eps, run_mean, run_var, 0.f, group_momentum ? group_momentum : zeros, stream))
-            return e;
-        return rdfc_norm_apply(x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, act, slope, prelu, stream);
-    }
     if (int e = rdfc_norm_stats(x, scratch, G, P, C, ldx, dtype, stream)) return e;
     const int nchunk = rdfc_norm_nchunk(P, C, dtype);
-    double *muvar = reinterpret_cast<double *>(scratch + part_floats(G, nchunk, 2, C)) + fold::l2_doubles(G, nchunk, 2 * C);
+    double *muvar = reinterpret_cast<double *>(scratch + part_floats(G, nchunk, 2, C));
     return rdfc_norm_finalize_apply_seq(scratch, nchunk, muvar, x, mean, rstd, gamma, beta, res, z, G, P, C, ldx, ldr, ldz, dtype, eps, run_mean,
                                         run_var, group_momentum ? group_momentum : zeros, act, slope, prelu, stream);
 }
@@ -1084,21 +929,11 @@ extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *me
     if (int e = check_map("rdfc_norm_backward", G, P, C, dtype, {lddz, ldx, lddx})) return e;
     RDFC_REQUIRE(dbeta_acc != nullptr || dgamma_acc == nullptr, "rdfc_norm_backward: d gamma accumulates together with d beta");
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
-    {   // pass 1: the three sums, finalized by the launch's last-arriving workgroup
+    {   // pass 1: the three sums (partial rows, then the fixed-order finalize launch)
         Map m = make_map(G, P, C, rdfc_vec(dtype));
-        fold::Args fa;
-        double *tail_;
-        unsigned *extra_;
-        const bool folded = plan_fold(G, cdiv(P, m.chunk), 3, C, cdiv(C / rdfc_vec(dtype), NT), scratch, 0, (hipStream_t)stream, fa, tail_, extra_);
-#ifdef RDFC_EXP_SKIP_BWD_REDUCE      // timing-only experiment (results are wrong): what the backward sums + their finalize cost the step
-        (void)folded;
-        hipMemsetAsync(sums, 0, (size_t)G * 3 * C * 4, (hipStream_t)stream);
-#else
-        launch_bwd_reduce(dtype, m, a, dz, x, res, scratch, lddz, ldx, ldr, fa, sums, stream);
+        launch_bwd_reduce(dtype, m, a, dz, x, res, scratch, lddz, ldx, ldr, stream);
         RDFC_LAUNCH_CHECK("rdfc_norm_backward (sums)");
-        if (!folded)
-            if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, nullptr, nullptr, stream)) return e;
-#endif
+        if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, nullptr, nullptr, stream)) return e;
     }
     // (the affine gradients are accumulated by the apply pass, which reads the sums anyway: the groups in group order)
     Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
@@ -1125,7 +960,7 @@ extern "C" int rdfc_adain_bwd_reduce(const void *dout, const void *x, const floa
     if (int e = check_map("rdfc_adain_bwd_reduce", N, P, C, dtype, {lddo, ldx})) return e;
     Map m = make_map(N, P, C, rdfc_vec(dtype));
     DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
-                                       mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, partial, lddo, ldx, ldgb, NO_FOLD, (float *)nullptr));
+                                       mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, partial, lddo, ldx, ldgb));
     RDFC_LAUNCH_CHECK("rdfc_adain_bwd_reduce");
     return 0;
 }
@@ -1142,21 +977,16 @@ extern "C" int rdfc_adain_bwd_apply(const void *dout, const void *x, const float
     return 0;
 }
 
-// W-AdaIN backward in one call: the sums (finalized inside the launch) + the apply pass.  scratch: rdfc_fold_scratch_floats(N, nchunk, 3, C)
+// W-AdaIN backward in one call: the sums + their finalize + the apply pass.  scratch: rdfc_norm_scratch_floats(N, nchunk, 3, C)
 extern "C" int rdfc_adain_backward(const void *dout, const void *x, const float *mean, const float *rstd, const void *gb, float *scratch,
                                    float *sums, void *dx, void *dgb, int N, int P, int C, int lddo, int ldx, int ldgb, int lddx, int lddgb,
                                    int dtype, void *stream) {
     if (int e = check_map("rdfc_adain_backward", N, P, C, dtype, {lddo, ldx, lddx})) return e;
     Map m = make_map(N, P, C, rdfc_vec(dtype));
-    fold::Args fa;
-    double *tail_;
-    unsigned *extra_;
-    const bool folded = plan_fold(N, cdiv(P, m.chunk), 3, C, cdiv(C / rdfc_vec(dtype), NT), scratch, 0, (hipStream_t)stream, fa, tail_, extra_);
     DISPATCH(dtype, hipLaunchKernelGGL(adain_bwd_reduce_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m,
-                                       mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, scratch, lddo, ldx, ldgb, fa, sums));
+                                       mean, rstd, (const T *)dout, (const T *)x, (const T *)gb, scratch, lddo, ldx, ldgb));
     RDFC_LAUNCH_CHECK("rdfc_adain_backward (sums)");
-    if (!folded)
-        if (int e = rdfc_norm_bwd_finalize(scratch, sums, N, P, C, dtype, stream)) return e;
+    if (int e = rdfc_norm_bwd_finalize(scratch, sums, N, P, C, dtype, stream)) return e;
     return rdfc_adain_bwd_apply(dout, x, mean, rstd, gb, sums, dx, dgb, N, P, C, lddo, ldx, ldgb, lddx, lddgb, dtype, stream);
 }
 
@@ -1174,7 +1004,7 @@ static int channel_sum_geometry(int P, int C, int ld, int dtype, bool &vecpath, 
 extern "C" int rdfc_channel_sum_scratch_floats(int P, int C, int ld, int dtype) {
     bool vp;
     int chunk;
-    return rdfc_fold_scratch_floats(1, channel_sum_geometry(P, C, ld, dtype, vp, chunk), 1, C);
+    return rdfc_norm_scratch_floats(1, channel_sum_geometry(P, C, ld, dtype, vp, chunk), 1, C);
 }
 
 extern "C" int rdfc_channel_sum_acc(const void *x, float *partial, float *out, float *acc, int P, int C, int ld, int dtype, void *stream) {
@@ -1183,19 +1013,14 @@ extern "C" int rdfc_channel_sum_acc(const void *x, float *partial, float *out, f
     bool vecpath;
     int chunk;
     const int nchunk = channel_sum_geometry(P, C, ld, dtype, vecpath, chunk), vec = rdfc_vec(dtype);
-    fold::Args fa;
-    double *tail_;
-    unsigned *extra_;
-    const bool folded = plan_fold(1, nchunk, 1, C, cdiv(vecpath ? C / vec : C, NT), partial, 0, (hipStream_t)stream, fa, tail_, extra_);
     if (vecpath) {
         Map m = make_map(1, P, C, vec);
-        DISPATCH(dtype, hipLaunchKernelGGL(chsum_vec_kernel<T>, grid_for(m, vec), dim3(NT), 0, (hipStream_t)stream, m, ld, (const T *)x, partial, fa, out, acc));
+        DISPATCH(dtype, hipLaunchKernelGGL(chsum_vec_kernel<T>, grid_for(m, vec), dim3(NT), 0, (hipStream_t)stream, m, ld, (const T *)x, partial));
     } else {
         dim3 grid(nchunk, 1, cdiv(C, NT));
-        DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, chunk, (const T *)x, partial, fa, out, acc));
+        DISPATCH(dtype, hipLaunchKernelGGL(chsum_kernel<T>, grid, dim3(NT), 0, (hipStream_t)stream, P, C, ld, chunk, (const T *)x, partial));
     }
-    if (!folded)
-        RDFC_FC_DISPATCH(pick_fc(nchunk), hipLaunchKernelGGL(sum_finalize_kernel<FC>, dim3(cdiv(C, FC), 1), dim3(FNT2), 0, (hipStream_t)stream, 1, C, 1, nchunk,
+    RDFC_FC_DISPATCH(pick_fc(nchunk), hipLaunchKernelGGL(sum_finalize_kernel<FC>, dim3(cdiv(C, FC), 1), dim3(FNT2), 0, (hipStream_t)stream, 1, C, 1, nchunk,
                                                              partial, out, acc, nullptr));
     RDFC_LAUNCH_CHECK("rdfc_channel_sum");
     return 0;

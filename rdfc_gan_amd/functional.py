@@ -59,7 +59,6 @@ _pack_reg = {}          # (data_ptr, dtype, scale) -> _Pack
 _pack_tables = {}       # (lo, hi, dtype) -> (registry generation, device job table, njobs, nblocks, entries)
 _pack_generation = 0    # bumped whenever an entry is added or replaced
 pack_misses = 0         # single-weight pack launches so far (diagnostic: a steady-state step has none)
-_BATCH_PACK = os.environ.get('RDFC_BATCH_PACK', '1') != '0'
 
 
 def _packed(weight, dtype, scale):
@@ -93,7 +92,7 @@ def weights_updated(flat):
     """FlatAdam.step() changed the weights stored in `flat` (behind autograd's back, on the current stream, every helper stream
     joined): rebuild the packed operands the step has been using, all in one launch (rdfc_pack_weights_batch) into the buffers
     they already have -- instead of ~80 small launches at their next first uses.  Operands outside `flat` stay as they are."""
-    if not (_BATCH_PACK and flat.is_cuda) or torch.cuda.is_current_stream_capturing():
+    if not flat.is_cuda or torch.cuda.is_current_stream_capturing():
         invalidate_packed_weights()
         return
     lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
@@ -122,10 +121,7 @@ def _accumulable(g):
 # have to sit in the backward chain: it is launched on a second HIP stream (forked behind the kernel that produced dy)
 # and the MFMA-bound split-K GEMM overlaps the HBM-bound normalisation kernels of the layers below.  join_side_stream()
 # brings the streams back together; FlatAdam calls it before it touches the gradients.  RDFC_WGRAD_STREAM=0 disables it.
-_REFLECT_FOLD = os.environ.get('RDFC_REFLECT_FOLD', '1') != '0'      # A/B: reflection pads folded into the conv loaders
 _WGRAD_STREAM = os.environ.get('RDFC_WGRAD_STREAM', '1') != '0'
-_PRIO_HELPER = int(os.environ.get('RDFC_PRIO_HELPER', '0'))     # HIP stream priorities (lower = more urgent) for experiments
-_PRIO_WGRAD = int(os.environ.get('RDFC_PRIO_WGRAD', '0'))
 _multi_stream = True        # False while a step is captured into / replayed from HIP graphs (single-stream capture)
 
 
@@ -150,7 +146,7 @@ _side = {}          # device -> [stream, list of tensors the pending launches st
 def _side_stream(device):
     s = _side.get(device)
     if s is None:
-        s = _side[device] = [torch.cuda.Stream(device=device, priority=_PRIO_WGRAD), []]
+        s = _side[device] = [torch.cuda.Stream(device=device), []]
     return s
 
 
@@ -161,7 +157,7 @@ def branch_stream(device):
     """second compute stream for an independent branch of a network (RDFGenerator's depth branch)"""
     s = _branch.get(device)
     if s is None:
-        s = _branch[device] = torch.cuda.Stream(device=device, priority=_PRIO_HELPER)
+        s = _branch[device] = torch.cuda.Stream(device=device)
     return s
 
 
@@ -172,7 +168,7 @@ def net_stream(device):
     """third compute stream: the half of the train step that does not depend on the other (RDFCGAN: the B->A chain)"""
     s = _net.get(device)
     if s is None:
-        s = _net[device] = torch.cuda.Stream(device=device, priority=_PRIO_HELPER)
+        s = _net[device] = torch.cuda.Stream(device=device)
     return s
 
 
@@ -317,7 +313,7 @@ class _ConvBlock(torch.autograd.Function):
             # weight gradient), else an explicit pad pass in front of the pad-0 conv
             d = hip.conv_desc(x.shape, Cout, spec.k, 1, spec.reflect, 1, ldx=hip.ld(x), ldy=Cout, dtype=hip.dt(x),
                               act=epi_act, slope=spec.slope, out_f32=out_f32)
-            folded = x.is_cuda and _REFLECT_FOLD and hip.conv_reflect_supported(d)
+            folded = x.is_cuda and hip.conv_reflect_supported(d)
             x_alias = x
             if folded:
                 hip.conv_forward(d, x, wf, bias, y, reflect=True)
@@ -552,12 +548,8 @@ class _CropCat(torch.autograd.Function):
         N, Hd, Wd, Cd = ctx.fd_shape
         _, He, We, _ = dout.shape
         g_fe = dout[..., Cd:]                       # channel slice: consumers take ld > C
-        if os.environ.get('RDFC_DEBUG_CONTIG'):
-            g_fe = g_fe.contiguous()
         if (Hd, Wd) == (He, We):
             g_fd = dout[..., :Cd]
-            if os.environ.get('RDFC_DEBUG_CONTIG'):
-                g_fd = g_fd.contiguous()
         else:
             g_fd = hip.zero_(torch.empty(N, Hd, Wd, Cd, dtype=dout.dtype, device=dout.device))
             hip.copy_window(dout[..., :Cd], g_fd)
@@ -683,7 +675,6 @@ class _FanOut(torch.autograd.Function):
         return hip.sum_maps(live), None, None
 
 
-_CHAINED = os.environ.get('RDFC_FANOUT_CHAIN', '1') != '0'
 
 
 def fanout(x, n, chained=False):
@@ -691,7 +682,7 @@ def fanout(x, n, chained=False):
     consumers' input-gradient launches instead (_Chain)"""
     if n <= 1 or not x.requires_grad:
         return (x,) * n
-    if chained and _CHAINED and x.is_cuda:
+    if chained and x.is_cuda:
         chain = _Chain(n)
         outs = _FanOut.apply(x, n, chain)
         for o in outs:

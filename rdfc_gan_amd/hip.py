@@ -26,9 +26,6 @@ PROFILE = None
 # one C call per kernel with a HIP event pair around each: (kernel, algorithmic bytes, start, end, launches) -- the HBM-roofline
 # entries of the bench line ("each reported as achieved GB/s / 8 TB/s")
 PROFILE_HBM = None
-# Timing-only experiments (results are WRONG): RDFC_EXP_SKIP=a,b,... makes the named wrappers return without launching, to size what a
-# fusion of that pass could gain at most before building it (profiles/r04_experiments.txt).  Never set outside tools/.
-_EXP_SKIP = frozenset(x for x in os.environ.get('RDFC_EXP_SKIP', '').split(',') if x)
 ACT = dict(none=0, relu=1, lrelu=2, tanh=3, sigmoid=4, prelu=5)
 _lib = None
 
@@ -393,8 +390,6 @@ def conv_wgrad(d, x, dy, into=None, stream=None, reflect=False):
     stream: raw HIP stream handle to launch on (default: the current stream)
     reflect: d.ph = d.pw is a REFLECTION padding of x (conv_reflect_supported(d) must hold)"""
     dw = into if into is not None else torch.zeros(d.Co, d.KH * d.KW, d.Ci, dtype=torch.float32, device=x.device)
-    if 'wgrad' in _EXP_SKIP:
-        return dw
     fn, name = (lib().rdfc_conv2d_wgrad_reflect, 'rdfc_conv2d_wgrad_reflect') if reflect else (lib().rdfc_conv2d_wgrad, 'rdfc_conv2d_wgrad')
     if stream is not None and PROFILE is None:
         _chk(fn(C.byref(d), _p(x), _p(dy), _p(dw), stream), name)
@@ -445,8 +440,6 @@ def copy_window(src, dst, accumulate=False):
     N, Hs, Ws, Cc = src.shape
     _, Hd, Wd, Cd = dst.shape
     assert Cc == Cd and src.dtype == dst.dtype
-    if 'copy_window' in _EXP_SKIP:
-        return dst
     _chk(lib().rdfc_copy_window(_p(src), _p(dst), N, Hs, Ws, Hd, Wd, min(Hs, Hd), min(Ws, Wd), Cc, ld(src), ld(dst),
                                 dt(src), int(accumulate), _st()), 'rdfc_copy_window')
     return dst
@@ -490,11 +483,11 @@ _fold_cache = {}
 
 
 def fold_scratch(G, nchunk, K, Cc):
-    """f32 elements of scratch a folded two-stage reduction needs (partial rows + level-2 rows: csrc/fold.h)"""
+    """f32 elements of scratch a two-stage reduction needs (partial rows + the f64 per-group statistics of a stacked-batch BatchNorm)"""
     key = (G, nchunk, K, Cc)
     n = _fold_cache.get(key)
     if n is None:
-        n = _fold_cache[key] = lib().rdfc_fold_scratch_floats(G, nchunk, K, Cc)
+        n = _fold_cache[key] = lib().rdfc_norm_scratch_floats(G, nchunk, K, Cc)
     return n
 
 
@@ -569,8 +562,6 @@ def norm_apply(x, mean, rstd, gamma, beta, res, z, act='none', slope=0.0, prelu=
     N, H, W, Cc = x.shape
     G = mean.shape[0]
     P = N * H * W // G
-    if 'apply' in _EXP_SKIP:
-        return z
     _chk(lib().rdfc_norm_apply(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), _p(z), G, P, Cc, ld(x),
                                ld(res) if res is not None else 0, ld(z), dt(x), ACT[act], _f(slope), _p(prelu), _st()),
          'rdfc_norm_apply')
@@ -641,8 +632,6 @@ def channel_sum(x, acc=None):
 
 def act_bwd(dy, y, act, slope=0.0):
     N, H, W, Cc = dy.shape
-    if 'act_bwd' in _EXP_SKIP:
-        return dy.contiguous()
     dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
     _chk(lib().rdfc_act_bwd(_p(dy), _p(y), _p(dx), N * H * W, Cc, ld(dy), ld(y), Cc, dt(dy), int(y.dtype == torch.float32),
                             ACT[act], _f(slope), _st()), 'rdfc_act_bwd')
@@ -783,8 +772,6 @@ def sum_maps(maps, out=None):
         out = torch.empty(N, H, W, Cc, dtype=m0.dtype, device=m0.device)
     n = len(maps)
     assert 1 <= n <= 4 and all(m.shape == m0.shape and m.dtype == m0.dtype for m in maps)
-    if 'sum_maps' in _EXP_SKIP:
-        return m0 if m0.is_contiguous() else out
     ptrs = (C.c_void_p * n)(*[m.data_ptr() for m in maps])
     lds = (C.c_int * n)(*[ld(m) for m in maps])
     _chk(lib().rdfc_sum_maps(n, ptrs, lds, _p(out), N * H * W, Cc, ld(out), dt(m0), _st()), 'rdfc_sum_maps')

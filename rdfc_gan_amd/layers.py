@@ -67,7 +67,6 @@ def _count_batch(norm, k):
 
 
 _spec_cache = {}
-_CAT_INTO = os.environ.get('RDFC_CAT_INTO', '1') != '0'
 
 
 def run_conv(x, conv, norm=None, act=None, res=None, out_f32=False, passthrough=False, reflect=0, cat_with=None):
@@ -130,9 +129,7 @@ class ConvSeq(nn.Sequential):
 
     def forward(self, x, res=None, out_f32=False, cat_with=None):
         """cat_with: -> cat((block(x), cat_with), channels) with the block writing its part of the concatenation in place (blocks with a
-        normalisation layer, equal map sizes; RDFC_CAT_INTO=0: a separate concatenation pass, for A/B runs)"""
-        if cat_with is not None and not _CAT_INTO:
-            return Fh.crop_cat(self.forward(x, res, out_f32), cat_with)
+        normalisation layer, equal map sizes)"""
         conv, norm, act = self[0], None, None
         for m in list(self)[1:]:
             if isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d)):

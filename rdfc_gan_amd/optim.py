@@ -121,7 +121,6 @@ class FlatAdam(torch.optim.Optimizer):
         self._buckets = [[(0, n)]]
         self._started = set()
         self.started_order = []       # bucket indices in the order their exchange was started in the current step (tests read it)
-        self._comm_stream = None
         self._hyper = None            # device {lr, step}: set by make_capturable(); the step then launches rdfc_adam_step_dev
         self._hyper_lr = None
         self.host_counts = True       # False while a captured graph replays step(): the caller advances self.steps
@@ -224,7 +223,6 @@ class FlatAdam(torch.optim.Optimizer):
         a compute stream and its waits stall that stream.  One-rank RCCL runs of bench.py: 38.7 ms per step without a process
         group, 41.3 with one and a communication stream per optimizer, 40.3-40.9 once the compute streams are bound to their
         queues first -- functional.reserve_streams -- with either scheme)
-        RDFC_DP_COMM=stream keeps the round-1 scheme (a communication stream per optimizer) for A/B runs.
         helpers=False: the bucket's gradients come from the current stream and the weight-gradient stream only (the
         discriminators' step beside G's backward): do not wait for what the other helper streams are still running.
         after: events the collective must also follow -- a bucket started from inside a backward is started by the LAST of several
@@ -242,23 +240,6 @@ class FlatAdam(torch.optim.Optimizer):
             return
         dev = self.flat_grad.device
         cur = torch.cuda.current_stream(dev)
-        if _DP_COMM == 'stream':
-            if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream()
-            cs = self._comm_stream
-            cs.wait_stream(cur)
-            for e_ in after:
-                cs.wait_event(e_)
-            for s_ in (Fh.helper_streams(dev) if helpers else [Fh.wgrad_stream(dev)]):
-                if s_ is not None:
-                    cs.wait_stream(s_)
-            with torch.cuda.stream(cs):
-                for view in views:
-                    dist.all_reduce(view)
-            ev = torch.cuda.Event()
-            ev.record(cs)
-            self._pending.append(ev)
-            return
         issue = Fh.wgrad_stream(dev) or cur
         if issue != cur:
             issue.wait_stream(cur)
@@ -281,10 +262,7 @@ class FlatAdam(torch.optim.Optimizer):
     def wait_grads(self):
         """the current stream waits for the bucket all-reduces started so far"""
         for w in self._pending:
-            if isinstance(w, torch.cuda.Event):
-                torch.cuda.current_stream().wait_event(w)
-            else:
-                w.wait()
+            w.wait()
         self._pending = []
 
     @torch.no_grad()
@@ -368,7 +346,6 @@ class FlatAdam(torch.optim.Optimizer):
                 self.param_groups[0][k_] = v
 
 
-_DP_COMM = os.environ.get('RDFC_DP_COMM', 'side')
 
 
 def dp_active():

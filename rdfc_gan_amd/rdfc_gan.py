@@ -46,7 +46,6 @@ def norm_normalize(norm_out):
 
 
 _NET_STREAMS = os.environ.get('RDFC_NET_STREAMS', '1') != '0'
-_GLOSS_NET = os.environ.get('RDFC_GLOSS_NET')            # A/B override: '0' | '1' (default: on unless a process group exists)
 # where the discriminators' own step is enqueued (bench.py, bf16, batch 8 at 228x304, three interleaved runs each): '0' behind G's
 # backward on the main / B->A streams as upstream orders it: 37.5-37.6 ms per step; '1' behind it on the host but forked before it
 # on the B->A stream: 37.0-37.2; 'first' (default) enqueued before it on the depth-branch stream: 36.1-36.4
@@ -573,7 +572,7 @@ class RDFCGAN:
         # D_B's G-loss pass on the B->A stream -- unless a process group exists: the runtime has four hardware queues, RCCL's
         # stream needs one, and a compute stream that shares a queue with it stalls behind the collectives' waits
         # (bench.py: 36.45 vs 36.85 ms per step with / without the fourth compute stream; one-rank RCCL 38.6 vs 37.3)
-        gloss_net = (_GLOSS_NET == '1') if _GLOSS_NET is not None else not (dist.is_available() and dist.is_initialized())
+        gloss_net = not (dist.is_available() and dist.is_initialized())
         gloss_net = gloss_net and self._net_streams_on()
         if gloss_net:
             with self._net_stream_ctx():
@@ -713,18 +712,16 @@ class RDFCGAN:
 
     # ---- HIP-graph mode: the step is captured once as three graphs (G step | D step | Adam) and replayed; the
     #      data-parallel all-reduces stay eager between them, the host only draws the pepper mask and copies the batch in
-    def enable_graph(self, enabled=True, multi_stream=False):
-        """multi_stream=False (default): everything is captured on one stream.  True (experimental): the capture keeps the
-        eager step's fork / join structure (RDFGenerator's depth branch, D_B's pass, every weight gradient on helper streams;
-        the event waits between them become edges of the graph).  Measured on ROCm 7.2 / MI355X (round 2): with any ONE
-        helper stream captured the replay works but is no faster than eager launches (46-56 ms per step against 40-44:
-        hipGraphLaunch costs the host about as much per node as a launch), and with all of them hipStreamEndCapture
-        segfaults -- graph mode is therefore not the benchmark's default."""
+    def enable_graph(self, enabled=True):
+        """everything is captured on one stream.  (Round 2 also captured the eager step's fork / join structure over the helper
+        streams: with any ONE helper stream captured the replay works but is no faster than eager launches -- 46-56 ms per step
+        against 40-44, hipGraphLaunch costs the host about as much per node as a launch -- and with all of them
+        hipStreamEndCapture segfaults on ROCm 7.2; that mode was removed in round 5.  Graph mode is not the benchmark's default.)"""
         if enabled and (self.use_label_net or self.G_normal is not None):
             raise NotImplementedError('graph mode captures the four-network step only')
         self._graph_mode = bool(enabled)
         self._graphs = None
-        Fh.set_multi_stream(multi_stream or not enabled)
+        Fh.set_multi_stream(not enabled)
         if enabled:
             for o in self.optimizers.values():
                 o.make_capturable()

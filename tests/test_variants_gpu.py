@@ -17,18 +17,23 @@ VARIANTS = [
     ('RDFC_T3S2', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # transposed 3x3 / stride 2 on igemm_glds' parity classes instead of the patch kernel
     ('RDFC_T3S2', '3', '(test_conv_fwd_dgrad_wgrad or conv_transpose or dgrad_with_addend) and not f32'),   # ... and the patch kernel also on the small launches the default leaves to igemm_glds (its one- and two-addend epilogues included)
     ('RDFC_GLDS_STACK', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # per-image row tiles in the 3x3 kernel
-    # round 4: the finalize of the two-stage reductions folded into the reduction launch (csrc/fold.h; opt-in, measured no faster)
-    ('RDFC_NORM_FOLD', '1', 'test_norm_fwd_bwd or test_adain or stacked_batches or layout_window_pad_sum'),
-    ('RDFC_NORM_FOLD', '1', 'folded', 'test_fold_gpu.py'),
+    # round 5: every tile height of the 128-channel 3x3 / stride-1 kernel (the default picks one per launch: conv_glds.hip glds_plan) on every
+    # conv test incl. fused statistics, reflection fold, addends, stacked batches and the full-size properties
+    ('RDFC_GLDS_JR', '4', 'not f32', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
+    ('RDFC_GLDS_JR', '6', 'not f32', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
+    ('RDFC_GLDS_JR', '8', 'not f32', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
+    ('RDFC_GLDS_JR', '10', 'not f32', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
+    # round 3's ring weight-gradient kernel (round 5's wgrad_ring2 is the default; the two give the same bits: tools/wgrad_ring_bench.py)
+    ('RDFC_WGRAD_RING2', '0', '(test_conv_fwd_dgrad_wgrad and not f32) or reflection_pad_folded or adjoint', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
 ]
 
 
-@pytest.mark.parametrize('variant', VARIANTS, ids=[f'{v[0]}={v[1]}' + (f'-{v[3][5:-7]}' if len(v) > 3 else '') for v in VARIANTS])
+@pytest.mark.parametrize('variant', VARIANTS, ids=[f'{v[0]}={v[1]}' for v in VARIANTS])
 def test_variant_passes_the_default_kernels_tests(variant):
     name, value, expr = variant[:3]
-    test_file = variant[3] if len(variant) > 3 else 'test_kernels_gpu.py'
+    test_files = variant[3:] if len(variant) > 3 else ('test_kernels_gpu.py',)
     env = dict(os.environ, **{name: value})
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', test_file), '-q', '-x', '-k', expr],
+    r = subprocess.run([sys.executable, '-m', 'pytest'] + [os.path.join(ROOT, 'tests', f) for f in test_files] + ['-q', '-x', '-k', expr],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-2500:]
     assert r.returncode == 0, tail
