@@ -6,8 +6,10 @@
 // three steps ahead; one raw barrier and one counted s_waitcnt vmcnt(N) per K-step; a wave owns 64 co x 64 px.
 // The activation tile is a per-lane gather (every lane's source pixel moves with the tap), which LDS-DMA allows:
 // only its destination is lane-linear.  A lane's pixels are fixed for the whole kernel, so the bounds test and the
-// source pointer are recomputed once per tap and advanced by 32 channels per slab; out-of-image pixels read a zero
-// page, so every wave issues the same number of DMAs per step.  Unlike the 2-D patch kernels the flat pixel tiling
+// source OFFSET (32 bits, through a buffer descriptor of the map: round 5) are recomputed once per tap; the slab
+// advances through the DMA's scalar offset, and an out-of-image pixel or a channel row beyond Cout is an offset
+// beyond the descriptor's extent, which arrives as zeros -- no vector instruction and no select per DMA, every wave
+// issues the same number of DMAs per step.  Unlike the 2-D patch kernels the flat pixel tiling
 // wastes nothing on small or odd-sized maps (PatchGAN's 27x37, the 15x19 / 29x38 encoder stages).
 #include "common.h"
 
@@ -27,14 +29,25 @@ struct IGParams {
     const void *addend;          // optional map added to the result before the store (rdfc_conv2d_dgrad_add)
     int ld_add;
     int row_store;               // epilogue through LDS: whole 128-byte channel rows per store instruction (common.h)
+    unsigned x_bytes, w_bytes;   // extents of the input map and of the packed weights (buffer descriptors of the LDS-DMA loads; < 2^31)
 };
 
-__device__ inline void glds16(const void *gsrc, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_base)
-                 : "memory");
+// one LDS-DMA instruction through a buffer descriptor: lane l reads 16 bytes at base + soff + voff (voff per lane, soff wave-uniform)
+// and lands at lds_base + 16 l; a lane whose voff is not below num_records arrives as zeros (conv_glds.hip: bdma16)
+constexpr unsigned DEAD = 0x80000000u;
+__device__ inline void bdma16(unsigned voff, u32x4 rsrc, unsigned soff, unsigned lds_base) {
+    // m0 is declared clobbered, not saved and restored (the compiler uses it for nothing else in this kernel; clang warns that m0 is
+    // reserved): at three waves per SIMD and 16 MFMAs per step this loop is short of scalar issue slots
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "memory", "m0");
+}
+__device__ inline u32x4 make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
 }
 template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -110,48 +123,40 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
         if ((tid & 3) == 0) pxo[row] = po;
     }
     const int bslot = tid & 3;
-    const bf16_t *wsrc[NA];
-    int wmul[NA];
+    const u32x4 xsrc = make_rsrc(x, p.x_bytes), wrs = make_rsrc(w, p.w_bytes);
+    unsigned woff[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int row = (k * NT + tid) >> 2;
-        wsrc[k] = zero;
-        wmul[k] = 0;
-        if (co0 + row < p.Cout) {
-            wsrc[k] = w + (size_t)(co0 + row) * (p.KH * p.KW) * p.Cin + ((bslot ^ ((row >> 1) & 2)) << 3);
-            wmul[k] = 1;
-        }
+        woff[k] = co0 + row < p.Cout ? 2u * (unsigned)((size_t)(co0 + row) * (p.KH * p.KW) * p.Cin + ((bslot ^ ((row >> 1) & 2)) << 3)) : DEAD;
     }
     __syncthreads();
     const int ntaps = ntaps_s, ncc = p.Cin / BK, G = ntaps * ncc;
 
     // ---- issue side: K-step h = (tap ht, slab hc), slabs inner ----------------------------------------------------------
-    const bf16_t *bsrc[NB];
-    int bstep[NB];
+    unsigned boff[NB];
     int ht = 0, hc = 0, hw = 0;                                  // hw = weight tap index of ht
     auto set_tap = [&](int t) {
         const int dy = tap_dy[t], dx = tap_dx[t];
-        hw = tap_w[t];
+        hw = __builtin_amdgcn_readfirstlane(tap_w[t]);          // (wave-uniform: it goes into the DMAs' scalar offset)
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int row = (k * NT + tid) >> 2;
             const int iy = pyy[k] + dy, ix = pxx[k] + dx;
             const bool ok = pnb[k] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            bsrc[k] = ok ? x + ((size_t)pnb[k] + (size_t)iy * p.Win + ix) * p.ld_in + ((bslot ^ ((row >> 1) & 2)) << 3) : zero;
-            bstep[k] = ok ? BK : 0;
+            boff[k] = ok ? 2u * (unsigned)(((size_t)pnb[k] + (size_t)iy * p.Win + ix) * p.ld_in + ((bslot ^ ((row >> 1) & 2)) << 3)) : DEAD;
         }
     };
     auto issue = [&](int h) {
+        // (a step beyond the last, h >= G, re-reads the last tap's first slab -- valid memory -- into a slot nobody reads: the DMA count
+        //  per step stays static without a second descriptor or a select)
         const bool live = h < G;
         const unsigned slot = lds0 + (h % RING) * SLOT;
-        const int woff = live ? hw * p.Cin + hc * BK : 0;
+        const unsigned so_w = 2u * (unsigned)(hw * p.Cin + hc * BK), so_x = 2u * (unsigned)(hc * BK);
 #pragma unroll
-        for (int k = 0; k < NA; ++k) glds16((live ? wsrc[k] : zero) + woff * wmul[k], slot + (k * NT + wave * 64) * 16);
+        for (int k = 0; k < NA; ++k) bdma16(woff[k], wrs, so_w, slot + (k * NT + wave * 64) * 16);
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            glds16(live ? bsrc[k] : zero, slot + AB + (k * NT + wave * 64) * 16);
-            bsrc[k] += bstep[k];
-        }
+        for (int k = 0; k < NB; ++k) bdma16(boff[k], xsrc, so_x, slot + AB + (k * NT + wave * 64) * 16);
         if (live) {
             if (++hc == ncc) {
                 hc = 0;
@@ -338,7 +343,13 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
     if (zero == nullptr) return 0;
     IGParams p{d->N, transposed ? d->Ho : d->Hi, transposed ? d->Wo : d->Wi, Cin, transposed ? d->Hi : d->Ho, transposed ? d->Wi : d->Wo, Cout,
                d->KH, d->KW, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw, ld_in, transposed ? d->ldx : d->ldy, transposed,
-               d->act, d->slope, d->out_f32, addend, ld_add, 0};
+               d->act, d->slope, d->out_f32, addend, ld_add, 0, 0, 0};
+    {
+        const size_t xb = 2 * (size_t)p.N * p.Hin * p.Win * p.ld_in, wb_ = 2 * (size_t)Cout * d->KH * d->KW * Cin;
+        if (xb >= 0x7ffffff0u || wb_ >= 0x7ffffff0u) return 0;                  // the loaders address both through 32-bit byte offsets
+        p.x_bytes = (unsigned)xb;
+        p.w_bytes = (unsigned)wb_;
+    }
     p.row_store = !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;

@@ -35,6 +35,7 @@ struct TParams {
     int row_store;               // epilogue through LDS: whole 128-byte channel rows per store instruction (common.h)
     const void *addend2;         // a second one (rdfc_conv2d_dgrad_add2: the alias cotangent AND a skip connection's)
     int ld_add2;
+    unsigned x_bytes, w_bytes;   // extents of the source map and of the packed weights (buffer descriptors of the LDS-DMA loads; < 2^31)
 };
 
 constexpr int BK = 32, NT = 256, TCO = 64;
@@ -51,14 +52,25 @@ template <int KS> struct Geo {
     static_assert(NR == 3 && NR <= KS, "one patch round per phase of the previous slab");
 };
 
-__device__ inline void glds16(const void *gsrc, unsigned lds_base) {
+// one LDS-DMA instruction through a buffer descriptor: lane l reads 16 bytes at base + soff + voff (voff per lane, soff wave-uniform)
+// and lands at lds_base + 16 l; a lane whose voff is not below num_records arrives as zeros (conv_glds.hip: bdma16)
+constexpr unsigned DEAD = 0x80000000u;
+__device__ inline void bdma16(unsigned voff, u32x4 rsrc, unsigned soff, unsigned lds_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_base)
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
                  : "memory");
 }
-
+__device__ inline u32x4 make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
 template <int DT, int KS>
 __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ w,
                                                                 const float *__restrict__ bias, void *__restrict__ yout,
@@ -82,39 +94,46 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
     const int ncc = p.Cin / BK;
 
     // ---- per-thread DMA sources (computed once) --------------------------------------------------------------------------------
-    const bf16_t *psrc[NR];
-    unsigned plive = 0, pdst[NR];
+    // 32-bit byte offsets through buffer descriptors (conv_glds.hip): a piece outside the map or a channel row beyond Cout is DEAD -> zeros
+    const u32x4 xsrc = make_rsrc(x, p.x_bytes), wrs = make_rsrc(w, p.w_bytes);
+    unsigned poff[NR], pdst[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int e = r * NT + tid, q = e >> 2, slot = e & 3;
-        psrc[r] = zero;
+        poff[r] = DEAD;
         if (q < NPATCH) {
             const int py = q / PW, px = q - py * PW, iy = y0 - ORG + py, ix = x0 - ORG + px;
-            if ((unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws) {
-                psrc[r] = x + ((size_t)(n * p.Hs + iy) * p.Ws + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3);
-                plive |= 1u << r;
-            }
+            if ((unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws)
+                poff[r] = 2u * (unsigned)(((size_t)(n * p.Hs + iy) * p.Ws + ix) * p.ld_in + ((slot ^ ((q >> 1) & 2)) << 3));
         }
         const int wbase = (r * NT + wave * 64) * 16;
         pdst[r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
     }
-    const bf16_t *wsrc[NWP];                                     // DMA k of a phase = tap kw = k, row co = tid >> 2
+    unsigned woff[NWP];                                          // DMA k of a phase = tap kw = k, row co = tid >> 2
     {
         const int row = tid >> 2, slot = tid & 3;
 #pragma unroll
         for (int k = 0; k < NWP; ++k)
-            wsrc[k] = co0 + row < p.Cout ? w + (size_t)(co0 + row) * KS * KS * p.Cin + k * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3) : nullptr;
+            woff[k] = co0 + row < p.Cout ? 2u * (unsigned)((size_t)(co0 + row) * KS * KS * p.Cin + k * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3)) : DEAD;
     }
     auto issue_w = [&](int it) {                                 // weights of global phase it = cc * KS + kh -> ring slot it % RING
         const int cc = it / KS, kh = it - cc * KS;
-        const int off = kh * KS * p.Cin + cc * BK;
+        u32x4 rs = wrs;
+        if (cc >= ncc) rs[2] = 0;                                // (a phase beyond the last slab: zeros)
+        const unsigned soff = 2u * (unsigned)(kh * KS * p.Cin + cc * BK);
 #pragma unroll
-        for (int k = 0; k < NWP; ++k)
-            glds16(cc < ncc && wsrc[k] != nullptr ? wsrc[k] + off : zero, lds0 + OFF_W + (it % RING) * WPH + (k * NT + wave * 64) * 16);
+        for (int k = 0; k < NWP; ++k) bdma16(woff[k], rs, soff, lds0 + OFF_W + (it % RING) * WPH + (k * NT + wave * 64) * 16);
     };
     auto issue_p = [&](int r, int cc) {                          // round r of slab cc -> patch buffer cc & 1
         const unsigned dst = pdst[r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[r];
-        glds16(cc < ncc ? psrc[r] + ((plive >> r) & 1 ? cc * BK : 0) : zero, dst);
+        u32x4 rs = xsrc;
+        if (cc >= ncc) rs[2] = 0;
+        bdma16(poff[r], rs, 2u * (unsigned)(cc * BK), dst);
+    };
+    auto issue_dummy = [&]() {                                   // (keeps the DMA count per phase static where a phase has no patch round)
+        u32x4 rs = xsrc;
+        rs[2] = 0;
+        bdma16(DEAD, rs, 0u, lds0 + OFF_JUNK);
     };
 
     // ---- fragment coordinates -----------------------------------------------------------------------------------------------------
@@ -145,7 +164,7 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
         __builtin_amdgcn_s_barrier();                                                                           \
         issue_w(it0 + KH + 1);                                                                                  \
         if (KH < NR) issue_p(KH < NR ? KH : 0, cc + 1);                                                         \
-        else glds16(zero, lds0 + OFF_JUNK);                   /* (a fourth phase issues a dummy piece: the vmcnt arithmetic stays the same) */ \
+        else issue_dummy();                                /* (a fourth phase issues a dummy piece: the vmcnt arithmetic stays the same) */ \
         const unsigned char *Wt = smem + OFF_W + ((it0 + KH) % RING) * WPH + a_off;                              \
         const unsigned char *Pt = smem + (cc & 1) * PATCH_BYTES;                                                \
         bf16x8 b_[3][JR];                                      /* column shifts -1 (KS = 4 only), 0, +1 */      \
@@ -328,7 +347,13 @@ int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const voi
     const bf16_t *zero = zero_page();
     if (zero == nullptr) return 0;
     TParams p{d->N, d->Ho, d->Wo, d->Hi, d->Wi, d->Co, d->Ci, d->ldy, d->ldx, d->act, d->slope, d->out_f32, cdiv(d->Wo, TC), cdiv(d->Ho, TRS),
-              addend, ld_add, 0, addend2, ld_add2};
+              addend, ld_add, 0, addend2, ld_add2, 0, 0};
+    {
+        const size_t xb = 2 * (size_t)p.N * p.Hs * p.Ws * p.ld_in, wb_ = 2 * (size_t)p.Cout * KS * KS * p.Cin;
+        if (xb >= 0x7ffffff0u || wb_ >= 0x7ffffff0u) return 0;                  // the loaders address both through 32-bit byte offsets
+        p.x_bytes = (unsigned)xb;
+        p.w_bytes = (unsigned)wb_;
+    }
     p.row_store = !d->out_f32 && p.Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(res) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   (addend2 == nullptr || (ld_add2 % 4 == 0 && (reinterpret_cast<size_t>(addend2) & 7) == 0)) &&

@@ -9,6 +9,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# what a forced tile height of the 3x3 kernel has to pass: every conv / statistics / reflection / addend test of test_kernels_gpu.py and the
+# adjointness + value tests at the benchmark's launch sizes
+JRK = '(conv or stat or reflect or addend or adjoint or values_against) and not f32 and not under_load and not scaling'
 VARIANTS = [
     ('RDFC_GLDS', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and bf16'),   # register-staged predecessors of the LDS-DMA 3x3 kernel
     ('RDFC_WGRAD_RING', '0', '(test_conv_fwd_dgrad_wgrad and not f32) or reflection_pad_folded'),   # segment walk + float atomics instead of the ring kernel
@@ -19,10 +22,10 @@ VARIANTS = [
     ('RDFC_GLDS_STACK', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # per-image row tiles in the 3x3 kernel
     # round 5: every tile height of the 128-channel 3x3 / stride-1 kernel (the default picks one per launch: conv_glds.hip glds_plan) on every
     # conv test incl. fused statistics, reflection fold, addends, stacked batches and the full-size properties
-    ('RDFC_GLDS_JR', '4', 'not f32', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
-    ('RDFC_GLDS_JR', '6', 'not f32', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
-    ('RDFC_GLDS_JR', '8', 'not f32', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
-    ('RDFC_GLDS_JR', '10', 'not f32', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
+    ('RDFC_GLDS_JR', '4', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
+    ('RDFC_GLDS_JR', '6', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
+    ('RDFC_GLDS_JR', '8', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
+    ('RDFC_GLDS_JR', '10', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
     # round 3's ring weight-gradient kernel (round 5's wgrad_ring2 is the default; the two give the same bits: tools/wgrad_ring_bench.py)
     ('RDFC_WGRAD_RING2', '0', '(test_conv_fwd_dgrad_wgrad and not f32) or reflection_pad_folded or adjoint', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
 ]
