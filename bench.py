@@ -192,6 +192,50 @@ def _self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def comm_in_step(model, one_step, steps, dev):
+    """what the gradient exchange costs INSIDE the step (untimed extra steps, every rank): (1) four traced steps -- per bucket, HIP events for
+    "dependencies met" on the issue stream and around the consuming stream's wait (rdfc_gan_amd/optim.py COMM_TRACE): when in the step the
+    bucket could start, when its consumer (the optimizer's Adam kernel) asked for it and how long that stream then stalled = the part of the
+    exchange that nothing overlapped; (2) the same K steps with the collectives switched off (COLLECTIVES_OFF: same control flow and streams,
+    gradients stay local): the difference to the timed figure is the whole cost of the exchange, overlap lost to RCCL's kernels included."""
+    from rdfc_gan_amd import optim
+    names = {id(o): n for n, o in model.optimizers.items()}
+    rows = {}
+    for i in range(4):
+        optim.COMM_TRACE = []
+        torch.cuda.synchronize()
+        start = torch.cuda.Event(enable_timing=True)
+        start.record()
+        one_step(i)
+        torch.cuda.synchronize()
+        for order, t in enumerate(optim.COMM_TRACE):
+            r = rows.setdefault((names[id(t['optimizer'])], t['bucket']), dict(order=order, ready=[], asked=[], stall=[]))
+            if t['ready'] is not None:
+                r['ready'].append(start.elapsed_time(t['ready']))
+            r['asked'].append(start.elapsed_time(t['wait_begin']))
+            r['stall'].append(t['wait_begin'].elapsed_time(t['wait_end']))
+    optim.COMM_TRACE = None
+    med = lambda v: round(sorted(v)[len(v) // 2], 3) if v else None
+    in_step = [dict(optimizer=k[0], bucket=k[1], wait_order=r['order'], ready_at_ms=med(r['ready']), consumer_asks_at_ms=med(r['asked']),
+                    exposed_wait_ms=med(r['stall'])) for k, r in sorted(rows.items(), key=lambda kv: kv[1]['order'])]
+    optim.COLLECTIVES_OFF = True
+    one_step(0)
+    torch.cuda.synchronize()
+    if dist.get_world_size() > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one_step(i)
+    torch.cuda.synchronize()
+    off = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    optim.COLLECTIVES_OFF = False
+    dist.all_reduce(off, op=dist.ReduceOp.MAX)
+    return dict(in_step=in_step, exposed_wait_ms_per_step=round(sum(r['exposed_wait_ms'] or 0.0 for r in in_step), 3),
+                ms_per_step_collectives_off=round(1e3 * float(off) / steps, 3),
+                note='in_step: medians over 4 traced steps, times from the step\'s first launch; exposed_wait = how long the consuming stream stalled for '
+                     'the bucket; ms_per_step_collectives_off: the same step with every collective skipped (max over ranks) -- compare with ms_per_step')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -366,6 +410,10 @@ def main():
         # self-check of the exchange (untimed): which backend / world the collectives really run on and what one all-reduce
         # of every gradient bucket costs alone, so that a scaling curve can be read against it
         comm = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), buckets=[])
+        if dist.get_backend() == 'nccl':
+            comm['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        comm['env'] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(('NCCL_', 'RCCL_', 'HSA_ENABLE_IPC', 'GPU_MAX_HW_QUEUES'))}
+        comm.update(comm_in_step(model, one_step, a.steps, dev))
         for oname, o in model.optimizers.items():
             for bi in range(len(o._buckets)):
                 views = [o.flat_grad[lo:hi] for lo, hi in o.bucket_ranges(bi)]      # (a bucket is one or a few ranges of the flat gradient)

@@ -234,6 +234,8 @@ class FlatAdam(torch.optim.Optimizer):
         self._started.add(i)
         self.started_order.append(i)
         views = [self.flat_grad[a:b] for a, b in self._buckets[i]]
+        if COLLECTIVES_OFF:                   # diagnostic (bench.py's comm block): the step's control flow without the exchange
+            return
         if not self.flat_grad.is_cuda:
             for view in views:
                 dist.all_reduce(view)         # gloo / CPU tests
@@ -249,8 +251,12 @@ class FlatAdam(torch.optim.Optimizer):
             if s_ != issue and s_ != cur:
                 issue.wait_stream(s_)
         with torch.cuda.stream(issue):
+            ready = None
+            if COMM_TRACE is not None:        # when everything the bucket depends on has run: the earliest the exchange can start
+                ready = torch.cuda.Event(enable_timing=True)
+                ready.record()
             for view in views:
-                self._pending.append(dist.all_reduce(view, async_op=True))
+                self._pending.append((i, ready, dist.all_reduce(view, async_op=True)))
 
     def all_reduce_grads_async(self):
         """start the all-reduce of every bucket that has not been started in this step.  No-op when not distributed."""
@@ -260,9 +266,22 @@ class FlatAdam(torch.optim.Optimizer):
             self.all_reduce_bucket_async(i)
 
     def wait_grads(self):
-        """the current stream waits for the bucket all-reduces started so far"""
-        for w in self._pending:
-            w.wait()
+        """the current stream waits for the bucket all-reduces started so far.  Under COMM_TRACE every bucket's wait sits between two
+        events on the waiting stream: what that stream stalls for is the exposed (not overlapped) part of the bucket's exchange."""
+        if COMM_TRACE is None:
+            for _i, _ready, w in self._pending:
+                w.wait()
+        else:
+            k = 0
+            while k < len(self._pending):
+                i, ready = self._pending[k][:2]
+                before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                before.record()
+                while k < len(self._pending) and self._pending[k][0] == i:
+                    self._pending[k][2].wait()
+                    k += 1
+                after.record()
+                COMM_TRACE.append(dict(optimizer=self, bucket=i, ready=ready, wait_begin=before, wait_end=after))
         self._pending = []
 
     @torch.no_grad()
@@ -346,6 +365,13 @@ class FlatAdam(torch.optim.Optimizer):
                 self.param_groups[0][k_] = v
 
 
+
+
+# diagnostics of the data-parallel exchange (bench.py's `comm` block, tests/test_dp*.py): COMM_TRACE = [] collects, per started bucket,
+# HIP events for "dependencies met" (issue stream) and the waiting stream's stall for it; COLLECTIVES_OFF = True runs the very same step
+# without the collectives (gradient buckets and loss means stay local) -- what the exchange costs the step is the difference.
+COMM_TRACE = None
+COLLECTIVES_OFF = False
 
 
 def dp_active():

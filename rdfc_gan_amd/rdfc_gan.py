@@ -36,6 +36,7 @@ from .discriminator import build_discriminator
 from .gan_loss import GANLoss, L1_loss
 from .generator import build_generator
 from .init_weights import init_weights
+from . import optim
 from .optim import FlatAdam, LossScaler, broadcast_module_state, dp_active
 
 
@@ -104,7 +105,8 @@ class _LossReadback:
                 torch.cuda.current_stream().wait_event(ev)              # a group packed on another stream
         keys = [k for ks, _, _ in self.posts for k in ks]
         packed = torch.cat([v for _, v, _ in self.posts]) / dist.get_world_size()
-        dist.all_reduce(packed)
+        if not optim.COLLECTIVES_OFF:
+            dist.all_reduce(packed)
         return keys, packed
 
     def collect(self, order):
@@ -482,11 +484,12 @@ class RDFCGAN:
         self._G_marks[name] += 1
         # every marker leaves an event on the stream it fired on: the bucket follows BOTH branches' streams, not only the one whose
         # marker happens to fire last (the gradients autograd accumulates behind the other branch's last node are on that stream)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self._G_mark_events.setdefault(name, []).append(ev)
+        if self.device.type == 'cuda':           # (the gloo host-logic tests drive the markers on CPU tensors: nothing to order there)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._G_mark_events.setdefault(name, []).append(ev)
         if self._G_marks[name] == 2 and name in self._G_bucket:
-            self.optimizer_G.all_reduce_bucket_async(self._G_bucket[name], after=self._G_mark_events.pop(name))
+            self.optimizer_G.all_reduce_bucket_async(self._G_bucket[name], after=self._G_mark_events.pop(name, ()))
 
     def _start_G_B2A_bucket(self):
         if self.is_train and not getattr(self, '_graph_mode', False):
@@ -954,7 +957,8 @@ class RDFCGAN:
         packed = torch.stack([loss[k].detach().float().reshape(()) for k in keys])
         if dp_active():
             packed = packed / dist.get_world_size()
-            dist.all_reduce(packed)
+            if not optim.COLLECTIVES_OFF:
+                dist.all_reduce(packed)
         return dict(zip(keys, packed.tolist()))
 
     # ---- mode / lr / checkpoints (base.py:74-117; lib/utils/checkpoint.py:21-58,113-166) -----------------------
