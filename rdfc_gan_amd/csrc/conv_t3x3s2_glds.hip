@@ -316,6 +316,7 @@ const bf16_t *zero_page() {
 template <int DT, int KS>
 int launch(const TParams &p, const void *x, const void *w, const float *bias, void *y, const bf16_t *zero, hipStream_t st) {
     constexpr int SMEM = Geo<KS>::SMEM;
+    static_assert(SMEM >= 4 * RS_TILE, "the row-store epilogue stages one tile per wave in the operand buffers");
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)convt3x3s2_glds_kernel<DT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
