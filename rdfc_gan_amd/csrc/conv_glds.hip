@@ -40,7 +40,21 @@ struct GParams {
     int reflect;                 // forward only: out-of-image patch pixels read their mirror image (ReflectionPad2d folded into the loader)
     int row_store;               // epilogue through LDS: whole 128-byte channel rows per store instruction (see the epilogue)
     unsigned x_bytes, w_bytes;   // extents of the input map and of the packed weights (buffer descriptors of the LDS-DMA loads; < 2^31)
+    float r_tiles_x, r_tiles_y, r_vstride, r_gstride;      // 1 / the divisors of the tile and virtual-row arithmetic (qdiv below; 0 where the divisor is)
+    int nchunk;                  // fused statistics: tiles per group = (tiles_y / stats_groups) * tiles_x
+    float r_nchunk;
 };
+
+// a / d and a % d for 0 <= a < 2^22, d > 0 through the float reciprocal rd = 1.f / d (rounded): the quotient estimate is off by at most one
+// either way and is corrected from the remainder.  hipcc expands an integer division by a run-time value into ~45 vector instructions;
+// a tile's prologue and epilogue held twenty of them (a 2-slab tile's first DMA was issued ~1 000 instructions into the kernel: round 5).
+__device__ __forceinline__ void qdiv(int a, int d, float rd, int &q, int &r) {
+    q = (int)((float)a * rd);
+    r = a - q * d;
+    const int lo = r < 0 ? 1 : 0, hi = r >= d ? 1 : 0;          // (selects, no branches: this runs per lane in the DMA-source set-up)
+    q += hi - lo;
+    r += (lo - hi) * d;
+}
 
 constexpr int BK = 32, TC = 16, PW = TC + 2;
 // weight ring: a ring of 3 tap slots (weights fetched two phases ahead) makes the 128-co workgroup 48 KB of LDS -> THREE per CU (the
@@ -96,6 +110,13 @@ template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcn
 // a phase, slab 2 of the K loop; no stamp executes in the shipped library.
 #ifdef RDFC_GLDS_STAMPS
 __device__ unsigned long long g_stamps[8][9][6];
+__device__ unsigned long long g_tile_stamps[512][10];        // sampled workgroups (wave 0): entry | operands of phase 0 landed | K loop done | stores issued | tile id + 1 | s_memrealtime (100 MHz) at entry | at the end | hw id
+#define RDFC_TSTAMP(K)                                                                        \
+    if (tstamp_on) {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tbuf[K])::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    }
 #define RDFC_STAMP(TAP, K)                                                                    \
     if (stamp_on && cc == 2) {                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                    \
@@ -104,23 +125,19 @@ __device__ unsigned long long g_stamps[8][9][6];
     }
 #else
 #define RDFC_STAMP(TAP, K)
+#define RDFC_TSTAMP(K)
 #endif
 
 // virtual row of the stacked batch -> (image, row inside it); image = N: the row belongs to no image (it reads zeros / stores nothing)
-__device__ __forceinline__ void vrow(const GParams &p, int v, int &img, int &row) {
-    if (v < 0) {
-        img = p.N;
-        row = 0;
-        return;
-    }
+__device__ __forceinline__ void vrow(const GParams &p, int v, int &img, int &row) {      // branch-free per lane (p.gstride is uniform)
+    const bool neg = v < 0;
+    v = neg ? 0 : v;
     int g = 0;
-    if (p.gstride) {
-        g = v / p.gstride;
-        v -= g * p.gstride;
-    }
-    const int l = v / p.vstride;
-    row = v - l * p.vstride;
-    img = (p.gstride && l >= p.npg) ? p.N : g * p.npg + l;
+    if (p.gstride) qdiv(v, p.gstride, p.r_gstride, g, v);
+    int l;
+    qdiv(v, p.vstride, p.r_vstride, l, row);
+    img = (neg || (p.gstride && l >= p.npg)) ? p.N : g * p.npg + l;
+    row = neg ? 0 : row;
 }
 
 // Variants measured and removed in round 3 (numbers in DESIGN.md section 7 and profiles/r01_conv_glds_stamps.txt): producer / consumer
@@ -170,10 +187,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
     const int t_all = t;                                        // tile index after the renumbering (unique)
-    const int tx = t % p.tiles_x;
-    t /= p.tiles_x;
+    int tx;
+    qdiv(t, p.tiles_x, p.r_tiles_x, t, tx);
     // stacked batch (p.vstride > 0): ty counts tile rows of the tall virtual map and y0 is a virtual row; else a tile belongs to image n
-    const int ty = p.vstride ? t : t % p.tiles_y, n = p.vstride ? 0 : t / p.tiles_y;
+    int ty = t, n = 0;
+    if (!p.vstride) qdiv(t, p.tiles_y, p.r_tiles_y, n, ty);
     const int y0 = ty * TR, x0 = tx * TC;
     const int ncc = p.Cin / BK;
 
@@ -190,28 +208,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     const u32x4 xsrc = make_rsrc(x, (unsigned)p.x_bytes), wsrc = make_rsrc(w, (unsigned)p.w_bytes);
     {
         const int dtid = wave * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int e = r * NT + dtid, q = e >> 2, slot = e & 3;
-            poff[r] = DEAD;
-            if (q < NPATCH) {
-                const int py = q / PW, px = q - py * PW;
-                int iy = y0 + p.oy0 + py, ix = x0 + p.ox0 + px, ni = n;
-                if (p.vstride) vrow(p, iy, ni, iy);         // virtual row -> (image, row); the rows between two images read zeros (iy >= Hin below)
-                if (p.reflect) {           // LDS-DMA sources are per lane: the halo of a reflection-padded map is just another address
-                    iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);
-                    ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
-                }                          // (what is still outside belongs to output pixels beyond the map: zeros)
-                if (ni < p.N && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)
-                    poff[r] = 2u * (unsigned)(((size_t)(ni * p.Hin + iy) * p.Win + ix) * p.ld_in + ((slot ^ ((px >> 1) & 2)) << 3));
-            }
-            const int wbase = (r * NT + wave * 64) * 16;         // this wave's 1 KB of the patch image
-            pdst[r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
-        }
         const int row = dtid >> 2, slot = dtid & 3;              // (rows 64 k further on share the swizzle: bit 1 of row / 2 is the same)
 #pragma unroll
         for (int k = 0; k < NWP; ++k)
-            woff[k] = co0 + row + 64 * k < p.Cout ? 2u * (unsigned)((size_t)(co0 + row + 64 * k) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3)) : DEAD;
+            woff[k] = co0 + row + 64 * k < p.Cout ? 2u * (unsigned)((co0 + row + 64 * k) * 9 * p.Cin + ((slot ^ ((row >> 1) & 2)) << 3)) : DEAD;
     }
     // Phase s of a slab multiplies the patch at shift (ky, kx) = (s % 3, s / 3) -- kernel column by kernel column, in EVERY variant, so
     // that each output sums its 9 Cin / 32 partial products in one order whatever tile height the launch picked (same bits) -- with the
@@ -225,6 +225,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
 #pragma unroll
         for (int k = 0; k < NWP; ++k) bdma16(woff[k], rs, soff, lds0 + OFF_W + (it % RING) * WSLOT + (k * NT + wave * 64) * 16);
     };
+    issue_w(0);                                                  // (in flight while the patch addresses are worked out)
+    {
+        const int dtid = wave * 64 + lane;
+        // The row part of a piece's address -- virtual row -> (image, row) of the stacked batch (two divisions), the reflection, the
+        // bounds test -- is computed ONCE per patch row, by PH threads in parallel, and handed around through LDS (the second patch
+        // buffer: nothing lands there before phase 0 has passed its barrier); a piece then adds its column.  With every thread doing
+        // the row arithmetic for each of its NR pieces, a tile's first DMA was issued ~1 000 instructions into the kernel and a 2-slab
+        // tile (64-channel layers at full resolution) spent a fifth of its life there (tools/glds_tile_stamps.py, round 5).
+        unsigned *rowtab = reinterpret_cast<unsigned *>(smem + PATCH_BYTES);
+        if (tid < PH) {
+            int iy = y0 + p.oy0 + tid, ni = n;
+            if (p.vstride) vrow(p, iy, ni, iy);                 // virtual row -> (image, row); the rows between two images read zeros (iy >= Hin below)
+            if (p.reflect) iy = iy < 0 ? -iy : (iy >= p.Hin ? 2 * p.Hin - 2 - iy : iy);       // LDS-DMA sources are per lane: the halo of a reflection-padded map is just another address
+            const bool live = ni < p.N && (unsigned)iy < (unsigned)p.Hin;
+            rowtab[tid] = live ? 2u * (unsigned)((ni * p.Hin + iy) * p.Win * p.ld_in) : DEAD;      // byte offset of the row (< 2^31: glds_shape_ok)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int e = r * NT + dtid, q = e >> 2, slot = e & 3;
+            {                              // (no per-lane branches: selects; the offset of a piece that is not live is never used)
+                const int py = q / PW, px = q - py * PW;
+                int ix = x0 + p.ox0 + px;
+                if (p.reflect) ix = ix < 0 ? -ix : (ix >= p.Win ? 2 * p.Win - 2 - ix : ix);
+                const unsigned ro = rowtab[py < PH ? py : PH - 1];
+                const bool live = q < NPATCH && ro != DEAD && (unsigned)ix < (unsigned)p.Win;     // (what is still outside belongs to output pixels beyond the map: zeros)
+                poff[r] = live ? ro + 2u * (unsigned)(ix * p.ld_in + ((slot ^ ((px >> 1) & 2)) << 3)) : DEAD;
+            }
+            const int wbase = (r * NT + wave * 64) * 16;         // this wave's 1 KB of the patch image
+            pdst[r] = wbase + 1024 <= PATCH_BYTES ? (unsigned)wbase : 0xffffffffu;
+        }
+    }
     auto issue_p = [&](int r, int cc) {                          // round r of slab cc -> patch buffer cc & 1
         const unsigned dst = pdst[r] == 0xffffffffu ? lds0 + OFF_JUNK : lds0 + (cc & 1) * PATCH_BYTES + pdst[r];
         u32x4 rs = xsrc;
@@ -265,6 +297,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     unsigned long long sbuf[9][6];
     const bool stamp_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;
     const int wave_all = wave;
+    unsigned long long tbuf[6];
+    const int tstride = (int)((gridDim.x * gridDim.y + 511) / 512), tlin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const bool tstamp_on = wave == 0 && tlin % tstride == 0;
+    RDFC_TSTAMP(0)
+    unsigned long long treal0 = 0, treal1 = 0;
+    if (tstamp_on) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(treal0)::"memory");
 #endif
 
     // ---- the K loop: every fragment read is issued a phase ahead, between the MFMAs of the phase before ----------------------------------
@@ -281,9 +319,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
 #pragma unroll
     for (int r = 0; r < NR; ++r) issue_p(r, 0);
 #pragma unroll
-    for (int h = 0; h <= WLOOK; ++h) issue_w(h);
-    wait_vm<WLOOK * NWP>();                                      // patch 0 and the weights of phase 0
+    for (int h = 1; h <= WLOOK; ++h) issue_w(h);                 // (phase 0's weights went out first of all)
+    wait_vm<WLOOK * NWP>();                                      // the weights of phase 0 and patch 0
     __builtin_amdgcn_s_barrier();
+    RDFC_TSTAMP(1)
     read_a(0, aa);
 #pragma unroll
     for (int j = 0; j < JR; ++j) bres[j] = read_b(0, 0, j);
@@ -331,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     }
 #undef RDFC_GLDS_PHASE
     wait_vm<0>();
+    RDFC_TSTAMP(2)
 #ifdef RDFC_GLDS_STAMPS
     if (stamp_on && lane == 0 && ncc > 2)
         for (int t_ = 0; t_ < 9; ++t_)
@@ -343,9 +383,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     const bool vec_ok = (p.ld_out & 3) == 0;
     int on[JR], oyr[JR];                                        // image and row of this wave's JR output rows (-1: none)
 #pragma unroll
-    for (int j = 0; j < JR; ++j) {
+    for (int j = 0; j < JR; ++j) {                              // (wave-uniform: the rows of an image follow each other, the division runs where one ends)
         int v = y0 + JR * wc + j, ni = n;
-        if (p.vstride) vrow(p, v, ni, v);
+        if (p.vstride) {
+            if (j > 0 && on[j - 1] < p.N && on[0] >= 0 && oyr[j - 1] >= 0 && oyr[j - 1] + 1 < p.H) {
+                ni = on[j - 1];
+                v = oyr[j - 1] + 1;
+            } else
+                vrow(p, v, ni, v);
+        }
         on[j] = ni;
         oyr[j] = (ni < p.N && v < p.H) ? v : -1;
     }
@@ -415,8 +461,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
             }
             if (co < p.Cout) {
                 // (statistics launches tile the stacked batch group by group: tiles_y / G tile rows per group, rows [g][chunk] in tile order)
-                const int nchunk = (p.tiles_y / p.stats_groups) * p.tiles_x;
-                const int g = t_all / nchunk, chunk = t_all - g * nchunk;
+                const int nchunk = p.nchunk;
+                int g, chunk;
+                qdiv(t_all, nchunk, p.r_nchunk, g, chunk);
                 float *dst = stats + ((size_t)(g * nchunk + chunk) * 2) * p.Cout + co;
                 dst[0] = a1;
                 dst[p.Cout] = a2;
@@ -469,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
     if (p.row_store) {
         const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
         __syncthreads();                                           // every wave is done with the operand tiles
+        RDFC_TSTAMP(4)
         unsigned char *Ot = smem + wave * RS_TILE;
 #pragma unroll
         for (int j0 = 0; j0 < JR; j0 += 4) {                       // 64 pixels (four tile rows) at a time through the wave's 9 KB
@@ -495,14 +543,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
                 }
             }
             const int cow = co0 + wr * 64;
-            rs_flush(Ot, lane, reinterpret_cast<bf16_t *>(yout) + cow, p.Cout - cow, [&](int px) -> long {
-                const int jj = px >> 4, ox = x0 + (px & 15);       // (jj: compile-time after unrolling)
-                if (j0 + jj >= JR) return -1;
+            if (j0 == 0) { RDFC_TSTAMP(5) }
+            long rowbase[4];                                       // element offset of the row group's rows at column x0 (wave-uniform), -1: no such row
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
                 const int j = j0 + jj < JR ? j0 + jj : JR - 1;
-                if (oyr[j] < 0 || ox >= p.W) return -1;
-                return (((long)on[j] * p.H + oyr[j]) * p.W + ox) * p.ld_out;
+                rowbase[jj] = (j0 + jj < JR && oyr[j] >= 0) ? (((long)on[j] * p.H + oyr[j]) * p.W + x0) * p.ld_out : -1;
+            }
+            rs_flush(Ot, lane, reinterpret_cast<bf16_t *>(yout) + cow, p.Cout - cow, [&](int px) -> long {
+                const int jj = px >> 4, c = px & 15;               // (jj: compile-time after unrolling)
+                if (rowbase[jj] < 0 || x0 + c >= p.W) return -1;
+                return rowbase[jj] + c * p.ld_out;
             });
         }
+#ifdef RDFC_GLDS_STAMPS
+        RDFC_TSTAMP(3)
+        if (tstamp_on && lane == 0) {
+            for (int k_ = 0; k_ < 4; ++k_) g_tile_stamps[tlin / tstride][k_] = tbuf[k_];
+            g_tile_stamps[tlin / tstride][4] = (unsigned long long)tlin + 1;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(treal1)::"memory");
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            g_tile_stamps[tlin / tstride][5] = treal0;
+            g_tile_stamps[tlin / tstride][6] = treal1;
+            g_tile_stamps[tlin / tstride][7] = hwid;
+            g_tile_stamps[tlin / tstride][8] = tbuf[4];
+            g_tile_stamps[tlin / tstride][9] = tbuf[5];
+        }
+#endif
         return;
     }
     if (p.act == RDFC_ACT_TANH) store_all([](float u) { return tanhf(u); });
@@ -683,6 +751,13 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     p.tiles_y = g.tiles_y;
     p.vstride = g.vstride;
     p.gstride = g.gstride;
+    p.r_tiles_x = 1.f / (float)p.tiles_x;
+    p.r_tiles_y = 1.f / (float)p.tiles_y;
+    p.r_vstride = p.vstride ? 1.f / (float)p.vstride : 0.f;
+    p.r_gstride = p.gstride ? 1.f / (float)p.gstride : 0.f;
+    p.nchunk = p.stats_groups > 0 ? (p.tiles_y / p.stats_groups) * p.tiles_x : 1;
+    p.r_nchunk = 1.f / (float)p.nchunk;
+    if ((long)p.tiles_x * p.tiles_y * (p.vstride ? 1 : p.N) >= (1L << 22) || (long)p.N * (p.vstride > 0 ? p.vstride : p.H) + g.gstride >= (1L << 22)) return 0;   // (qdiv's range)
 #define RDFC_GLDS_LAUNCH(DT_)                                                                                        \
     if (Cout <= 64) return launch<64, DT_>(p, in, w, bias, out, zero, stats, st);                                  \
     switch (g.jr) {                                                                                                  \
@@ -702,5 +777,13 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
 extern "C" int rdfc_debug_glds_stamps(unsigned long long *out) {
     hipDeviceSynchronize();
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
+}
+extern "C" int rdfc_debug_glds_tile_stamps(unsigned long long *out, int clear) {
+    hipDeviceSynchronize();
+    if (clear) {
+        static unsigned long long z[512][10];
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), z, sizeof(z)) == hipSuccess ? 0 : 1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stamps), sizeof(g_tile_stamps)) == hipSuccess ? 0 : 1;
 }
 #endif

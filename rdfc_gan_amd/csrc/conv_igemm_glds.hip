@@ -30,7 +30,20 @@ struct IGParams {
     int ld_add;
     int row_store;               // epilogue through LDS: whole 128-byte channel rows per store instruction (common.h)
     unsigned x_bytes, w_bytes;   // extents of the input map and of the packed weights (buffer descriptors of the LDS-DMA loads; < 2^31)
+    float r_sh, r_sw, r_kw;      // 1 / sh, 1 / sw, 1 / KW (qdiv)
 };
+
+// a / d and a % d for 0 <= a < 2^21, d > 0 through a float reciprocal rd ~ 1.f / d (1 ulp is enough): the quotient estimate is off by at
+// most one either way and is corrected from the remainder (conv_glds.hip: hipcc expands a division by a run-time value into ~45 vector
+// instructions, and this kernel's set-up held 4-8 of them per thread plus a serial tap loop on thread 0: its first DMA was issued
+// 900-1 200 instructions into the kernel, which the short reductions of the stride-2 and 1x1 layers -- 6 to 18 K-steps -- could not hide)
+__device__ __forceinline__ void qdiv(int a, int d, float rd, int &q, int &r) {
+    q = (int)((float)a * rd);
+    r = a - q * d;
+    const int lo = r < 0 ? 1 : 0, hi = r >= d ? 1 : 0;
+    q += hi - lo;
+    r += (lo - hi) * d;
+}
 
 // one LDS-DMA instruction through a buffer descriptor: lane l reads 16 bytes at base + soff + voff (voff per lane, soff wave-uniform)
 // and lands at lds_base + 16 l; a lane whose voff is not below num_records arrives as zeros (conv_glds.hip: bdma16)
@@ -72,55 +85,70 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
 
     // ---- pixel enumeration (as conv_igemm.hip) --------------------------------------------------------------------
     int cy = 0, cx = 0, Ha = p.Hout, Wb = p.Wout;
-    if (p.transposed) {
-        cy = blockIdx.z / p.sw;
-        cx = blockIdx.z % p.sw;
-        Ha = cy < p.Hout ? (p.Hout - cy + p.sh - 1) / p.sh : 0;
-        Wb = cx < p.Wout ? (p.Wout - cx + p.sw - 1) / p.sw : 0;
+    if (p.transposed) {                                          // (wave-uniform)
+        int t_;
+        qdiv((int)blockIdx.z, p.sw, p.r_sw, cy, cx);
+        Ha = Wb = 0;
+        if (cy < p.Hout) qdiv(p.Hout - cy + p.sh - 1, p.sh, p.r_sh, Ha, t_);
+        if (cx < p.Wout) qdiv(p.Wout - cx + p.sw - 1, p.sw, p.r_sw, Wb, t_);
     }
-    const int Pc = p.N * Ha * Wb;
+    const int HW = Ha * Wb, Pc = p.N * HW;
     const int m0 = blockIdx.x * TPX;
     if (m0 >= Pc) return;
-    if (tid == 0) {
-        int nt = 0;
-        const int ry = p.transposed ? (cy + p.ph) % p.sh : 0, rx = p.transposed ? (cx + p.pw) % p.sw : 0;
-        for (int kh = 0; kh < p.KH; ++kh)
-            for (int kw = 0; kw < p.KW; ++kw) {
-                if (!p.transposed) {
-                    tap_w[nt] = kh * p.KW + kw; tap_dy[nt] = kh * p.dh; tap_dx[nt] = kw * p.dw; ++nt;
-                } else {
-                    const int ey = ry - kh * p.dh, ex = rx - kw * p.dw;     // must be multiples of the stride
-                    if (ey % p.sh == 0 && ex % p.sw == 0) {
-                        tap_w[nt] = kh * p.KW + kw; tap_dy[nt] = ey / p.sh; tap_dx[nt] = ex / p.sw; ++nt;
-                    }
-                }
-            }
-        ntaps_s = nt;
+    // the taps of this parity class, one lane per (kh, kw), compacted in tap order by a ballot (a serial loop on thread 0 with its
+    // divisions cost ~1 500 instructions while the other 255 threads waited)
+    if (wave == 0) {
+        const int ntap_all = p.KH * p.KW;
+        int kh, kw, dy = 0, dx = 0;
+        qdiv(lane < ntap_all ? lane : 0, p.KW, p.r_kw, kh, kw);
+        bool valid = lane < ntap_all;
+        if (!p.transposed) {
+            dy = kh * p.dh;
+            dx = kw * p.dw;
+        } else {
+            int ry, rx, t_, qy, qx, rem_y, rem_x;
+            qdiv(cy + p.ph, p.sh, p.r_sh, t_, ry);
+            qdiv(cx + p.pw, p.sw, p.r_sw, t_, rx);
+            // ey = ry - kh dh and ex = rx - kw dw must be multiples of the stride (they may be negative: shifted by 1024 strides)
+            qdiv(ry - kh * p.dh + 1024 * p.sh, p.sh, p.r_sh, qy, rem_y);
+            qdiv(rx - kw * p.dw + 1024 * p.sw, p.sw, p.r_sw, qx, rem_x);
+            valid = valid && rem_y == 0 && rem_x == 0;
+            dy = qy - 1024;
+            dx = qx - 1024;
+        }
+        const unsigned long long mask = __ballot(valid);
+        if (valid) {
+            const int at = __popcll(mask & ((1ull << lane) - 1ull));
+            tap_w[at] = lane;
+            tap_dy[at] = dy;
+            tap_dx[at] = dx;
+        }
+        if (lane == 0) ntaps_s = __popcll(mask);
     }
     // this thread's NB gathered pixels: tile rows (k * NT + tid) >> 2, 16-byte slot tid & 3
+    const float r_hw = __builtin_amdgcn_rcpf((float)HW), r_wb = __builtin_amdgcn_rcpf((float)Wb);
     int pnb[NB], pyy[NB], pxx[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const int row = (k * NT + tid) >> 2, m = m0 + row;
-        pnb[k] = -1;
-        pyy[k] = pxx[k] = 0;
-        int po = -1;
-        if (m < Pc) {
-            const int n = m / (Ha * Wb), r = m - n * (Ha * Wb);
-            const int a = r / Wb, b = r - a * Wb;
-            pnb[k] = n * p.Hin * p.Win;
-            if (!p.transposed) {
-                pyy[k] = a * p.sh - p.ph;
-                pxx[k] = b * p.sw - p.pw;
-                po = m;
-            } else {
-                const int oy = cy + a * p.sh, ox = cx + b * p.sw;
-                pyy[k] = (oy + p.ph) / p.sh;
-                pxx[k] = (ox + p.pw) / p.sw;
-                po = (n * p.Hout + oy) * p.Wout + ox;
-            }
+        const bool in = m < Pc;
+        int n, r, a, b;
+        qdiv(in ? m : 0, HW, r_hw, n, r);
+        qdiv(r, Wb, r_wb, a, b);
+        pnb[k] = in ? n * p.Hin * p.Win : -1;
+        int po;
+        if (!p.transposed) {
+            pyy[k] = a * p.sh - p.ph;
+            pxx[k] = b * p.sw - p.pw;
+            po = m;
+        } else {
+            const int oy = cy + a * p.sh, ox = cx + b * p.sw;
+            int t_;
+            qdiv(oy + p.ph, p.sh, p.r_sh, pyy[k], t_);
+            qdiv(ox + p.pw, p.sw, p.r_sw, pxx[k], t_);
+            po = (n * p.Hout + oy) * p.Wout + ox;
         }
-        if ((tid & 3) == 0) pxo[row] = po;
+        if ((tid & 3) == 0) pxo[row] = in ? po : -1;
     }
     const int bslot = tid & 3;
     const u32x4 xsrc = make_rsrc(x, p.x_bytes), wrs = make_rsrc(w, p.w_bytes);
@@ -128,7 +156,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int row = (k * NT + tid) >> 2;
-        woff[k] = co0 + row < p.Cout ? 2u * (unsigned)((size_t)(co0 + row) * (p.KH * p.KW) * p.Cin + ((bslot ^ ((row >> 1) & 2)) << 3)) : DEAD;
+        woff[k] = co0 + row < p.Cout ? 2u * (unsigned)((co0 + row) * (p.KH * p.KW) * p.Cin + ((bslot ^ ((row >> 1) & 2)) << 3)) : DEAD;
     }
     __syncthreads();
     const int ntaps = ntaps_s, ncc = p.Cin / BK, G = ntaps * ncc;
@@ -144,7 +172,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
             const int row = (k * NT + tid) >> 2;
             const int iy = pyy[k] + dy, ix = pxx[k] + dx;
             const bool ok = pnb[k] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            boff[k] = ok ? 2u * (unsigned)(((size_t)pnb[k] + (size_t)iy * p.Win + ix) * p.ld_in + ((bslot ^ ((row >> 1) & 2)) << 3)) : DEAD;
+            boff[k] = ok ? 2u * (unsigned)((pnb[k] + iy * p.Win + ix) * p.ld_in + ((bslot ^ ((row >> 1) & 2)) << 3)) : DEAD;       // (< 2^31: the launcher checks x_bytes)
         }
     };
     auto issue = [&](int h) {
@@ -353,6 +381,10 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
     p.row_store = !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
+    if ((long)p.N * p.Hout * p.Wout >= (1L << 21) || d->KH * d->dh + d->ph > 1000 || d->KW * d->dw + d->pw > 1000 || d->sh > 1000 || d->sw > 1000) return 0;   // (qdiv's range)
+    p.r_sh = 1.f / (float)d->sh;
+    p.r_sw = 1.f / (float)d->sw;
+    p.r_kw = 1.f / (float)d->KW;
     if (d->dtype == RDFC_F16)
         return Cout > 64 ? launch<128, RDFC_F16>(p, in, w, bias, out, zero, st) : launch<64, RDFC_F16>(p, in, w, bias, out, zero, st);
     if (Cout > 64) return launch<128>(p, in, w, bias, out, zero, st);

@@ -18,6 +18,8 @@ SHAPES = [  # N, H, W, Ci, Co, k, s, p, which   -- the step's igemm_glds / convt
     (16, 228, 304, 64, 192, 3, 2, 1, 'dgrad'), (16, 114, 152, 64, 384, 3, 2, 1, 'dgrad'), (16, 114, 152, 64, 128, 4, 2, 1, 'dgrad'),
     (16, 28, 38, 256, 512, 4, 1, 1, 'dgrad'), (16, 114, 152, 192, 384, 1, 1, 0, 'dgrad'),
 ]
+if os.environ.get('AB_SHAPES'):                     # e.g. AB_SHAPES='[(16,228,304,64,64,3,1,1,"fwd")]'
+    SHAPES = eval(os.environ['AB_SHAPES'])
 for (N, H, W, Ci, Co, k, s, p, which) in SHAPES:
     x = torch.randn(N, H, W, Ci, device='cuda').to(dt)
     w = torch.randn(Co, Ci, k, k, device='cuda') * 0.05
