@@ -362,9 +362,10 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring2_kernel(RPa
 #pragma unroll
     for (int k = 0; k < NY; ++k) {
         const int pos = 8 * wave + PY * k + ylp, slot = lane % CPY;
+        const int src = slot ^ (2 * pair_swz<YROW>(pos));        // the chunk this lane FETCHES (the swizzle is applied to the source)
         ycol[k] = PY * k + ylp;
-        yoff[k] = 2u * (unsigned)(((long)(ci * p.Ho + cy) * p.Wo + cj + ycol[k]) * p.ldy + co0 + ((slot ^ (2 * pair_swz<YROW>(pos))) << 3));
-        if (co0 + (slot << 3) >= p.Co) yoff[k] = DEAD_OFF;       // (a 128-co tile's second half beyond Co: stays beyond num_records whatever is added)
+        yoff[k] = 2u * (unsigned)(((long)(ci * p.Ho + cy) * p.Wo + cj + ycol[k]) * p.ldy + co0 + (src << 3));
+        if (co0 + (src << 3) >= p.Co) yoff[k] = DEAD_OFF;        // (channels beyond Co -- a 128-co tile's second half, the upper 32 of a 32-channel layer: stays beyond num_records whatever is added)
     }
     const int xslot = lane % CPX, xpos = 8 * wave + xlp;
     const int xchunk = ci0 + ((xslot ^ (2 * pair_swz<XROW>(xpos))) << 3);
@@ -698,7 +699,15 @@ static bool ring_takes(const rdfc_conv_desc *d, int reflect, int &L) {
     if (!(d->KH == d->KW && (K == 3 || K == 4) && d->sh == d->sw && (S == 1 || S == 2) && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return false;
     if ((S != 1 || K != 3) && (mode < 2 || d->ph != 1 || reflect)) return false;
     if (d->Ho != (d->Hi + 2 * d->ph - K) / S + 1 || d->Wo != (d->Wi + 2 * d->pw - K) / S + 1) return false;
-    if (d->Co % 64 || d->Ci % 64 || d->ldx % 8 || d->ldy % 8 || d->Wo < 24) return false;
+    if (d->Ci % 64 || d->ldx % 8 || d->ldy % 8 || d->Wo < 24) return false;
+    if (d->Co % 64) {
+        // 32 output channels (the 128 -> 32 head convs at full resolution): the 64-co tile with its upper half beyond Cout -- zeros from the
+        // descriptor's range check, nothing stored -- on the round-5 kernel only (the round-3 kernel reads a zero page per piece instead)
+        const char *env2 = getenv("RDFC_WGRAD_RING2");
+        const bool ring2 = env2 == nullptr || atoi(env2) != 0;
+        const size_t xb = 2 * (size_t)d->N * d->Hi * d->Wi * d->ldx, yb = 2 * (size_t)d->N * d->Ho * d->Wo * d->ldy;
+        if (!(d->Co == 32 && S == 1 && K == 3 && ring2 && xb < 0x7ffffff0u && yb < 0x7ffffff0u && mode >= 2)) return false;
+    }
     if (reflect && (d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return false;
     const int omax = S == 1 ? K - 1 : K / 2;                   // largest tap shift within a plane's flat sequence
     L = (d->Wo + omax + 7) / 8 * 8;

@@ -104,6 +104,8 @@ CONV_CASES = [
     (4, 130, 140, 3, 64, 4, 2, 1),
     (4, 130, 140, 1, 64, 4, 2, 1),
     (4, 130, 141, 3, 64, 3, 1, 1),
+    # round 5: the 128 -> 32 head convs' weight gradient on the ring kernel's 64-channel tile (upper half beyond Cout: range-checked zeros)
+    (4, 48, 64, 128, 32, 3, 1, 1),
 ]
 
 

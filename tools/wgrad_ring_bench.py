@@ -15,7 +15,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 SHAPES = [  # N, H, W, Ci, Co, pad, reflect, kernel, stride
     (16, 57, 76, 256, 256, 1, 0, 3, 1), (16, 29, 38, 512, 512, 1, 0, 3, 1), (16, 114, 152, 128, 128, 1, 0, 3, 1), (16, 228, 304, 64, 64, 1, 0, 3, 1),
     (16, 228, 304, 128, 64, 1, 0, 3, 1), (16, 114, 152, 256, 128, 1, 0, 3, 1), (16, 57, 76, 256, 256, 1, 1, 3, 1), (3, 29, 38, 128, 192, 1, 0, 3, 1),
-    (2, 31, 45, 64, 128, 0, 0, 3, 1),
+    (2, 31, 45, 64, 128, 0, 0, 3, 1), (16, 228, 304, 128, 32, 1, 0, 3, 1), (2, 40, 52, 128, 32, 1, 0, 3, 1),
     # stride 2 / 4x4 (the encoders' down-sampling convs, the transposed decoder convs seen from their output, PatchGAN)
     (16, 114, 152, 128, 256, 1, 0, 3, 2), (16, 228, 304, 64, 128, 1, 0, 3, 2), (16, 228, 304, 64, 192, 1, 0, 3, 2), (16, 57, 76, 256, 512, 1, 0, 3, 2),
     (16, 58, 76, 128, 768, 1, 0, 3, 2), (16, 114, 152, 64, 384, 1, 0, 3, 2), (16, 114, 152, 64, 128, 1, 0, 4, 2), (16, 57, 76, 128, 256, 1, 0, 4, 2),
