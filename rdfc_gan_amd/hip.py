@@ -479,15 +479,15 @@ def norm_nchunk(P, Cc, dtype_code):
     return n
 
 
-_fold_cache = {}
+_scratch_cache = {}
 
 
-def fold_scratch(G, nchunk, K, Cc):
+def norm_scratch(G, nchunk, K, Cc):
     """f32 elements of scratch a two-stage reduction needs (partial rows + the f64 per-group statistics of a stacked-batch BatchNorm)"""
     key = (G, nchunk, K, Cc)
-    n = _fold_cache.get(key)
+    n = _scratch_cache.get(key)
     if n is None:
-        n = _fold_cache[key] = lib().rdfc_norm_scratch_floats(G, nchunk, K, Cc)
+        n = _scratch_cache[key] = lib().rdfc_norm_scratch_floats(G, nchunk, K, Cc)
     return n
 
 
@@ -510,7 +510,7 @@ def norm_forward(x, G, eps, gamma, beta, res, z, act='none', slope=0.0, prelu=No
     N, H, W, Cc = x.shape
     P = N * H * W // G
     d = dt(x)
-    npart = fold_scratch(G, norm_nchunk(P, Cc, d), 2, Cc)
+    npart = norm_scratch(G, norm_nchunk(P, Cc, d), 2, Cc)
     buf = torch.empty(npart + 2 * G * Cc, dtype=torch.float32, device=x.device)      # [partials, level-2 rows | mean | rstd]
     base = buf.data_ptr()
     if PROFILE_HBM is not None:
@@ -549,7 +549,7 @@ def norm_stats(x, G, eps, run_mean=None, run_var=None, momentum=0.1):
     """x [N,H,W,C]; G = 1 (batch) or N (instance). -> mean[G,C], rstd[G,C]"""
     N, H, W, Cc = x.shape
     P = N * H * W // G
-    npart = fold_scratch(G, norm_nchunk(P, Cc, dt(x)), 2, Cc)
+    npart = norm_scratch(G, norm_nchunk(P, Cc, dt(x)), 2, Cc)
     buf = torch.empty(npart + 2 * G * Cc, dtype=torch.float32, device=x.device)      # [partials, level-2 rows | mean | rstd]
     base = buf.data_ptr()
     _chk(lib().rdfc_norm_stats_final(_p(x), base, base + 4 * npart, base + 4 * (npart + G * Cc), G, P, Cc, ld(x), dt(x), _f(eps),
@@ -577,7 +577,7 @@ def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, pr
     G = mean.shape[0]
     P = N * H * W // G
     d = dt(x)
-    npart = fold_scratch(G, norm_nchunk(P, Cc, d), 3, Cc)
+    npart = norm_scratch(G, norm_nchunk(P, Cc, d), 3, Cc)
     buf = torch.empty(npart + G * 3 * Cc, dtype=torch.float32, device=x.device)       # [partials, level-2 rows | sums]
     base = buf.data_ptr()
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
@@ -610,7 +610,7 @@ def adain_apply(x, mean, rstd, gb, out):
 def adain_backward(dout, x, mean, rstd, gb):
     N, H, W, Cc = x.shape
     P = H * W
-    npart = fold_scratch(N, norm_nchunk(P, Cc, dt(x)), 3, Cc)
+    npart = norm_scratch(N, norm_nchunk(P, Cc, dt(x)), 3, Cc)
     buf = torch.empty(npart + N * 3 * Cc, dtype=torch.float32, device=x.device)       # [partials, level-2 rows | sums]
     base = buf.data_ptr()
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)

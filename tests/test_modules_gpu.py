@@ -434,11 +434,10 @@ def test_step_schedules_walk_the_same_trajectory(monkeypatch):
         Fh.set_multi_stream(True)
 
 
-@pytest.mark.parametrize('graph_streams', ['one_stream'])     # ('fork_join': hipStreamEndCapture of the full four-stream step segfaults on ROCm 7.2 -- opt-in only)
+@pytest.mark.parametrize('graph_streams', ['one_stream'])     # (a fork / join capture of the four-stream step segfaulted in hipStreamEndCapture on ROCm 7.2; the option was removed in round 5)
 def test_graph_mode_matches_eager(graph_streams):
     """RDFCGAN.enable_graph(): three captured HIP graphs (G step | D step | Adam) replayed per step must walk the
-    same trajectory as the eager step (same host RNG draws, device-side Adam step count, BatchNorm batch counters) --
-    with the helper streams' fork / join captured into the graphs (default) and with a one-stream capture."""
+    same trajectory as the eager step (same host RNG draws, device-side Adam step count, BatchNorm batch counters); one-stream capture."""
     import random
     from rdfc_gan_amd import functional as Fh
     from rdfc_gan_amd.rdfc_gan import RDFCGAN
@@ -453,7 +452,7 @@ def test_graph_mode_matches_eager(graph_streams):
         Fh.invalidate_packed_weights()
         m.train()
         if mode == 'graph':
-            m.enable_graph(True, multi_stream=graph_streams == 'fork_join')
+            m.enable_graph(True)
         losses = []
         for it in range(3):
             data, nA, _ = step_batch(it, hp['B'], hp['H'], hp['W'])

@@ -41,3 +41,23 @@ trace.reverse()
 mx = max(trace); at = trace.index(mx)
 print(f'{len(ins)} instructions in the loop; max live VGPRs {mx} at instruction {at}: {ins[at]}')
 print('live at the barriers:', [trace[i] for i, x in enumerate(ins) if x.startswith('s_barrier')])
+if len(sys.argv) > 3:                    # third argument: where the registers live at the maximum were last written (by opcode)
+    live = set()
+    lives = []
+    for _ in range(3):
+        lives = []
+        for (d, u) in reversed(du):
+            live = (live - d) | u
+            lives.append(set(live))
+    lives.reverse()
+    L = lives[at]
+    import collections
+    src = collections.Counter()
+    for r in L:
+        k = at
+        for back in range(1, len(du) + 1):
+            k = (at - back) % len(du)
+            if r in du[k][0]:
+                break
+        src[(ins[k].split()[0], 'before' if k < at else 'wraps')] += 1
+    print('defined by:', src.most_common(25))
