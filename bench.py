@@ -478,14 +478,14 @@ def main():
             # committed rocprofv3 passes over this same command (tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
             # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), apply to the default workload only and
             # are refused when they were taken from other kernel sources than the ones this library was built from
-            tfile = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+            tfile = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
             default_wl = (a.batch, a.height, a.width, a.dtype, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, 'f16', False, False, False)   # (--full-objective sets label_net)
             if default_wl and os.path.exists(tfile):
                 tab = json.load(open(tfile))
                 meta = tab.pop('_meta', {})
                 loaded = hip.build_hash()                  # compiled into the library that is actually loaded
                 if meta.get('csrc_sha16') != loaded:
-                    out['roofline']['traffic_note'] = (f"profiles/r04_pmc_traffic.json was measured on kernel sources {meta.get('csrc_sha16')}, the loaded library was built from "
+                    out['roofline']['traffic_note'] = (f"profiles/r05_pmc_traffic.json was measured on kernel sources {meta.get('csrc_sha16')}, the loaded library was built from "
                                                        f'{loaded}: stale counters refused (re-run tools/pmc_bench.sh)')
                 else:
                     for k, v in tab.items():
@@ -500,7 +500,7 @@ def main():
                                 simd_cycles = out['roofline']['avg_launch_us'] * 2400.0 * 1024
                                 out['roofline']['mfma_busy'] = dict(cycles_per_launch=round(v['mfma_busy_cycles']), mfma_insts_per_launch=round(v['mfma_insts']),
                                                                     frac_of_simd_cycles=round(v['mfma_busy_cycles'] / simd_cycles, 4),
-                                                                    note='SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/r04_pmc_traffic.json) / (avg_launch_us x 2.4 GHz x 1024 SIMDs)')
+                                                                    note='SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/r05_pmc_traffic.json) / (avg_launch_us x 2.4 GHz x 1024 SIMDs)')
             if iso:
                 ifl = sum(r[1] for r in iso if r[5] == top)
                 isec = sum(r[2].elapsed_time(r[3]) * 1e-3 for r in iso if r[5] == top)

@@ -132,3 +132,52 @@ def test_results_do_not_change_under_load(case, dtype):
         assert torch.equal(dx, dx_ref), (r, 'dgrad', float((dx.float() - dx_ref.float()).abs().max()))
         if hip.wgrad_is_deterministic(d):
             assert torch.equal(dw, dw_ref), (r, 'wgrad', float((dw - dw_ref).abs().max()))
+
+
+HEIGHT_CASES = [(16, 57, 76, 256, 256), (16, 114, 152, 128, 128), (16, 29, 38, 512, 512), (16, 228, 304, 64, 128), (6, 97, 131, 192, 320)]
+
+
+@pytest.mark.parametrize('dtype', DT, ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', HEIGHT_CASES, ids=['x'.join(str(v) for v in c) for c in HEIGHT_CASES])
+def test_every_tile_height_gives_the_same_bits(case, dtype):
+    """round 5: the 128-channel 3x3 kernel picks its pixel-tile height (4 / 6 / 8 / 10 rows of 16 per wave) per launch; every height walks the
+    taps in the same order, so forward (bias + activation), fused statistics and input gradient (with an addend) must not depend on it."""
+    from rdfc_gan_amd import hip
+    N, H, W, Ci, Co = case
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(N, H, W, Ci, device=DEV, generator=g).to(dtype)
+    w = torch.randn(Co, Ci, 3, 3, device=DEV, generator=g) * (0.7 / (Ci * 9) ** 0.5)
+    b = torch.randn(Co, device=DEV, generator=g) * 0.1
+    gy = torch.randn(N, H, W, Co, device=DEV, generator=g).to(dtype)
+    add = torch.randn(N, H, W, Ci, device=DEV, generator=g).to(dtype)
+    wf, wb = hip.pack_weight(w.contiguous(), dtype)
+    d = hip.conv_desc(x.shape, Co, 3, 1, 1, ldx=Ci, ldy=Co, dtype=hip.dt(x), act='lrelu', slope=0.2)
+    d0 = hip.conv_desc(x.shape, Co, 3, 1, 1, ldx=Ci, ldy=Co, dtype=hip.dt(x))
+    lib = hip.lib()
+    ref, ref_stats, names = None, None, set()
+    try:
+        for jr in (4, 6, 8, 10):
+            stats = None
+            lib.rdfc_tune_glds_rows(jr)
+            y = torch.full((N, H, W, Co), 3.0, dtype=dtype, device=DEV)
+            hip.conv_forward(d, x, wf, b, y)
+            names.add(lib.rdfc_last_kernel().decode())
+            out = [y]
+            if hip.conv_stats_nchunk(d0, 1) > 0:
+                y2 = torch.full((N, H, W, Co), 3.0, dtype=dtype, device=DEV)
+                mean, rstd = hip.conv_forward_stats(d0, x, wf, b, y2, 1, 1e-5)
+                out += [y2]                                     # (the statistics themselves: a different tiling adds the partial rows in a different order -- compared to 1e-6 below)
+                stats = (mean.clone(), rstd.clone())
+            dx = torch.full_like(x, 3.0)
+            hip.conv_dgrad(d0, gy, wb, None, dx, addend=add)
+            out.append(dx)
+            if ref is None:
+                ref, ref_stats = out, stats
+            else:
+                for i, (a, r) in enumerate(zip(out, ref)):
+                    assert torch.equal(a, r), (jr, i, float((a.float() - r.float()).abs().max()))
+                for a, r in zip(stats or (), ref_stats or ()):
+                    assert float((a - r).abs().max() / r.abs().max()) < 1e-6
+    finally:
+        lib.rdfc_tune_glds_rows(0)
+    assert len(names) == 4, names                               # four different instantiations ran

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # what a forced tile height of the 3x3 kernel has to pass: every conv / statistics / reflection / addend test of test_kernels_gpu.py and the
 # adjointness + value tests at the benchmark's launch sizes
-JRK = '(conv or stat or reflect or addend or adjoint or values_against) and not f32 and not under_load and not scaling'
+JRK = '(conv or stat or reflect or addend or adjoint) and not f32 and not under_load and not scaling and not values_against and not tile_height'
 VARIANTS = [
     ('RDFC_GLDS', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and bf16'),   # register-staged predecessors of the LDS-DMA 3x3 kernel
     ('RDFC_WGRAD_RING', '0', '(test_conv_fwd_dgrad_wgrad and not f32) or reflection_pad_folded'),   # segment walk + float atomics instead of the ring kernel
@@ -21,7 +21,8 @@ VARIANTS = [
     ('RDFC_T3S2', '3', '(test_conv_fwd_dgrad_wgrad or conv_transpose or dgrad_with_addend) and not f32'),   # ... and the patch kernel also on the small launches the default leaves to igemm_glds (its one- and two-addend epilogues included)
     ('RDFC_GLDS_STACK', '0', '(test_conv_fwd_dgrad_wgrad or conv_transpose) and not f32'),   # per-image row tiles in the 3x3 kernel
     # round 5: every tile height of the 128-channel 3x3 / stride-1 kernel (the default picks one per launch: conv_glds.hip glds_plan) on every
-    # conv test incl. fused statistics, reflection fold, addends, stacked batches and the full-size properties
+    # conv test incl. fused statistics, reflection fold, addends, stacked batches and the full-size adjointness (that all heights give the same
+    # bits at the benchmark's sizes is test_fullsize_gpu.py::test_every_tile_height_gives_the_same_bits, in one process)
     ('RDFC_GLDS_JR', '4', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
     ('RDFC_GLDS_JR', '6', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
     ('RDFC_GLDS_JR', '8', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),

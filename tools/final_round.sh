@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box, repo root): bash tools/final_round.sh r03   -> every artefact of a round under gpurun_out/<tag>_*
-tag=${1:-r04}
+tag=${1:-r05}
 mkdir -p gpurun_out
 bash tools/pmc_bench.sh $tag                                                # HBM-side bytes per kernel (separate --pmc passes)
 cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json       # (this box's copy: the bench line below cites counters of THIS build)
@@ -20,6 +20,7 @@ python bench.py --steps 10 --warmup 3 --no-cpu-baseline --dtype f16 --height 480
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --dtype f32 > gpurun_out/${tag}_f32_bench.json 2>/dev/null
 # every conv shape alone (one stream)
 RDFC_BRANCH_STREAMS=0 RDFC_NET_STREAMS=0 RDFC_WGRAD_STREAM=0 RDFC_D_UNDER_G=0 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-as-worded --event-every 1 --by-shape gpurun_out/${tag}_by_shape_one_stream.txt > gpurun_out/${tag}_bench_one_stream.json 2>/dev/null
+JRS=4,6,8,10 python tools/conv_tall_bench.py 3 10 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_conv_tall_ab.txt     # the 3x3 kernel at every forced tile height against the plan's choice
 for f in ${tag}_bench ${tag}_bench_under_rocprof ${tag}_rccl_one_rank_bench ${tag}_nlspn_bench ${tag}_bf16_bench ${tag}_f16_480x640_bench ${tag}_f32_bench ${tag}_bench_one_stream; do
 python3 - gpurun_out/$f.json <<'PY'
 import json,sys
