@@ -195,7 +195,7 @@ def test_config3_batch8_step_against_oracle(monkeypatch):
     """BASELINE configs[2] at its own batch: ONE optimisation step of the four-network schedule with NLSPN on (18 propagation steps, TGASS,
     confidence propagation) at batch 8, 228x304, f32 parity mode, against oracle.step.HotPathStep running upstream's literal schedule on
     the host with the oracle's NLSPN (round-4 verdict: config #3 had only been compared at B = 1 / through the bench).  Every loss entry,
-    fake_B / fake_A and the norms of the updated weights; limits are 2x what MI355X measured (in the comment)."""
+    fake_B / fake_A and the norms of the updated weights; limits are 2-3x what MI355X measured (in the comment at the assertion)."""
     from oracle import nets as onets
     from oracle.step import HotPathStep
     from rdfc_gan_amd import rdfc_gan as rg
@@ -233,7 +233,9 @@ def test_config3_batch8_step_against_oracle(monkeypatch):
                 r = ref_norms[key][n]
                 worst_n = max(worst_n, abs(float(v.double().norm()) - r) / (abs(r) + 1e-4))
     print(f'[config 3, batch 8, f32] losses worst rel {worst_l:.2e}; fake_B max {float(dB.max()):.2e} fake_A max {float(dA.max()):.2e}; weight norms worst rel {worst_n:.2e}')
-    assert worst_l < 2e-4 and float(dB.max()) < 2e-3 and float(dA.max()) < 2e-4 and worst_n < 2e-3, (worst_l, float(dB.max()), float(dA.max()), worst_n)
+    # measured on MI355X (round 5): losses 9.4e-8, fake_B 1.05e-4, fake_A 1.5e-5, weight norms 6.3e-4 (Adam's first lr-sized step amplifies the
+    # f32 summation-order differences of the gradients: the norm statistic is the loosest of the four)
+    assert worst_l < 2e-6 and float(dB.max()) < 3e-4 and float(dA.max()) < 5e-5 and worst_n < 1.5e-3, (worst_l, float(dB.max()), float(dA.max()), worst_n)
 
 
 def test_config3_nlspn_18_steps_228x304_against_oracle():
