@@ -33,6 +33,55 @@ PEAK_TFLOPS = dict(bf16=2500.0, f16=2500.0, f32=157.3)        # dense MFMA peaks
 PEAK_HBM_GBS = 8000.0                                         # HBM3E spec (6 290 GB/s measured by a float4 copy), MI355X_MICROARCH.md
 
 
+def _log(msg):
+    """progress on stderr (rank 0): the default run takes several minutes -- headline, three extra legs, a CPU baseline of ~6 minutes"""
+    if int(os.environ.get('RANK', 0)) == 0:
+        print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def pmc_table(suffix=''):
+    """the newest committed rocprofv3 --pmc summary of a workload: profiles/rNN_pmc_traffic<suffix>.json (tools/pmc_bench.sh; suffix '' = the
+    headline command, '_bf16', '_nlspn', '_480x640' = the extra legs).  -> (table without _meta, _meta, file name) or (None, None, None)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_pmc_traffic{suffix}.json')):
+        m = re.match(r'r(\d\d)_pmc_traffic' + re.escape(suffix) + r'\.json$', os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None, None, None
+    tab = json.load(open(best[1]))
+    meta = tab.pop('_meta', {})
+    return tab, meta, os.path.relpath(best[1], ROOT)
+
+
+def pmc_for_kernel(roof, top, suffix, loaded_hash):
+    """fill roofline['traffic'] / ['mfma_busy'] of the dominant kernel `top` from the workload's PMC summary; counters taken from other
+    kernel sources than the loaded library's are refused.  -> the summary's _meta (or None)"""
+    tab, meta, fname = pmc_table(suffix)
+    if tab is None:
+        return None
+    if meta.get('csrc_sha16') != loaded_hash:
+        roof['traffic_note'] = (f"{fname} was measured on kernel sources {meta.get('csrc_sha16')}, the loaded library was built from "
+                                f'{loaded_hash}: stale counters refused (re-run tools/pmc_bench.sh)')
+        return None
+    for k, v in tab.items():
+        if top + '(' in k:
+            roof['traffic'] = round(v['fetch_bytes'] + v['write_bytes'])
+            roof['traffic_note'] = (f"bytes per launch (read {v['fetch_bytes'] / 1e6:.1f} MB + write {v['write_bytes'] / 1e6:.1f} MB), "
+                                    f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_bench.sh over this workload ({fname}), kernel sources {meta.get('csrc_sha16')}")
+            if v.get('mfma_busy_cycles'):
+                # third --pmc pass of the same script: cycles the matrix pipes were busy, summed over the chip's 1 024 SIMDs, per launch,
+                # against the SIMD-cycles of this run's average launch at the 2.4 GHz peak clock (an upper bound for the clock, so a
+                # lower bound for the busy fraction)
+                simd_cycles = roof['avg_launch_us'] * 2400.0 * 1024
+                roof['mfma_busy'] = dict(cycles_per_launch=round(v['mfma_busy_cycles']), mfma_insts_per_launch=round(v['mfma_insts']),
+                                         frac_of_simd_cycles=round(v['mfma_busy_cycles'] / simd_cycles, 4),
+                                         note=f'SQ_VALU_MFMA_BUSY_CYCLES per launch ({fname}) / (avg_launch_us x 2.4 GHz x 1024 SIMDs)')
+    return meta
+
+
 def step_gflop_per_pair(exact_schedule, scale=1.0, label_net=False):
     """G nets: fwd x3 (x2 when the dead forwards are elided) + bwd x2 (bwd = 2x fwd);
     D nets: fwd x3 + input-gradient-only pass x1 + full bwd x2; G_label (--label-net): fwd x2 + bwd x2."""
@@ -110,10 +159,14 @@ def cpu_baseline(B, H, W, exact_schedule=True, budget_s=150.0, steps=0):
         st.step(lambda tag: nrm)
         return time.perf_counter() - t0
 
+    _log(f'cpu_baseline: 1 warm-up step at batch 1 + {steps if steps > 0 else "up to 3"} timed step(s) at batch {B} on {torch.get_num_threads()} threads '
+         f'(~2 minutes each on a 128-thread GPU-box host; --cpu-steps 0 keeps to a {budget_s:.0f} s budget, --no-cpu-baseline skips it) ...')
     warm = one(1)
     times = [one(B)]
+    _log(f'cpu_baseline: step 1 took {times[0]:.1f} s')
     while len(times) < steps if steps > 0 else (len(times) < 3 and sum(times) + times[-1] <= budget_s):
         times.append(one(B))
+        _log(f'cpu_baseline: step {len(times)} took {times[-1]:.1f} s')
     times.sort()
     med = times[len(times) // 2]
     return dict(value=round(B / med, 5), unit='pairs/s', cores=torch.get_num_threads(), kind='port',
@@ -218,22 +271,28 @@ def comm_in_step(model, one_step, steps, dev):
     med = lambda v: round(sorted(v)[len(v) // 2], 3) if v else None
     in_step = [dict(optimizer=k[0], bucket=k[1], wait_order=r['order'], ready_at_ms=med(r['ready']), consumer_asks_at_ms=med(r['asked']),
                     exposed_wait_ms=med(r['stall'])) for k, r in sorted(rows.items(), key=lambda kv: kv[1]['order'])]
+    # (the flag is a module global: whatever happens inside, later collectives must not stay switched off; and the steps below apply every
+    #  rank's LOCAL gradients, so weights, Adam moments and the loss-scaler state drift apart -- rank 0's state is broadcast again afterwards)
     optim.COLLECTIVES_OFF = True
-    one_step(0)
-    torch.cuda.synchronize()
-    if dist.get_world_size() > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        one_step(i)
-    torch.cuda.synchronize()
-    off = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    optim.COLLECTIVES_OFF = False
+    try:
+        one_step(0)
+        torch.cuda.synchronize()
+        if dist.get_world_size() > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one_step(i)
+        torch.cuda.synchronize()
+        off = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    finally:
+        optim.COLLECTIVES_OFF = False
+    optim.resync_replicas(model.models.values(), model.optimizers.values())
     dist.all_reduce(off, op=dist.ReduceOp.MAX)
     return dict(in_step=in_step, exposed_wait_ms_per_step=round(sum(r['exposed_wait_ms'] or 0.0 for r in in_step), 3),
                 ms_per_step_collectives_off=round(1e3 * float(off) / steps, 3),
                 note='in_step: medians over 4 traced steps, times from the step\'s first launch; exposed_wait = how long the consuming stream stalled for '
-                     'the bucket; ms_per_step_collectives_off: the same step with every collective skipped (max over ranks) -- compare with ms_per_step')
+                     'the bucket; ms_per_step_collectives_off: the same step with every collective skipped (max over ranks) -- compare with ms_per_step; '
+                     'the replicas are re-synchronised from rank 0 after that leg (parameters, buffers, Adam moments, step counts, loss scale)')
 
 
 def main():
@@ -270,6 +329,9 @@ def main():
     ap.add_argument('--graph', action='store_true', help='capture the step into HIP graphs and replay them (single stream; on ROCm 7.2 the '
                     'replay costs about as much per node as an eager launch, so the multi-stream eager step is faster)')
     ap.add_argument('--event-every', type=int, default=20, help='per-kernel HIP events on every n-th timed step, the first one included (eager mode; such a step takes ~8 % longer: ~1 000 event pairs and the normalisation layers as one call per kernel)')
+    ap.add_argument('--n1-value', type=float, default=None, help='pairs/s of the N = 1 run on the same box: the line then carries `scaling_efficiency_vs_n1` = '
+                    'value / (n_gpus x this).  Or --n1-line FILE with the JSON line of that run')
+    ap.add_argument('--n1-line', default=None, help='file holding the JSON line of the N = 1 run on the same box (its last line starting with "{" is read)')
     ap.add_argument('--by-shape', default=None, help='write a per-conv-shape time / TFLOP/s table (debug aid) to this file')
     a = ap.parse_args()
 
@@ -293,7 +355,11 @@ def main():
         if a.rccl_self_test:          # one rank, every collective of the step through RCCL all the same (rdfc_gan_amd/optim.py dp_active)
             assert world == 1
             os.environ['RDFC_DP_FORCE'] = '1'
-            for k, v in (('MASTER_PORT', '29533'), ('RANK', '0'), ('WORLD_SIZE', '1')):
+            import socket
+            with socket.socket() as sk:                   # (a free rendezvous port: a fixed one collides with a second session on the box)
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+            for k, v in (('MASTER_PORT', str(port)), ('RANK', '0'), ('WORLD_SIZE', '1')):
                 os.environ.setdefault(k, v)
         backend = os.environ.get('RDFC_BENCH_BACKEND', 'nccl')
         dist.init_process_group(backend, **(dict(device_id=dev) if backend == 'nccl' else {}))
@@ -326,6 +392,11 @@ def main():
     # weight gradients).  --graph: after one eager warm-up step the step is captured into three HIP graphs (G step | D step |
     # Adam; the data-parallel all-reduces stay eager between them) and replayed.
     graphed = a.graph
+    if rank == 0:
+        legs = a.dtype == 'f16' and world == 1 and not a.no_as_worded and not graphed and not a.label_net and not a.nlspn
+        _log(f'headline: {a.warmup} warm-up + {a.steps} timed steps'
+             + ('; then extra legs (bf16 as worded, #3 NLSPN, #5 480x640: ~1 minute)' if legs else '')
+             + ('' if a.no_cpu_baseline or world > 1 else f'; then the CPU baseline (--cpu-steps {a.cpu_steps}: ~{2 * max(a.cpu_steps, 1) + 0.5:.0f} minutes of host time)'))
     for i in range(a.warmup):
         if graphed and i == 1:
             model.enable_graph(True)
@@ -450,6 +521,17 @@ def main():
                    unsynced_ms_per_step=round(1e3 * unsynced[0] / a.steps, 3) if unsynced else None, launch='eager, 4 streams (main | depth branch, then the discriminators\' step | weight gradients | D_B\'s G-loss pass), batched calls' if not graphed else 'hip graphs (3 per step), one stream',
                    step_tflops=round(pairs_s * gflop_pair / 1e3, 2),
                    step_frac_of_mfma_peak=round(pairs_s * gflop_pair / 1e3 / (PEAK_TFLOPS[a.dtype] * world), 4))
+        # multi-GPU reading aids (the driver computes scaling efficiency itself from the per-N `value`s; these only make one line self-explanatory)
+        out['value_per_gpu'] = round(pairs_s / world, 3)
+        n1 = a.n1_value
+        if n1 is None and a.n1_line:
+            try:
+                n1 = float(json.loads([l for l in open(a.n1_line).read().splitlines() if l.startswith('{')][-1])['value'])
+            except (OSError, IndexError, KeyError, ValueError) as e:
+                out['scaling_efficiency_note'] = f'--n1-line {a.n1_line}: unreadable ({e})'
+        if n1:
+            out['scaling_efficiency_vs_n1'] = round(pairs_s / (world * n1), 4)
+            out['n1_value'] = n1
         out['rmse_dev_m'] = round(rmse_dev, 6)        # eval-path dense-depth RMSE of this dtype against the f32 parity mode, metres (north star: <= 1e-3)
         if model.scaler is not None:
             out['loss_scale'] = dict(scale=model.scaler.scale(), dynamic=model.scaler.dynamic, skipped_steps=model.scaler.skipped())
@@ -478,29 +560,15 @@ def main():
             # committed rocprofv3 passes over this same command (tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
             # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), apply to the default workload only and
             # are refused when they were taken from other kernel sources than the ones this library was built from
-            tfile = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
-            default_wl = (a.batch, a.height, a.width, a.dtype, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, 'f16', False, False, False)   # (--full-objective sets label_net)
-            if default_wl and os.path.exists(tfile):
-                tab = json.load(open(tfile))
-                meta = tab.pop('_meta', {})
-                loaded = hip.build_hash()                  # compiled into the library that is actually loaded
-                if meta.get('csrc_sha16') != loaded:
-                    out['roofline']['traffic_note'] = (f"profiles/r05_pmc_traffic.json was measured on kernel sources {meta.get('csrc_sha16')}, the loaded library was built from "
-                                                       f'{loaded}: stale counters refused (re-run tools/pmc_bench.sh)')
-                else:
-                    for k, v in tab.items():
-                        if top + '(' in k:
-                            out['roofline']['traffic'] = round(v['fetch_bytes'] + v['write_bytes'])
-                            out['roofline']['traffic_note'] = (f"bytes per launch (read {v['fetch_bytes'] / 1e6:.1f} MB + write {v['write_bytes'] / 1e6:.1f} MB), "
-                                                               f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_bench.sh over this command, kernel sources {meta.get('csrc_sha16')}")
-                            if v.get('mfma_busy_cycles'):
-                                # third --pmc pass of the same script: cycles the matrix pipes were busy, summed over the chip's 1 024 SIMDs, per launch,
-                                # against the SIMD-cycles of this run's average launch at the 2.4 GHz peak clock (an upper bound for the clock, so a
-                                # lower bound for the busy fraction)
-                                simd_cycles = out['roofline']['avg_launch_us'] * 2400.0 * 1024
-                                out['roofline']['mfma_busy'] = dict(cycles_per_launch=round(v['mfma_busy_cycles']), mfma_insts_per_launch=round(v['mfma_insts']),
-                                                                    frac_of_simd_cycles=round(v['mfma_busy_cycles'] / simd_cycles, 4),
-                                                                    note='SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/r05_pmc_traffic.json) / (avg_launch_us x 2.4 GHz x 1024 SIMDs)')
+            default_wl = (a.batch, a.height, a.width, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, False, False, False)   # (--full-objective sets label_net)
+            suffix = {'f16': '', 'bf16': '_bf16'}.get(a.dtype) if default_wl else ('_nlspn' if (a.batch, a.height, a.width, a.dtype, a.nlspn, a.label_net, a.exact_schedule) == (8, 228, 304, 'f16', True, False, False) else None)
+            if suffix is not None:
+                meta = pmc_for_kernel(out['roofline'], top, suffix, hip.build_hash())
+                if meta is not None and meta.get('fabric_gb_per_step') is not None:
+                    # every kernel's (FETCH_SIZE x 2 + WRITE_SIZE) x launches of the profiled steps / those steps: what a step moves between the
+                    # L2s and the fabric (Infinity Cache + HBM); by category in the summary's _meta
+                    out['fabric_gb_per_step'] = meta['fabric_gb_per_step']
+                    out['fabric_gb_per_step_by_category'] = meta.get('fabric_gb_by_category')
             if iso:
                 ifl = sum(r[1] for r in iso if r[5] == top)
                 isec = sum(r[2].elapsed_time(r[3]) * 1e-3 for r in iso if r[5] == top)
@@ -559,7 +627,8 @@ def main():
             del model
             torch.cuda.empty_cache()
 
-            def leg(dtype, nlspn, batch, H, W, tag):
+            def leg(dtype, nlspn, batch, H, W, tag, pmc_suffix):
+                _log(f'extra leg: {tag[:60]} ...')
                 Fh.set_compute_dtype(dict(bf16=torch.bfloat16, f16=torch.float16)[dtype])
                 Fh.invalidate_packed_weights()
                 torch.manual_seed(0)
@@ -611,15 +680,18 @@ def main():
                     if inum:
                         r['roofline']['isolated'] = dict(achieved=round(ifl / isec / 1e12, 2), frac=round(ifl / isec / 1e12 / PEAK_TFLOPS[dtype], 4),
                                                          avg_launch_us=round(1e6 * isec / inum, 2), launches=inum)
+                    lmeta = pmc_for_kernel(r['roofline'], top_, pmc_suffix, hip.build_hash())
+                    if lmeta is not None and lmeta.get('fabric_gb_per_step') is not None:
+                        r['fabric_gb_per_step'] = lmeta['fabric_gb_per_step']
                 del m
                 torch.cuda.empty_cache()
                 return r
-            out['as_worded_bf16'] = leg('bf16', False, a.batch, a.height, a.width, 'BASELINE configs[1] as worded: the headline workload with bf16 conv operands')
+            out['as_worded_bf16'] = leg('bf16', False, a.batch, a.height, a.width, 'BASELINE configs[1] as worded: the headline workload with bf16 conv operands', '_bf16')
             out['as_worded_bf16']['note'] = 'same process, same box, same schedule and protocol as the headline, after the f16 measurement'
             if (a.batch, a.height, a.width) == (8, 228, 304):
                 out['configs'] = {
-                    '#3_nlspn': leg('f16', True, 8, 228, 304, 'BASELINE configs[2]: configs[1] + NLSPN propagation (18 steps, TGASS, confidence propagation; f32 gather kernels)'),
-                    '#5_480x640_b4_f16': leg('f16', False, 4, 480, 640, "BASELINE configs[4]'s per-GPU shape: SUN RGB-D 640x480 inputs, batch 4, f16 activations, f32 loss accumulation"),
+                    '#3_nlspn': leg('f16', True, 8, 228, 304, 'BASELINE configs[2]: configs[1] + NLSPN propagation (18 steps, TGASS, confidence propagation; f32 gather kernels)', '_nlspn'),
+                    '#5_480x640_b4_f16': leg('f16', False, 4, 480, 640, "BASELINE configs[4]'s per-GPU shape: SUN RGB-D 640x480 inputs, batch 4, f16 activations, f32 loss accumulation", '_480x640'),
                 }
             Fh.set_compute_dtype(torch.float16)
         if not a.no_cpu_baseline and world == 1:    # rank 0 at N=1 only

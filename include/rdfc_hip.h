@@ -45,6 +45,11 @@ const char *rdfc_last_kernel(void);
  * (rows of 16 pixels per wave: 4 | 6 | 8 | 10; 0 = chosen per launch, the default; same as RDFC_GLDS_JR in the environment).
  * Results do not depend on it.  No upstream counterpart. */
 void rdfc_tune_glds_rows(int rows_per_wave);
+/* Measurement aid (tools/wgrad_ring_bench.py): which weight-gradient launches the ring kernel takes -- 0 none (tap-gather / segment-walk
+ * kernels with float atomics), 1 3x3 / stride 1 only, 2 (default) also stride 2 and 4x4, 3 also the launches the default leaves to the
+ * older kernels by measurement; the initial value comes from RDFC_WGRAD_RING, read once.  Process-wide, not thread-safe.  No upstream
+ * counterpart. */
+void rdfc_tune_wgrad_ring(int mode);
 int rdfc_version(void);
 /* sha256 (first 16 hex digits) of the kernel sources this library was built from (rdfc_gan_amd/build.py: source_hash()): measurement
  * artefacts under profiles/ carry it, and bench.py refuses counters taken from another build.  No upstream counterpart. */

@@ -625,6 +625,12 @@ static bool glds_shape_ok(const rdfc_conv_desc *d, int transposed) {
     const int ld_in = transposed ? d->ldy : d->ldx;
     const size_t in_bytes = 2 * (size_t)d->N * (transposed ? d->Ho : d->Hi) * (transposed ? d->Wo : d->Wi) * ld_in;
     if (in_bytes >= 0x7ffffff0u || 2 * (size_t)Cout * 9 * Cin >= 0x7ffffff0u) return false;     // the loaders address both through 32-bit byte offsets
+    {   // qdiv's range (2^22 tiles / virtual rows), bounded from the shape alone -- whatever tile height and stacking glds_plan then picks -- so
+        // that this test, the statistics-row query and the launch agree (round 5 tested it at the launch only: rdfc_conv3x3_glds_stats_nchunk
+        // could promise rows for a launch that was then refused).  16 x 480 x 640 is 2 % of it.
+        const long H = transposed ? d->Hi : d->Ho, W = transposed ? d->Wi : d->Wo;
+        if (2 * (long)d->N * (H + 4) + 64 >= (1L << 22) || (long)cdiv(W, TC) * d->N * (H / 8 + 3) >= (1L << 22)) return false;
+    }
     return ld_in % 8 == 0 && Cout >= 64;
 }
 
@@ -676,8 +682,10 @@ static int stack_groups(int N, int G, int H, int Hin, int oy0, int TR, int &tile
 struct GPlan {
     int jr, tiles_y, vstride, gstride;
 };
-static int g_glds_jr = getenv("RDFC_GLDS_JR") ? atoi(getenv("RDFC_GLDS_JR")) : 0;
-extern "C" void rdfc_tune_glds_rows(int jr) { g_glds_jr = jr; }    // measurement aid (tools/conv_tall_bench.py): A/B of the tile heights in one process
+// (a height the kernel is not instantiated for -- anything but 4, 6, 8, 10 -- means "no preference": glds_plan would otherwise skip every candidate)
+static int glds_jr_ok(int jr) { return (jr == 4 || jr == 6 || jr == 8 || jr == 10) ? jr : 0; }
+static int g_glds_jr = glds_jr_ok(getenv("RDFC_GLDS_JR") ? atoi(getenv("RDFC_GLDS_JR")) : 0);
+extern "C" void rdfc_tune_glds_rows(int jr) { g_glds_jr = glds_jr_ok(jr); }    // measurement aid (tools/conv_tall_bench.py): A/B of the tile heights in one process; not thread-safe
 static GPlan glds_plan(int N, int H, int W, int Hin, int oy0, int Cin, int Cout, int G, bool reflect) {
     const int forced = g_glds_jr;
     auto tiles = [&](int TR, GPlan &g) {
@@ -748,6 +756,7 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
         p.npg = p.N / G;
     }
     const GPlan g = glds_plan(p.N, p.H, p.W, p.Hin, p.oy0, Cin, Cout, stats != nullptr ? G : 0, reflect != 0);
+    if (g.tiles_y <= 0) return 0;                              // (no plan: an empty grid must not count as "launched")
     p.tiles_y = g.tiles_y;
     p.vstride = g.vstride;
     p.gstride = g.gstride;

@@ -47,6 +47,16 @@ __device__ __forceinline__ void qdiv(int a, int d, float rd, int &q, int &r) {
 
 // one LDS-DMA instruction through a buffer descriptor: lane l reads 16 bytes at base + soff + voff (voff per lane, soff wave-uniform)
 // and lands at lds_base + 16 l; a lane whose voff is not below num_records arrives as zeros (conv_glds.hip: bdma16)
+// the same for 0 <= a < 2^31 through a double reciprocal (the flat pixel index of a large batch: 8 x 480 x 640 is beyond qdiv's 2^21; once per
+// gathered pixel in the set-up, three f64 instructions)
+__device__ __forceinline__ void qdiv_wide(int a, int d, double rd, int &q, int &r) {
+    q = (int)((double)a * rd);
+    r = a - q * d;
+    const int lo = r < 0 ? 1 : 0, hi = r >= d ? 1 : 0;
+    q += hi - lo;
+    r += (lo - hi) * d;
+}
+
 constexpr unsigned DEAD = 0x80000000u;
 __device__ inline void bdma16(unsigned voff, u32x4 rsrc, unsigned soff, unsigned lds_base) {
     // m0 is declared clobbered, not saved and restored (the compiler uses it for nothing else in this kernel; clang warns that m0 is
@@ -126,14 +136,15 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
         if (lane == 0) ntaps_s = __popcll(mask);
     }
     // this thread's NB gathered pixels: tile rows (k * NT + tid) >> 2, 16-byte slot tid & 3
-    const float r_hw = __builtin_amdgcn_rcpf((float)HW), r_wb = __builtin_amdgcn_rcpf((float)Wb);
+    const double r_hw = 1.0 / (double)HW;                        // (m runs over the whole batch: qdiv_wide; the remainder is < HW < 2^21)
+    const float r_wb = __builtin_amdgcn_rcpf((float)Wb);
     int pnb[NB], pyy[NB], pxx[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const int row = (k * NT + tid) >> 2, m = m0 + row;
         const bool in = m < Pc;
         int n, r, a, b;
-        qdiv(in ? m : 0, HW, r_hw, n, r);
+        qdiv_wide(in ? m : 0, HW, r_hw, n, r);
         qdiv(r, Wb, r_wb, a, b);
         pnb[k] = in ? n * p.Hin * p.Win : -1;
         int po;
@@ -381,7 +392,10 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
     p.row_store = !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
-    if ((long)p.N * p.Hout * p.Wout >= (1L << 21) || d->KH * d->dh + d->ph > 1000 || d->KW * d->dw + d->pw > 1000 || d->sh > 1000 || d->sw > 1000) return 0;   // (qdiv's range)
+    // qdiv's range: one image's (parity class of) output pixels and the stride / tap arithmetic below 2^21; the batch's flat pixel index goes
+    // through qdiv_wide (round 5 refused N * Hout * Wout >= 2^21 here -- batch 8 at 480 x 640 fell back to the register-staged kernel silently)
+    if ((long)p.Hout * p.Wout >= (1L << 21) || (long)p.N * p.Hout * p.Wout >= 0x7fffff00L || d->KH * d->dh + d->ph > 1000 || d->KW * d->dw + d->pw > 1000 ||
+        d->sh > 1000 || d->sw > 1000) return 0;
     p.r_sh = 1.f / (float)d->sh;
     p.r_sw = 1.f / (float)d->sw;
     p.r_kw = 1.f / (float)d->KW;

@@ -41,13 +41,6 @@ struct RParams {
 
 constexpr int SEG = 32, NT = 256;
 
-__device__ inline void glds16(const void *gsrc, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_base)
-                 : "memory");
-}
 template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // swizzle of the 32-byte channel-pair index by image row (conv_wgrad_glds.hip: conflict-free transposing reads for every kx)
@@ -56,213 +49,17 @@ template <int ROWB> __device__ inline int pair_swz(int row) {
     else return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
 }
 
-// fragment: 16 channels [cbase, cbase+16) x 32 pixels (image rows (row0 + i) & MASK, i = 0..31) -> 8 consecutive pixels per lane
-template <int ROWB, int MASK> __device__ inline bf16x8 tr_frag(const unsigned char *img, int row0, int cbase, int lane) {
-    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-    const int r0 = (row0 + 8 * g + q) & MASK, r1 = (r0 + 4) & MASK, cp = cbase >> 4;
-    const unsigned char *a0 = img + r0 * ROWB + ((cp ^ pair_swz<ROWB>(r0)) << 5) + pp * 8;
-    const unsigned char *a1 = img + r1 * ROWB + ((cp ^ pair_swz<ROWB>(r1)) << 5) + pp * 8;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a1);
-    // (assembled from 32-bit halves: an element-wise s16x8 initialiser costs four v_mov per read -- 96 per k-step, as much
-    //  vector-issue time as the k-step's 24 MFMAs)
-    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-    const u32x4 r = {l2[0], l2[1], h2[0], h2[1]};
-    return __builtin_bit_cast(bf16x8, r);
-}
-
 // tap kx of a kernel row -> (parity plane, shift within the plane's flat sequence)
 template <int S> __device__ constexpr int tap_plane(int kx) { return S == 1 ? 0 : ((kx & 1) ^ 1); }
 template <int S> __device__ constexpr int tap_shift(int kx) { return S == 1 ? kx : (kx + 1) / 2; }
 
-template <int TCO, int DT, int S = 1, int K = 3>
-__global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring_kernel(RParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
-                                                                          float *__restrict__ slab, const bf16_t *__restrict__ zero) {
-    constexpr int TCI = 64, NPL = S;                            // X planes per kernel row
-    constexpr int LOOK = S == 1 ? 3 : 2, RY = LOOK + 1, XR = S == 1 ? 8 : 4;
-    constexpr int YROW = TCO * 2, XROW = TCI * 2;               // bytes per pixel row of the two images
-    constexpr int YB = SEG * YROW, XBLK = SEG * XROW;           // 8 | 4 KB per dY slot, 4 KB per X block
-    constexpr int NY = YB / (NT * 16), NX = XBLK / (NT * 16);   // DMAs per thread and k-step: dY 2 | 1, X 1 per plane
-    constexpr int PER_STEP = NY + NPL * NX;
-    constexpr int CPY = TCO / 8, CPX = TCI / 8;                 // 16-byte chunks per pixel
-    constexpr int OFF_X = RY * YB, XRING = XR * XBLK, XMASK = XR * SEG - 1;
-    constexpr int WCO = TCO / 64, WCI = 4 / WCO;                // waves along co / ci
-    constexpr int WTCO = TCO / WCO, WTCI = TCI / WCI;           // wave tile: 64 co x (32 | 16) ci
-    constexpr int MT = WTCO / 16, NTF = WTCI / 16;
-    static_assert(XR >= LOOK + 2 && (XR & (XR - 1)) == 0, "X ring: a power of two, at least LOOK + 2 blocks");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = blockIdx.y, slice = blockIdx.x;
-    if (p.xcd_group) {           // all the tiles of one K slice on ONE XCD (they re-read the same dY / X pixels), eight slices side by side
-        const int k = blockIdx.x >> 3;
-        tile = k % p.tiles;
-        slice = (k / p.tiles) * 8 + (blockIdx.x & 7);
-    }
-    if (slice >= p.nslices) return;
-    const int ky = tile % K;
-    tile /= K;
-    const int ci0 = (tile % p.tiles_ci) * TCI, co0 = (tile / p.tiles_ci) * TCO;
-    const int seg0 = slice * p.steps_per_slice;
-    int nseg = p.total_steps - seg0;
-    if (nseg > p.steps_per_slice) nseg = p.steps_per_slice;
-
-    // ---- lane-constant parts of the DMA sources -------------------------------------------------------------------------------
-    // piece k of a step: wave-instruction (k * 4 + wave) of the block = positions g .. g + 64 / CP - 1, g = (k * NT + wave * 64) / CP;
-    // lane: position g + lane / CP, LDS slot lane % CP, which holds source chunk slot ^ 2 * swz(row in block)
-    int ylane[NY], ygrp[NY], xlane[NX], xgrp[NX], xcol[NX];
-    const int ylp = lane / CPY, xlp = lane / CPX;
-#pragma unroll
-    for (int k = 0; k < NY; ++k) {
-        ygrp[k] = (k * NT + wave * 64) / CPY;
-        const int px = ygrp[k] + ylp, slot = lane % CPY;
-        ylane[k] = ylp * p.ldy + co0 + ((slot ^ (2 * pair_swz<YROW>(px))) << 3);
-    }
-#pragma unroll
-    for (int k = 0; k < NX; ++k) {
-        xgrp[k] = (k * NT + wave * 64) / CPX;
-        const int px = xgrp[k] + xlp, slot = lane % CPX;
-        xcol[k] = ci0 + ((slot ^ (2 * pair_swz<XROW>(px))) << 3);
-        xlane[k] = xlp * S * p.ldx + xcol[k];                   // (plane 1 adds one pixel: + ldx)
-    }
-
-    // ---- wave-uniform cursors of the next dY / X' block to issue, advanced incrementally (no multiply in the loop) ---------------
-    // a cursor's base pointer addresses the pixel at (its row, its column) of the UNPADDED map -- "virtually" while the column is
-    // one of the L - Wo padding positions: it is only ever dereferenced by lanes whose column is inside the row
-    int jy, rowy, jx, yx, imgx;
-    const bf16_t *ybase, *xbase;
-    {
-        const long f = (long)seg0 * SEG;
-        const int row = (int)(f / p.L), j = (int)(f - (long)row * p.L), img = row / p.Ho, y = row - img * p.Ho;
-        jy = jx = j;
-        rowy = row;
-        yx = y;
-        imgx = img;
-        ybase = dy + ((long)row * p.Wo + j) * p.ldy;
-        xbase = x + (((long)img * p.Hi + S * y + ky - p.pad) * p.Wi + (S * j + p.xoff)) * p.ldx;
-    }
-    const int ywrap = (p.Wo - p.L) * p.ldy;                       // element offsets added when a column wraps into the next row ...
-    const int xwrap = S * (p.Wi - p.L) * p.ldx, ximg = (p.Hi - S * p.Ho) * p.Wi * p.ldx;      // ... / the next image
-    int ny_issued = 0, nx_issued = 0;                          // block indices of the next issues
-    auto issue_y = [&]() {                                     // dY block ny_issued -> slot ny_issued % RY
-        const bool live = ny_issued < nseg;
-        const unsigned slot = lds0 + (ny_issued % RY) * YB;
-#pragma unroll
-        for (int k = 0; k < NY; ++k) {
-            int j = jy + ygrp[k], row = rowy, off = ygrp[k] * p.ldy;
-            if (j >= p.L) { j -= p.L; ++row; off += ywrap; }
-            const int bound = (live && row < p.nrows) ? p.Wo - j : 0;            // lanes of this piece with a column below it are valid
-            glds16(ylp < bound ? ybase + off + ylane[k] : zero, slot + (k * NT + wave * 64) * 16);
-        }
-        if (live) {
-            jy += SEG;
-            ybase += SEG * p.ldy;
-            if (jy >= p.L) { jy -= p.L; ++rowy; ybase += ywrap; }
-        }
-        ++ny_issued;
-    };
-    auto issue_x = [&]() {                                     // X' block nx_issued (every plane) -> ring block nx_issued % XR
-        const bool live = nx_issued <= nseg;                   // (one block beyond the last dY block: its first positions are read)
-        const unsigned blk = lds0 + OFF_X + (nx_issued % XR) * XBLK;
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-            for (int k = 0; k < NX; ++k) {
-                int j = jx + xgrp[k], yy = yx, img = imgx, off = xgrp[k] * S * p.ldx + pl * p.ldx;
-                if (j >= p.L) {
-                    j -= p.L;
-                    off += xwrap;
-                    if (++yy == p.Ho) { yy = 0; ++img; off += ximg; }
-                }
-                int yin = S * yy + ky - p.pad;
-                int xin = S * (j + xlp) + p.xoff + pl;               // per lane
-                const bf16_t *src;
-                if (S == 1 && p.reflect) {                         // mirrored halo: row and column of the source follow the reflection
-                    yin = yin < 0 ? -yin : (yin >= p.Hi ? 2 * p.Hi - 2 - yin : yin);
-                    xin = xin < 0 ? -xin : (xin >= p.Wi ? 2 * p.Wi - 2 - xin : xin);
-                    src = x + (((long)img * p.Hi + yin) * p.Wi + xin) * p.ldx + xcol[k];
-                } else
-                    src = xbase + off + xlane[k];
-                const bool rowok = live && img < p.N && (unsigned)yin < (unsigned)p.Hi;
-                glds16(rowok && (unsigned)xin < (unsigned)p.Wi ? src : zero, blk + pl * XRING + (k * NT + wave * 64) * 16);
-            }
-        if (live) {
-            jx += SEG;
-            xbase += SEG * S * p.ldx;
-            if (jx >= p.L) {
-                jx -= p.L;
-                xbase += xwrap;
-                if (++yx == p.Ho) { yx = 0; ++imgx; xbase += ximg; }
-            }
-        }
-        ++nx_issued;
-    };
-
-    const int wr = wave / WCI, wc = wave % WCI;
-    f32x4 acc[K][MT][NTF];
-#pragma unroll
-    for (int t = 0; t < K; ++t)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NTF; ++j) acc[t][i][j] = f32x4{0, 0, 0, 0};
-
-    if (nseg > 0) {
-        issue_x();                                               // X' block 0
-#pragma unroll
-        for (int h = 0; h < LOOK; ++h) {                         // dY block h, X' block h + 1
-            issue_y();
-            issue_x();
-        }
-        for (int s = 0; s < nseg; ++s) {
-            wait_vm_and_reads<(LOOK - 1) * PER_STEP>();                    // everything issued up to step s - LOOK has landed: dY(s), X'(s), X'(s+1)
-            __builtin_amdgcn_s_barrier();
-            issue_y();                                           // dY(s + LOOK) -> the slot of step s - 1; X'(s + LOOK + 1) -> block s + LOOK + 1 - XR <= s - 1
-            issue_x();
-            const unsigned char *Ys = smem + (s % RY) * YB, *Xs = smem + OFF_X;
-            bf16x8 a[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = tr_frag<YROW, SEG - 1>(Ys, 0, wr * WTCO + 16 * i, lane);
-            const int xrow0 = (s % XR) * SEG;
-#pragma unroll
-            for (int t = 0; t < K; ++t) {
-                bf16x8 b[NTF];
-#pragma unroll
-                for (int j = 0; j < NTF; ++j)
-                    b[j] = tr_frag<XROW, XMASK>(Xs + tap_plane<S>(t) * XRING, xrow0 + tap_shift<S>(t), wc * WTCI + 16 * j, lane);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NTF; ++j) acc[t][i][j] = mma16<DT>(a[i], b[j], acc[t][i][j]);
-            }
-        }
-        wait_vm<0>();
-    }
-
-    // ---- this slice's partial tile -> slab[slice][co][ky * 3 + t][ci] (row co = 4 * (lane >> 4) + r, column ci = lane & 15) -------------
-    float *out = slab + (size_t)slice * p.Co * (K * K) * p.Ci;
-#pragma unroll
-    for (int t = 0; t < K; ++t)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NTF; ++j) {
-                const int ci = ci0 + wc * WTCI + 16 * j + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + wr * WTCO + 16 * i + 4 * (lane >> 4) + r;
-                    if (co < p.Co && ci < p.Ci) out[((size_t)co * (K * K) + ky * K + t) * p.Ci + ci] = acc[t][i][j][r];
-                }
-            }
-}
-
-// ---- round 5: the same walk with (almost) no vector or scalar address arithmetic in the loop -------------------------------------------
-// The loop above spends 94 vector and 138 scalar instructions on a k-step of 24 MFMAs (hipcc -S, tools/isa_loop.py): per-piece source
-// pointers with a zero-page select per lane, the swizzled address of every transposing read recomputed from the step's ring position, the
-// cursors' wrap logic as branches.  Two waves per SIMD cannot issue that beside 2 x 24 MFMAs: the kernel is issue-bound at 0.24 of the
-// matrix peak.  wgrad_ring2_kernel keeps the geometry (flat pixel walk, dY slots, X' ring, slab output: same bits) and changes how it
-// is addressed:
+// ---- round 5: the walk with (almost) no vector or scalar address arithmetic in the loop ----------------------------------------------
+// Round 3's kernel (wgrad_ring_kernel, removed in round 6 after a round as the A/B leg: bit-equal on all 20 benchmark shapes,
+// profiles/r05_wgrad_ring2_ab.txt) spent 94 vector and 138 scalar instructions on a k-step of 24 MFMAs (hipcc -S, tools/isa_loop.py):
+// per-piece source pointers with a zero-page select per lane, the swizzled address of every transposing read recomputed from the step's
+// ring position, the cursors' wrap logic as branches.  Two waves per SIMD cannot issue that beside 2 x 24 MFMAs: it was issue-bound at
+// 0.24 of the matrix peak.  wgrad_ring2_kernel keeps the geometry (flat pixel walk, dY slots, X' ring, slab output: same bits) and
+// changes how it is addressed:
 //   * LDS-DMA through buffer descriptors (conv_glds.hip: bdma16): a piece lies in ONE row of its map, so its descriptor is that row --
 //     base = the row's first byte (dY: the piece's first column), num_records = the row's extent -- and every lane's offset is a
 //     CONSTANT (dY) or a constant plus one wave-uniform column term (X': one v_add; a column left of the row wraps to a huge offset).
@@ -562,19 +359,6 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     }
 }
 
-const bf16_t *zero_page() {
-    static void *pages[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (pages[dev] == nullptr) {
-        void *ptr = nullptr;
-        if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
-        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
-        pages[dev] = ptr;
-    }
-    return (const bf16_t *)pages[dev];
-}
-
 // Scratch for the partial slabs: one buffer per (device, stream) -- launches on one stream run one after the other, so the next
 // launch's workgroups cannot overwrite slabs a reduction still reads.  Grown on demand, with two exceptions: never while the stream is
 // being captured (no allocation inside a capture: the launch then goes to the float-atomics kernels unless the stream's slab was
@@ -628,27 +412,22 @@ float *slab_for(hipStream_t st, size_t bytes, bool reserve_only = false) {
 }
 
 template <int TCO, int DT, int S, int K>
-int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
-    constexpr int RY = (S == 1 ? 3 : 2) + 1, XR = S == 1 ? 8 : 4;
-    constexpr int SMEM1 = RY * (SEG * TCO * 2) + S * XR * (SEG * 64 * 2), SMEM2 = 4 * (SEG * TCO * 2) + S * XR * (SEG * 64 * 2);
-    const char *env2 = getenv("RDFC_WGRAD_RING2");              // (read per call, like RDFC_WGRAD_RING: tools/wgrad_ring_bench.py switches it between launches)
-    const bool ring2 = (env2 == nullptr || atoi(env2) != 0) && p.x_bytes != 0 && p.y_bytes != 0;
-    const int SMEM = ring2 ? SMEM2 : SMEM1;
+int launch(RParams p, const void *x, const void *dy, float *dw, hipStream_t st) {
+    constexpr int XR = S == 1 ? 8 : 4;
+    constexpr int SMEM = 4 * (SEG * TCO * 2) + S * XR * (SEG * 64 * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wgrad_ring_kernel<TCO, DT, S, K>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM1) != hipSuccess) return 0;
-        if (hipFuncSetAttribute((const void *)wgrad_ring2_kernel<TCO, DT, S, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)wgrad_ring2_kernel<TCO, DT, S, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         if constexpr (S == 1 && K == 3)
-            if (hipFuncSetAttribute((const void *)wgrad_ring2_kernel<TCO, DT, S, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2) != hipSuccess) return 0;
+            if (hipFuncSetAttribute((const void *)wgrad_ring2_kernel<TCO, DT, S, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     p.tiles_ci = cdiv(p.Ci, 64);
     const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * K;
     // one round of the chip's workgroup slots (2 per CU with the 128-co tile, 3 with the 64-co one) within a slab budget: every
     // workgroup writes its tile once (plain stores) and the reduction reads it once
-    constexpr int slots_env = 0;
     constexpr double cap_mb = 64.0;
-    const int slots = slots_env ? slots_env : (TCO == 64 ? 768 : 512);
+    const int slots = TCO == 64 ? 768 : 512;
     int slices = slots / tiles;
     const size_t dw_bytes = (size_t)4 * p.Co * p.Ci * K * K;
     const int cap = (int)(cap_mb * 1.0e6 / (double)dw_bytes);
@@ -661,53 +440,50 @@ int launch(RParams p, const void *x, const void *dy, float *dw, const bf16_t *ze
     p.tiles = tiles;
     float *slab = slab_for(st, dw_bytes * slices);
     if (slab == nullptr) return 0;
-    constexpr bool xcd_group = true;
-    p.xcd_group = xcd_group && tiles <= 4 && slices >= 8;
+    p.xcd_group = tiles <= 4 && slices >= 8;
     const dim3 grid = p.xcd_group ? dim3(cdiv(slices, 8) * 8 * tiles, 1) : dim3(slices, tiles);
-    if (ring2) {
-        rdfc_note_kernel("wgrad_ring2_kernel<%d, %d, %d, %d, %s>", TCO, DT, S, K, p.reflect ? "true" : "false");
-        if constexpr (S == 1 && K == 3) {
-            if (p.reflect) hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, true>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
-            else hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, false>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
-        } else
-            hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, false>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
-    } else {
-        rdfc_note_kernel("wgrad_ring_kernel<%d, %d, %d, %d>", TCO, DT, S, K);
-        hipLaunchKernelGGL((wgrad_ring_kernel<TCO, DT, S, K>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab, zero);
-    }
+    rdfc_note_kernel("wgrad_ring2_kernel<%d, %d, %d, %d, %s>", TCO, DT, S, K, p.reflect ? "true" : "false");
+    if constexpr (S == 1 && K == 3) {
+        if (p.reflect) hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, true>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
+        else hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, false>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
+    } else
+        hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, false>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
     const size_t n4 = dw_bytes / 16;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float *)slab, dw, n4, slices);
     return 1;
 }
 
 template <int S, int K>
-int launch_sk(const rdfc_conv_desc *d, const RParams &p, const void *x, const void *dy, float *dw, const bf16_t *zero, hipStream_t st) {
+int launch_sk(const rdfc_conv_desc *d, const RParams &p, const void *x, const void *dy, float *dw, hipStream_t st) {
     // 128-co tiles from 256 output channels up (as conv_wgrad_glds.hip: below that the 64-co tile's larger grid wins)
     if (d->Co % 128 == 0 && d->Co >= 256)
-        return d->dtype == RDFC_F16 ? launch<128, RDFC_F16, S, K>(p, x, dy, dw, zero, st) : launch<128, RDFC_BF16, S, K>(p, x, dy, dw, zero, st);
-    return d->dtype == RDFC_F16 ? launch<64, RDFC_F16, S, K>(p, x, dy, dw, zero, st) : launch<64, RDFC_BF16, S, K>(p, x, dy, dw, zero, st);
+        return d->dtype == RDFC_F16 ? launch<128, RDFC_F16, S, K>(p, x, dy, dw, st) : launch<128, RDFC_BF16, S, K>(p, x, dy, dw, st);
+    return d->dtype == RDFC_F16 ? launch<64, RDFC_F16, S, K>(p, x, dy, dw, st) : launch<64, RDFC_BF16, S, K>(p, x, dy, dw, st);
 }
 
 }  // namespace
 
 // whether this kernel takes the launch (shape rules + the measured exceptions); L = padded row length of the flat pixel walk
+// 0: off; 1: 3x3 / stride 1 only; 2 (default): also stride 2 and 4x4; 3: 2 without the size exceptions (tests).  Read from RDFC_WGRAD_RING
+// ONCE (round 5 called getenv on every weight-gradient launch); tools/wgrad_ring_bench.py switches it between launches through
+// rdfc_tune_wgrad_ring (a measurement aid like rdfc_tune_glds_rows: process-wide, not thread-safe).
+static int g_ring_mode = getenv("RDFC_WGRAD_RING") != nullptr ? atoi(getenv("RDFC_WGRAD_RING")) : 2;
+extern "C" void rdfc_tune_wgrad_ring(int mode) { g_ring_mode = mode; }
 static bool ring_takes(const rdfc_conv_desc *d, int reflect, int &L) {
-    const char *env_ = getenv("RDFC_WGRAD_RING");               // (read per call: tools/wgrad_ring_bench.py switches it between launches)
-    const int mode = env_ != nullptr ? atoi(env_) : 2;          // 0: off; 1: 3x3 / stride 1 only; 2 (default): also stride 2 and 4x4; 3: 2 without the size exceptions (tests)
+    const int mode = g_ring_mode;
     if (mode == 0 || !rdfc_is16(d->dtype)) return false;
     const int S = d->sh, K = d->KH;
     if (!(d->KH == d->KW && (K == 3 || K == 4) && d->sh == d->sw && (S == 1 || S == 2) && d->dh == 1 && d->dw == 1 && d->ph == d->pw && d->ph <= 1)) return false;
     if ((S != 1 || K != 3) && (mode < 2 || d->ph != 1 || reflect)) return false;
     if (d->Ho != (d->Hi + 2 * d->ph - K) / S + 1 || d->Wo != (d->Wi + 2 * d->pw - K) / S + 1) return false;
     if (d->Ci % 64 || d->ldx % 8 || d->ldy % 8 || d->Wo < 24) return false;
-    if (d->Co % 64) {
-        // 32 output channels (the 128 -> 32 head convs at full resolution): the 64-co tile with its upper half beyond Cout -- zeros from the
-        // descriptor's range check, nothing stored -- on the round-5 kernel only (the round-3 kernel reads a zero page per piece instead)
-        const char *env2 = getenv("RDFC_WGRAD_RING2");
-        const bool ring2 = env2 == nullptr || atoi(env2) != 0;
+    {   // both maps are addressed through 32-bit byte offsets (buffer descriptors); larger ones go to the tap-gather / register-staged kernels
         const size_t xb = 2 * (size_t)d->N * d->Hi * d->Wi * d->ldx, yb = 2 * (size_t)d->N * d->Ho * d->Wo * d->ldy;
-        if (!(d->Co == 32 && S == 1 && K == 3 && ring2 && xb < 0x7ffffff0u && yb < 0x7ffffff0u && mode >= 2)) return false;
+        if (xb >= 0x7ffffff0u || yb >= 0x7ffffff0u) return false;
     }
+    // 32 output channels (the 128 -> 32 head convs at full resolution): the 64-co tile with its upper half beyond Cout -- zeros from the
+    // descriptor's range check, nothing stored
+    if (d->Co % 64 && !(d->Co == 32 && S == 1 && K == 3 && mode >= 2)) return false;
     if (reflect && (d->ph < 1 || d->ph >= d->Hi || d->pw >= d->Wi)) return false;
     const int omax = S == 1 ? K - 1 : K / 2;                   // largest tap shift within a plane's flat sequence
     L = (d->Wo + omax + 7) / 8 * 8;
@@ -743,15 +519,12 @@ int rdfc_try_wgrad_ring(const rdfc_conv_desc *d, const void *x, const void *dy, 
     int L = 0;
     if (!ring_takes(d, reflect, L)) return 0;
     const int S = d->sh, K = d->KH;
-    const bf16_t *zero = zero_page();
-    if (zero == nullptr) return 0;
     RParams p{d->N, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->Co, d->ph, d->ldx, d->ldy, L, d->N * d->Ho, 0, 0, 0, 0, 0, 0, reflect, S == 1 ? -d->ph : -2, 0, 0};
-    const size_t xb = 2 * (size_t)d->N * d->Hi * d->Wi * d->ldx, yb = 2 * (size_t)d->N * d->Ho * d->Wo * d->ldy;
-    p.x_bytes = xb < 0x7ffffff0u ? (unsigned)xb : 0;            // (0: a map too large for 32-bit offsets -> the round-3 kernel takes the launch)
-    p.y_bytes = yb < 0x7ffffff0u ? (unsigned)yb : 0;
+    p.x_bytes = (unsigned)(2 * (size_t)d->N * d->Hi * d->Wi * d->ldx);      // (< 2^31: ring_takes)
+    p.y_bytes = (unsigned)(2 * (size_t)d->N * d->Ho * d->Wo * d->ldy);
     p.total_steps = cdiv((long)p.nrows * p.L, SEG);
-    if (S == 1 && K == 3) return launch_sk<1, 3>(d, p, x, dy, dw, zero, st);
-    if (S == 2 && K == 3) return launch_sk<2, 3>(d, p, x, dy, dw, zero, st);
-    if (S == 2 && K == 4) return launch_sk<2, 4>(d, p, x, dy, dw, zero, st);
-    return launch_sk<1, 4>(d, p, x, dy, dw, zero, st);
+    if (S == 1 && K == 3) return launch_sk<1, 3>(d, p, x, dy, dw, st);
+    if (S == 2 && K == 3) return launch_sk<2, 3>(d, p, x, dy, dw, st);
+    if (S == 2 && K == 4) return launch_sk<2, 4>(d, p, x, dy, dw, st);
+    return launch_sk<1, 4>(d, p, x, dy, dw, st);
 }

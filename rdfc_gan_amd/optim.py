@@ -391,3 +391,21 @@ def broadcast_module_state(modules, src=0):
         for t in list(m.parameters()) + list(m.buffers()):
             dist.broadcast(t.data, src)
     Fh.invalidate_packed_weights()
+
+
+def resync_replicas(modules, optimizers, src=0):
+    """Make every rank a copy of rank `src` again: parameters and buffers (broadcast_module_state), Adam moments, step counts and the
+    device-side loss-scaler state of every optimizer.  For diagnostics that let replicas drift on purpose (bench.py's
+    collectives-off leg runs optimizer steps on local gradients); training never needs it."""
+    if not dp_active():
+        return
+    broadcast_module_state(modules, src)
+    seen = set()
+    for o in optimizers:
+        for t in (o.exp_avg, o.exp_avg_sq, o._ostate, o._hyper, getattr(o.scaler, 'state', None)):
+            if t is not None and id(t) not in seen:
+                seen.add(id(t))
+                dist.broadcast(t, src)
+        steps = torch.tensor([o.steps], dtype=torch.int64, device=o.flat.device)
+        dist.broadcast(steps, src)
+        o.steps = int(steps)

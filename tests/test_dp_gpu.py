@@ -11,11 +11,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """a rendezvous port nobody holds (fixed numbers collide with a second test session or a lingering torchrun on the same box)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return str(s.getsockname()[1])
+
+
 @pytest.mark.parametrize('full', [False, True], ids=['four_networks', 'full_objective'])
 def test_two_ranks_stay_identical(full):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_SMOKE_FULL='1' if full else '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29518' if full else '29517', os.path.join(ROOT, 'tools', 'dp_smoke.py')]
+           '--master-port', _free_port(), os.path.join(ROOT, 'tools', 'dp_smoke.py')]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
@@ -38,7 +46,7 @@ def test_in_backward_buckets_follow_both_branches_streams(wgrad_stream):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_SMOKE_FULL='0', DP_SMOKE_DELAY_MAIN='1',
                RDFC_WGRAD_STREAM=wgrad_stream)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29524' if wgrad_stream == '1' else '29525', os.path.join(ROOT, 'tools', 'dp_smoke.py')]
+           '--master-port', _free_port(), os.path.join(ROOT, 'tools', 'dp_smoke.py')]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
@@ -52,7 +60,7 @@ def test_two_ranks_stay_identical_under_graph_replay():
     and overflow check inside the captured Adam segment)."""
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_SMOKE_FULL='0', DP_SMOKE_GRAPH='1', DP_SMOKE_DTYPE='f16')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29523', os.path.join(ROOT, 'tools', 'dp_smoke.py')]
+           '--master-port', _free_port(), os.path.join(ROOT, 'tools', 'dp_smoke.py')]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
@@ -63,7 +71,7 @@ def test_rccl_one_rank_step_equals_plain_step():
     """every collective of the step through RCCL itself (one rank on the one GPU, RDFC_DP_FORCE): broadcast, the bucketed
     all-reduces on the communication stream, the packed loss all-reduces; results must match the step without a process group
     (tools/dp_smoke.py: first-step losses bit for bit, parameters after two steps within the run-to-run bound of the float atomics)"""
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29521', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
                HSA_ENABLE_IPC_MODE_LEGACY='0', DP_SMOKE_BACKEND='nccl', DP_SMOKE_FULL='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'dp_smoke.py')], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=600)
@@ -78,7 +86,7 @@ def test_bench_multi_rank_control_flow():
     import json
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', RDFC_BENCH_DEVICE='0', RDFC_BENCH_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29519', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2',
+           '--master-port', _free_port(), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2',
            '--height', '64', '--width', '80']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
@@ -99,7 +107,7 @@ def test_bench_multi_rank_control_flow():
 def test_bench_rccl_one_rank_comm_block():
     """the same block through RCCL itself (one rank, --rccl-self-test): RCCL's version and environment are on the line"""
     import json
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29526', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--rccl-self-test', '--steps', '3', '--warmup', '1', '--batch', '2', '--height', '64', '--width', '80',
            '--no-cpu-baseline', '--no-as-worded']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)

@@ -27,8 +27,6 @@ VARIANTS = [
     ('RDFC_GLDS_JR', '6', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
     ('RDFC_GLDS_JR', '8', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
     ('RDFC_GLDS_JR', '10', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
-    # round 3's ring weight-gradient kernel (round 5's wgrad_ring2 is the default; the two give the same bits: tools/wgrad_ring_bench.py)
-    ('RDFC_WGRAD_RING2', '0', '(test_conv_fwd_dgrad_wgrad and not f32) or reflection_pad_folded or adjoint', 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
 ]
 
 

@@ -1,8 +1,8 @@
-"""MODE=ring2: A/B of round 5's wgrad_ring2_kernel (RDFC_WGRAD_RING2=1) against round 3's wgrad_ring_kernel (=0), same shapes, same
-checks (the two must agree bit for bit: same walk, same order of the f32 adds).  Default:
-A/B of the ring weight-gradient kernel (conv_wgrad_ring.hip, RDFC_WGRAD_RING=1) against conv_wgrad_glds.hip (=0) on the step's
-3x3 / stride-1 layers: interleaved rounds in ONE process (the switch is read per launch), random operands; the ring kernel's result
-must repeat bit for bit (fixed-order slab reduction) and agree with the other kernel to f32 summation-order accuracy.
+"""A/B of the ring weight-gradient kernel (conv_wgrad_ring.hip: wgrad_ring2_kernel, mode 3 = every launch it can take) against the
+tap-gather / segment-walk kernels with float atomics (mode 0) on the step's layers: interleaved rounds in ONE process (the mode is
+switched between launches through rdfc_tune_wgrad_ring), random operands; the ring kernel's result must repeat bit for bit
+(fixed-order slab reduction) and agree with the other kernel to f32 summation-order accuracy.  (Round 5's MODE=ring2 leg -- round 3's
+wgrad_ring_kernel against wgrad_ring2_kernel, bit-equal on all shapes: profiles/r05_wgrad_ring2_ab.txt -- went with the old kernel.)
 python tools/wgrad_ring_bench.py [rounds] [iters]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,11 +22,8 @@ SHAPES = [  # N, H, W, Ci, Co, pad, reflect, kernel, stride
     (16, 28, 38, 256, 512, 1, 0, 4, 1), (3, 31, 61, 64, 128, 1, 0, 4, 2), (2, 33, 59, 128, 64, 1, 0, 3, 2)]
 if len(sys.argv) > 3:
     SHAPES = [sh for sh in SHAPES if (sh[7], sh[8]) == tuple(int(v) for v in sys.argv[3].split(','))]
-RING2 = os.environ.get('MODE') == 'ring2'
-VAR = 'RDFC_WGRAD_RING2' if RING2 else 'RDFC_WGRAD_RING'
-MODES = ('0', '1') if RING2 else ('0', '3')
-if RING2:
-    os.environ['RDFC_WGRAD_RING'] = '3'
+VAR = 'RDFC_WGRAD_RING'
+MODES = ('0', '3')
 dtn = os.environ.get('PP_DTYPE', 'bf16')
 dt = dict(bf16=torch.bfloat16, f16=torch.float16)[dtn]
 
@@ -50,7 +47,7 @@ for (N, H, W, Ci, Co, pad, reflect, ksz, st) in SHAPES:
     d = hip.conv_desc(x.shape, Co, ksz, st, pad, ldx=Ci, ldy=Co, dtype=hip.dt(x))
     outs, kern = {}, {}
     for m in MODES:
-        os.environ[VAR] = m
+        hip.lib().rdfc_tune_wgrad_ring(int(m))
         bad = 0
         for rep in range(4):
             dw = hip.conv_wgrad(d, x, gy, reflect=bool(reflect))
@@ -68,7 +65,7 @@ for (N, H, W, Ci, Co, pad, reflect, ksz, st) in SHAPES:
     res = {m: [] for m in MODES}
     for r in range(rounds):
         for m in MODES:
-            os.environ[VAR] = m
+            hip.lib().rdfc_tune_wgrad_ring(int(m))
             res[m].append(timed(lambda: hip.conv_wgrad(d, x, gy, into=buf, reflect=bool(reflect))))
     line = '  '
     for m in MODES:
