@@ -64,7 +64,11 @@ def check(net, res, g, out_atol, grad_in_l2, grad_l2, norm_median, norm_max, buf
     stock: {key: relative L2 error of a stock-PyTorch evaluation of the oracle net in the same storage precision}: the
     input gradients here may not be worse than 1.3x that (+ 0.02).
     grad_scalar: limit for sampled gradients that are ONE number (a PReLU slope: the sum of dz * u over every negative unit of a map, with
-    heavy cancellation -- in f32 mode it already sits 5.6e-3 from the oracle, i.e. ~1e5 roundings' worth); default: grad_l2."""
+    heavy cancellation -- in f32 mode it already sits 5.6e-3 from the oracle, i.e. ~1e5 roundings' worth); default: grad_l2.
+    norm_max=None / grad_scalar='seeds': the statistic is printed but not asserted on this one fixture -- in the 16-bit modes the MAXIMUM
+    over ~340 gradient norms and a single heavily cancelling scalar move several-fold with the summation order of one kernel (round 5) and,
+    in a stock PyTorch evaluation, with the weight seed (0.13 ... 0.32 and 0.07 ... 0.83: tests/golden/make_stock_lowp.py); they are
+    asserted over six weight seeds against that stock evaluation by test_noisy_lowp_statistics_over_weight_seeds."""
     report, bad = [], []
 
     def note(k, e, lim):
@@ -84,7 +88,10 @@ def check(net, res, g, out_atol, grad_in_l2, grad_l2, norm_median, norm_max, buf
                 note(k + '/stock', e / max(stock[k], 1e-9), 1.3 + 0.02 / max(stock[k], 1e-9))
         elif k.startswith('grad.'):
             got = dict(net.named_parameters())[k[5:]].grad.detach().cpu().numpy()
-            note(k, err(got, g[k])[1], grad_scalar if (grad_scalar is not None and g[k].size == 1) else grad_l2)
+            if g[k].size == 1 and grad_scalar == 'seeds':
+                report.append(f'{k}={err(got, g[k])[1]:.2e} (one number: asserted over weight seeds)')
+            else:
+                note(k, err(got, g[k])[1], grad_scalar if (grad_scalar is not None and g[k].size == 1) else grad_l2)
     names, summ = grad_summary(net)
     ref = dict(zip(g['grad_names'], g['grad_summary'][:, 1]))
     assert sorted(names) == sorted(ref)
@@ -99,7 +106,10 @@ def check(net, res, g, out_atol, grad_in_l2, grad_l2, norm_median, norm_max, buf
     rel = np.array(list(rels.values()))
     worst = sorted(rels.items(), key=lambda kv: -kv[1])[:6]
     note('param_grad_norm.median', float(np.median(rel)), norm_median)
-    note('param_grad_norm.max', float(rel.max()), norm_max)
+    if norm_max is None:
+        report.append(f'param_grad_norm.max={float(rel.max()):.2e} (asserted over weight seeds)')
+    else:
+        note('param_grad_norm.max', float(rel.max()), norm_max)
     report.append('worst=' + ', '.join(f'{k}:{v:.1e}' for k, v in worst))
     sd = net.state_dict()
     if len(g['buf_names']):
@@ -119,12 +129,11 @@ def check(net, res, g, out_atol, grad_in_l2, grad_l2, norm_median, norm_max, buf
 TOLS = {
     'g_a2b': {torch.float32: dict(out_atol=5e-5, grad_in_l2=8e-3, grad_l2=8e-3, norm_median=2e-4, norm_max=4e-3, buf_rtol=1e-5),
               # f32 measured: out 1.0e-5, grad_in 4.3e-3 (full size) / 1.4e-3, sampled grads 4.7e-3, median 8.1e-5, max 1.9e-3, buffers 1.8e-7
-              torch.bfloat16: dict(out_atol=0.15, grad_in_l2=0.6, grad_l2=1.0, norm_median=2e-2, norm_max=0.25, buf_rtol=2e-3),
+              torch.bfloat16: dict(out_atol=0.15, grad_in_l2=0.6, grad_l2=1.0, norm_median=2e-2, norm_max=None, buf_rtol=2e-3),
               # bf16 measured: out 7.6e-2, grad_in 0.32, sampled grads 0.54 (a 40-sample BatchNorm weight), median 8.8e-3, max 0.106, buffers 8.2e-4
-              # (round 5: the 3x3 kernel sums its taps kernel column by kernel column -- another f32 order, so another draw of which
-              #  bf16 results round the other way: outputs and input gradient unchanged (4.5e-2 / 0.318, 0.91x stock), the WORST of the
-              #  340 parameter-gradient norms 0.207; norm_max is the maximum of a noisy statistic, its limit went from 0.2 to 0.25)
-              torch.float16: dict(out_atol=2e-2, grad_in_l2=0.24, grad_l2=0.6, norm_median=5.5e-3, norm_max=0.14, buf_rtol=3e-4)},
+              # (the WORST of the 340 parameter-gradient norms read 0.106 in round 4 and 0.207 in round 5, when the 3x3 kernel's tap order
+              #  changed; round 5 widened its limit 0.2 -> 0.25.  Round 6: no single-fixture limit any more -- norm_max=None, see check())
+              torch.float16: dict(out_atol=2e-2, grad_in_l2=0.24, grad_l2=0.6, norm_median=5.5e-3, norm_max=None, buf_rtol=3e-4)},
               # f16 measured: out 9.5e-3, grad_in 0.116 (0.91x a stock f16 evaluation), sampled grads 0.29, median 2.3e-3, max 6.8e-2, buffers 1.1e-4
     'g_a2b_nlspn': {torch.float32: dict(out_atol=1e-4, grad_in_l2=2e-3, grad_l2=2e-3, norm_median=2e-4, norm_max=1e-3, buf_rtol=1e-5),
                     # f32 measured with the fused NLSPN kernels: out 4.7e-5 (18 propagation steps), grad_in 6.7e-4, grads 9.5e-4, max 3.0e-4
@@ -138,13 +147,12 @@ TOLS = {
                     # f16 measured: out 3.2e-2 (rms 1.7e-3), grad_in 9.5e-2, sampled grads 0.33, median 2.7e-3, max 3.7e-2, buffers 1.1e-4
     'g_b2a': {torch.float32: dict(out_atol=3e-5, grad_in_l2=7e-3, grad_l2=7e-3, norm_median=4e-5, norm_max=1.1e-2, buf_rtol=1e-5),
               # f32 measured: out 1.25e-5, grad_in 3.5e-3, grads 3.1e-3, median 1.8e-5, max 5.3e-3 (a weight in front of an InstanceNorm)
-              torch.bfloat16: dict(out_atol=0.12, grad_in_l2=0.45, grad_l2=5e-2, grad_scalar=0.3, norm_median=3e-3, norm_max=0.3, buf_rtol=2e-3),
+              torch.bfloat16: dict(out_atol=0.12, grad_in_l2=0.45, grad_l2=5e-2, grad_scalar='seeds', norm_median=3e-3, norm_max=None, buf_rtol=2e-3),
               # bf16 measured: out 5.6e-2, grad_in 0.22, grads 2.1e-2, median 1.1e-3, max 0.148
-              # (round 5: the sampled PReLU slope model.6.weight -- one number -- moved from 2.1e-2 to 0.118 when the 3x3 kernel's summation order
-              #  changed, on three trees of the round alike, while every tensor-valued statistic stayed put (grad_in 0.22, model.23.weight 2.9e-3);
-              #  f16, with 8x finer storage, reads 0.08-0.11 on it.  A scalar with ~1e5-fold cancellation is not held to the tensors' limit:
-              #  grad_scalar = the norm_max limit, which covers the same three slopes.)
-              torch.float16: dict(out_atol=2e-2, grad_in_l2=0.16, grad_l2=0.22, norm_median=1.2e-3, norm_max=0.22, buf_rtol=1e-3)},
+              # (the sampled PReLU slope model.6.weight -- one number with ~1e5-fold cancellation -- moved from 2.1e-2 to 0.118 when the 3x3
+              #  kernel's summation order changed in round 5, every tensor-valued statistic stayed put; round 5 gave it a limit of its own, 0.3.
+              #  Round 6: the three slopes and the maximum over the gradient norms are asserted over six weight seeds instead, see check())
+              torch.float16: dict(out_atol=2e-2, grad_in_l2=0.16, grad_l2=0.22, grad_scalar='seeds', norm_median=1.2e-3, norm_max=None, buf_rtol=1e-3)},
               # f16 measured: out 9.4e-3, grad_in 8.0e-2 (0.92x stock f16), grads 0.109, median 5.8e-4, max 0.109
     'patchgan': {torch.float32: dict(out_atol=1.5e-5, grad_in_l2=5e-6, grad_l2=5e-6, norm_median=1e-7, norm_max=1e-6, buf_rtol=1e-6),
                  # f32 measured: out 5.8e-6, grad_in 1.8e-6, grads 2.3e-6, median 4.4e-8, max 3.5e-7, buffers 9.4e-8
@@ -163,6 +171,13 @@ TOLS = {
                    # bf16 measured: out 5.0e-2, grad_in 0.193, grads 0.204, median 2.4e-3, max 1.9e-2, buffers 1.8e-4
 }
 _STOCK = {}
+_SEEDS = []
+
+
+def _stock_seeds():
+    if not _SEEDS:
+        _SEEDS.append(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stock_lowp_seeds.npz')))
+    return _SEEDS[0]
 
 
 def _stock_lowp(kind, dtype):
@@ -170,6 +185,13 @@ def _stock_lowp(kind, dtype):
     weights and activations in `dtype`, on the fixture inputs: what the storage precision alone costs"""
     key = (kind, dtype)
     if key in _STOCK:
+        return _STOCK[key]
+    if kind in ('g_a2b', 'g_b2a'):
+        # the two generators: computed once on the host by tests/golden/make_stock_lowp.py (the same evaluation as below, weight seed 0) and
+        # committed -- ~40 s of bf16 / f16 host convolutions per GPU test run until round 5
+        gin = _stock_seeds()[f"gin.{'bf16' if dtype == torch.bfloat16 else 'f16'}.{kind}.0"]
+        idx = (1, 2) if kind == 'g_a2b' else (0,)            # (RDFGenerator never reads its rgb argument: inputs 1 and 2 carry gradients)
+        _STOCK[key] = {f'grad_in.{i}': float(v) for i, v in zip(idx, gin)}
         return _STOCK[key]
     from oracle import nets as onets
     mk, inputs, tag = {
@@ -226,6 +248,57 @@ def test_g_b2a(golden, dtype):
     x = gen_inputs('g_b2a', 2, 60, 76)[1].to(DEV)
     stock = _stock_lowp('g_b2a', dtype) if dtype != torch.float32 else None
     print(check(net, run(net, (x,), 'g_b2a_small'), golden('g_b2a_small'), stock=stock, **TOLS['g_b2a'][dtype]))
+
+
+@pytest.mark.parametrize('dtype', DT[1:], ids=IDS[1:])
+@pytest.mark.parametrize('kind', ['g_a2b', 'g_b2a'])
+def test_noisy_lowp_statistics_over_weight_seeds(kind, dtype):
+    """round-5 verdict, weak item 2: the two statistics whose single-fixture limits were widened in round 5 -- the MAXIMUM relative error over
+    the ~340 parameter-gradient norms, and the gradients of the PReLU slopes (one number each, heavy cancellation) -- as a statistic over SIX
+    weight seeds with a limit tied to what 16-bit storage alone costs: a stock PyTorch evaluation of the oracle net with weights and
+    activations in the same type (tests/golden/stock_lowp_seeds.npz, made on the host by tests/golden/make_stock_lowp.py; the reference of
+    both sides is the oracle in fp32).  Over the seeds the stock evaluation's own maximum wanders 0.13 ... 0.32 (g_a2b, bf16) and
+    0.07 ... 0.83 (g_b2a, bf16): no single draw bounds anything, the MEDIAN over the seeds does.
+    Asserted: median over seeds of {max, median over the norms, worst PReLU slope} <= 1.5 x the stock evaluation's + a small floor."""
+    from rdfc_gan_amd.generator import RDFGenerator, ResnetGenerator
+    S = _stock_seeds()
+    dn = 'bf16' if dtype == torch.bfloat16 else 'f16'
+    names = [str(n) for n in S[f'names.{kind}']]
+    nseed = len([k for k in S.files if k.startswith(f'ref.{kind}.')])
+    assert nseed >= 5
+    setup_dtype(dtype)
+    mk = (lambda: RDFGenerator(pretrained_on_imagenet=False)) if kind == 'g_a2b' else (lambda: ResnetGenerator(1, 3, 64, 'IN2d'))
+    tag = f'{kind}_small'
+    ins = gen_inputs(kind, 2, 60, 76)
+    ins = tuple(t.to(DEV) for t in (ins if kind == 'g_a2b' else (ins[1],)))
+    rows = {'hip': [], 'stock': []}
+    for seed in range(nseed):
+        net = mk()
+        net.load_state_dict(det_state_dict(net.state_dict(), seed))
+        net.to(DEV).train()
+        xs = [t.clone().requires_grad_(True) for t in ins]
+        o = net(*xs)
+        o = o if isinstance(o, dict) else {'out': o}
+        loss = 0
+        for k, v in o.items():
+            loss = loss + (v * out_weights(tag, k, v.shape).to(DEV)).sum()
+        loss.backward()
+        got = {k: float(p.grad.double().norm()) for k, p in net.named_parameters() if p.grad is not None}
+        assert sorted(got) == names
+        ref = S[f'ref.{kind}.{seed}']
+        live = ref >= 1e-6 * ref.max()                     # (analytically-zero gradients: conv biases in front of an InstanceNorm)
+        slopes = np.array([n.endswith('.weight') and dict(net.named_parameters())[n].numel() == 1 for n in names])
+        for who, vec in (('hip', np.array([got[n] for n in names])), ('stock', S[f'{dn}.{kind}.{seed}'])):
+            rel = np.abs(vec - ref) / np.maximum(ref, 1e-30)
+            rows[who].append((float(rel[live].max()), float(np.median(rel[live])), float(rel[slopes & live].max()) if (slopes & live).any() else 0.0))
+        del net
+    hip_, stock = np.array(rows['hip']), np.array(rows['stock'])
+    print(f'\n[seeds] {kind} {dn}: per seed (max | median | worst PReLU slope)\n  hip   ' + ' '.join(f'{a:.3f}|{b:.1e}|{c:.3f}' for a, b, c in hip_)
+          + '\n  stock ' + ' '.join(f'{a:.3f}|{b:.1e}|{c:.3f}' for a, b, c in stock))
+    mh, ms = np.median(hip_, axis=0), np.median(stock, axis=0)
+    print(f'  medians over {nseed} seeds: hip {mh}, stock {ms}, ratio {mh / np.maximum(ms, 1e-12)}')
+    for j, what in enumerate(('max over the gradient norms', 'median over the gradient norms', 'worst PReLU-slope gradient')):
+        assert mh[j] <= 1.5 * ms[j] + (2e-2, 1e-3, 2e-2)[j], f'{kind} {dn}: {what}: median over seeds {mh[j]:.3e} against stock {ms[j]:.3e}'
 
 
 @pytest.mark.parametrize('dtype', DT, ids=IDS)
@@ -519,6 +592,9 @@ def test_graph_capture_after_eager_steps():
         m.enable_graph(False)
 
 
+_EVAL_REF = {}
+
+
 @pytest.mark.parametrize('dtype', DT, ids=IDS)
 def test_eval_path_end_to_end_metrics_within_north_star_tolerance(dtype):
     """forward_test -> RDFGANMetric.evaluate_normalised (228x304) against the CPU oracle's generator + oracle.metrics on the same
@@ -539,9 +615,6 @@ def test_eval_path_end_to_end_metrics_within_north_star_tolerance(dtype):
     from rdfc_gan_amd import functional as Fh
     Fh.invalidate_packed_weights()
     m.eval()
-    ref_net = on.RDFGenerator()
-    ref_net.load_state_dict(det_state_dict(ref_net.state_dict(), 0))
-    ref_net.eval()
     lim = {torch.float32: 1e-4, torch.float16: 1e-3, torch.bfloat16: 3e-3}[dtype]
     worst = 0.0
     for tag in ('eval_e2e', 'eval_e2e_b', 'eval_e2e_c'):
@@ -550,9 +623,15 @@ def test_eval_path_end_to_end_metrics_within_north_star_tolerance(dtype):
         gt[raw <= -1.0] = -1.0
         out = m.forward_test(rgb=rgb, raw_depth=raw, gt_normal=normal)
         got = RDFGANMetric().evaluate_normalised(gt.to(DEV), out['pred_depth'], None).double().cpu().numpy()
-        with torch.no_grad():
-            pred_ref = ref_net(rgb, raw, normal)['pred_depth']
-        ref = np.stack([om.image_metrics(om.denormalise(gt[k].numpy()), om.denormalise(pred_ref[k].numpy()), acc=np.float64) for k in range(2)])
+        if tag not in _EVAL_REF:              # the oracle's side (one fp32 host forward per seed) is the same for the three dtype cases: once per session
+            if 'net' not in _EVAL_REF:
+                _EVAL_REF['net'] = on.RDFGenerator()
+                _EVAL_REF['net'].load_state_dict(det_state_dict(_EVAL_REF['net'].state_dict(), 0))
+                _EVAL_REF['net'].eval()
+            with torch.no_grad():
+                pred_ref = _EVAL_REF['net'](rgb, raw, normal)['pred_depth']
+            _EVAL_REF[tag] = np.stack([om.image_metrics(om.denormalise(gt[k].numpy()), om.denormalise(pred_ref[k].numpy()), acc=np.float64) for k in range(2)])
+        ref = _EVAL_REF[tag]
         worst = max(worst, float(np.abs(got[:, 0] - ref[:, 0]).max()))
         assert np.abs(got[:, 0] - ref[:, 0]).max() < lim, (tag, got[:, 0], ref[:, 0])        # RMSE, metres
         assert np.abs(got[:, 1] - ref[:, 1]).max() < lim, tag                                # MAE
@@ -565,24 +644,21 @@ _FULL = {}
 
 
 def _oracle_full_step():
-    """one oracle step (upstream's literal schedule, fp32, CPU) at B = 2, 228x304 -- computed once per session (~1 min)"""
+    """one oracle step (upstream's literal schedule, fp32, CPU) at B = 2, 228x304: read from tests/golden/oracle_steps.npz (made by
+    tests/golden/make_oracle_steps.py on the host: the same call as below, ~1 min per GPU test run until round 5);
+    RDFC_LIVE_ORACLE=1 recomputes it here"""
     if 'ref' in _FULL:
         return _FULL['ref']
-    from oracle import nets as onets
-    from oracle.step import HotPathStep
-    hp = STEP_HP
-    nets = dict(G_A2B=onets.RDFGenerator(), G_B2A=onets.ResnetGenerator(1, 3, 64, 'IN2d'), disc_A=onets.PatchGANDiscriminator(1),
-                disc_B=onets.PatchGANDiscriminator(3))
-    for net in nets.values():
-        net.load_state_dict(det_state_dict(net.state_dict(), 0))
-        net.train()
-    st = HotPathStep(nets['G_A2B'], nets['G_B2A'], nets['disc_A'], nets['disc_B'], lr=hp['lr'], betas=(0.5, 0.999))
     data, nA, nfA = step_batch(0, 2, 228, 304)
-    st.set_input(data)
     normals = dict(real_A=nA, fake_A=nfA, fake_A_again=nfA)
-    losses = st.step(lambda tag: normals[tag], pepper_fn=None)
-    norms = {k: {n: float(v.double().norm()) for n, v in net.state_dict().items() if v.dtype.is_floating_point} for k, net in nets.items()}
-    _FULL['ref'] = (data, normals, losses, st.fake_B.clone(), st.fake_A.clone(), norms)
+    if os.environ.get('RDFC_LIVE_ORACLE') == '1':
+        from make_oracle_steps import oracle_step
+        losses, fB, fA, norms = oracle_step('full2')
+    else:
+        from make_oracle_steps import load
+        losses, fB, fA, norms, sub, _sums = load('full2')
+        assert sub == (1, 1)
+    _FULL['ref'] = (data, normals, losses, fB, fA, norms)
     return _FULL['ref']
 
 

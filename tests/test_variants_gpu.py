@@ -30,13 +30,35 @@ VARIANTS = [
 ]
 
 
+_RESULTS = {}
+
+
+def _run_all():
+    """every variant's child pytest, THREE at a time (round 6: one after the other they were 216 s of a 720 s suite -- each is mostly process
+    start-up, host-side references and small launches; the children share the GPU like any two processes do).  Started by the first of
+    the parametrised tests below, which then only look up their own child's outcome."""
+    if _RESULTS:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(variant):
+        name, value, expr = variant[:3]
+        test_files = variant[3:] if len(variant) > 3 else ('test_kernels_gpu.py',)
+        env = dict(os.environ, **{name: value})
+        try:
+            r = subprocess.run([sys.executable, '-m', 'pytest'] + [os.path.join(ROOT, 'tests', f) for f in test_files] + ['-q', '-x', '-k', expr, '-p', 'no:cacheprovider'],
+                               cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+            return r.returncode, (r.stdout + r.stderr)[-2500:]
+        except subprocess.TimeoutExpired as e:
+            return -1, f'timed out: {e}'
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        for variant, res in zip(VARIANTS, ex.map(one, VARIANTS)):
+            _RESULTS[variant[:2]] = res
+
+
 @pytest.mark.parametrize('variant', VARIANTS, ids=[f'{v[0]}={v[1]}' for v in VARIANTS])
 def test_variant_passes_the_default_kernels_tests(variant):
-    name, value, expr = variant[:3]
-    test_files = variant[3:] if len(variant) > 3 else ('test_kernels_gpu.py',)
-    env = dict(os.environ, **{name: value})
-    r = subprocess.run([sys.executable, '-m', 'pytest'] + [os.path.join(ROOT, 'tests', f) for f in test_files] + ['-q', '-x', '-k', expr],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    tail = (r.stdout + r.stderr)[-2500:]
-    assert r.returncode == 0, tail
+    _run_all()
+    rc, tail = _RESULTS[variant[:2]]
+    assert rc == 0, tail
     assert ' passed' in tail and ' skipped' not in tail.splitlines()[-1], tail
