@@ -51,10 +51,6 @@ void rdfc_tune_glds_rows(int rows_per_wave);
  * counterpart. */
 void rdfc_tune_wgrad_ring(int mode);
 int rdfc_version(void);
-/* A HIP stream (hipStreamNonBlocking) with a scheduling priority: level < 0 the greatest the device offers, 0 normal, > 0 the least.
- * Stands in for torch.cuda.Stream(priority=...), which on ROCm knows "normal" and "high" only; the train step puts its weight
- * gradients on a LOW stream (rdfc_gan_amd/functional.py).  The stream lives until the process ends. */
-int rdfc_stream_create(int level, void **stream);
 /* sha256 (first 16 hex digits) of the kernel sources this library was built from (rdfc_gan_amd/build.py: source_hash()): measurement
  * artefacts under profiles/ carry it, and bench.py refuses counters taken from another build.  No upstream counterpart. */
 const char *rdfc_build_hash(void);

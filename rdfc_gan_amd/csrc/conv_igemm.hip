@@ -372,6 +372,8 @@ int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const voi
                              const void *addend = nullptr, int ld_add = 0, const void *addend2 = nullptr, int ld_add2 = 0);     // conv_t3x3s2_glds.hip
 int rdfc_try_conv_thin_in(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
                           hipStream_t st);               // conv_thin_in.hip
+int rdfc_try_conv_narrow(const rdfc_conv_desc *d, int transposed, const void *in, const void *w, const float *bias, void *out,
+                         hipStream_t st);                // conv_narrow.hip
 static bool patch_enabled() {
     constexpr bool on = true;
     return on;
@@ -388,6 +390,7 @@ extern "C" int rdfc_conv2d_forward(const rdfc_conv_desc *d, const void *x, const
     hipStream_t st = (hipStream_t)stream;
     if (rdfc_try_conv_thin(d, 0, x, w_fwd, bias, y, st)) {
     } else if (rdfc_try_conv_thin_in(d, 0, x, w_fwd, bias, y, st)) {
+    } else if (rdfc_try_conv_narrow(d, 0, x, w_fwd, bias, y, st)) {
     } else if (rdfc_try_conv3x3_glds(d, 0, x, w_fwd, bias, y, st)) {
     } else if (rdfc_try_igemm_glds(d, 0, x, w_fwd, bias, y, st)) {
     } else if (patch_enabled() && rdfc_try_conv3x3_patch(d, 0, x, w_fwd, bias, y, st)) {
@@ -449,6 +452,7 @@ extern "C" int rdfc_conv2d_dgrad(const rdfc_conv_desc *d, const void *dy, const 
     if (rdfc_try_head_dgrad(d, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_conv_thin(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_conv_thin_in(d, 1, dy, w_bwd, bias, dx, st)) {
+    } else if (rdfc_try_conv_narrow(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_conv3x3_glds(d, 1, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_convt3x3s2_glds(d, dy, w_bwd, bias, dx, st)) {
     } else if (rdfc_try_igemm_glds(d, 1, dy, w_bwd, bias, dx, st)) {

@@ -255,6 +255,7 @@ int rdfc_try_wgrad9(const rdfc_conv_desc *d, const void *x, const void *dy, floa
 int rdfc_try_wgrad_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st, int reflect = 0);   // conv_wgrad_glds.hip
 int rdfc_try_wgrad_gather_glds(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad_gather_glds.hip
 int rdfc_try_wgrad_thin(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st);   // conv_wgrad_thin.hip
+int rdfc_try_wgrad_narrow(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw, hipStream_t st); // conv_narrow.hip
 
 extern "C" int rdfc_conv2d_reflect_supported(const rdfc_conv_desc *d);
 // weight gradient of a conv whose input is reflection-padded by ph = pw (x is the UNPADDED map): see rdfc_conv2d_forward_reflect
@@ -282,6 +283,7 @@ extern "C" int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const v
     hipStream_t st = (hipStream_t)stream;
     constexpr bool w9 = true;
     if (rdfc_try_wgrad_thin(d, x, dy, dw_packed, st)) {
+    } else if (rdfc_try_wgrad_narrow(d, x, dy, dw_packed, st)) {
     } else if (rdfc_try_wgrad_glds(d, x, dy, dw_packed, st)) {
     } else if (rdfc_try_wgrad_gather_glds(d, x, dy, dw_packed, st)) {
     } else if (w9 && rdfc_try_wgrad9(d, x, dy, dw_packed, st)) {

@@ -499,9 +499,10 @@ static bool ring_takes(const rdfc_conv_desc *d, int reflect, int &L) {
 
 // include/rdfc_hip.h: 1 when rdfc_conv2d_wgrad[_reflect] of this layer adds its split-K partials in a fixed order (bitwise
 // reproducible results), 0 when the launch goes to a kernel that accumulates with float atomics
+int rdfc_wgrad_narrow_covers(const rdfc_conv_desc *d);            // conv_narrow.hip (per-workgroup partials added in workgroup order)
 extern "C" int rdfc_conv2d_wgrad_deterministic(const rdfc_conv_desc *d, int reflect) {
     int L = 0;
-    return d != nullptr && ring_takes(d, reflect, L) ? 1 : 0;
+    return d != nullptr && ((!reflect && rdfc_wgrad_narrow_covers(d)) || ring_takes(d, reflect, L)) ? 1 : 0;
 }
 
 // include/rdfc_hip.h: make sure `stream` owns a slab of at least `bytes` (0: the default 64 MB, enough for every layer of the hot path)

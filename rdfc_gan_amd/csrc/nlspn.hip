@@ -195,10 +195,15 @@ __global__ __launch_bounds__(NT) void prop_bwd_feat_kernel(Geo g, const float *_
                 // four unconditional LDS adds: a corner outside the image lands in a window cell that is never flushed
                 long long *ga = gacc + r0 * WW + c0;
                 const float s_ = v * up;
-                atomicAdd(reinterpret_cast<unsigned long long *>(ga), (unsigned long long)(long long)(hh * hw * s_));
-                atomicAdd(reinterpret_cast<unsigned long long *>(ga + 1), (unsigned long long)(long long)(hh * c.lw * s_));
-                atomicAdd(reinterpret_cast<unsigned long long *>(ga + WW), (unsigned long long)(long long)(c.lh * hw * s_));
-                atomicAdd(reinterpret_cast<unsigned long long *>(ga + WW + 1), (unsigned long long)(long long)(c.lh * c.lw * s_));
+#ifdef RDFC_EXP_NOSCATTER                                             // (timing builds only: tools/build_variant.sh)
+                if (s_ == 12345.678f)
+#endif
+                {
+                    atomicAdd(reinterpret_cast<unsigned long long *>(ga), (unsigned long long)(long long)(hh * hw * s_));
+                    atomicAdd(reinterpret_cast<unsigned long long *>(ga + 1), (unsigned long long)(long long)(hh * c.lw * s_));
+                    atomicAdd(reinterpret_cast<unsigned long long *>(ga + WW), (unsigned long long)(long long)(c.lh * hw * s_));
+                    atomicAdd(reinterpret_cast<unsigned long long *>(ga + WW + 1), (unsigned long long)(long long)(c.lh * c.lw * s_));
+                }
             } else {
                 if (c.v00) atomicAdd(gi + (size_t)c.h0 * W + c.w0, hh * hw * v);
                 if (c.v01) atomicAdd(gi + (size_t)c.h0 * W + c.w0 + 1, hh * c.lw * v);
@@ -208,6 +213,9 @@ __global__ __launch_bounds__(NT) void prop_bwd_feat_kernel(Geo g, const float *_
         }
     }
     __syncthreads();
+#ifdef RDFC_EXP_NOFLUSH
+    if (down == 12345.678) 
+#endif
     for (int e = threadIdx.x; e < WN; e += NT) {
         const long long a = gacc[e];
         if (a != 0) {

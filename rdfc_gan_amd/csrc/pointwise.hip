@@ -24,25 +24,6 @@ void rdfc_note_kernel(const char *fmt, ...) {
 extern "C" const char *rdfc_last_kernel(void) { return g_kernel; }
 extern "C" int rdfc_version(void) { return 100; }
 
-// A HIP stream with a scheduling priority: level -1 = the greatest priority the device offers, 0 = normal, +1 = the least.  PyTorch-ROCm
-// only hands out normal and high streams (c10: two priority pools); the weight-gradient stream of the train step wants to be BELOW the
-// streams that carry the step's dependency chain (rdfc_gan_amd/functional.py wraps the handle in torch.cuda.ExternalStream).
-extern "C" int rdfc_stream_create(int level, void **stream) {
-    RDFC_REQUIRE(stream != nullptr, "rdfc_stream_create: null pointer");
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
-        rdfc_set_error("rdfc_stream_create: hipDeviceGetStreamPriorityRange failed");
-        return 2;
-    }
-    const int prio = level < 0 ? greatest : (level > 0 ? least : (least + greatest) / 2);
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) {
-        rdfc_set_error("rdfc_stream_create: hipStreamCreateWithPriority(%d) failed", prio);
-        return 2;
-    }
-    *stream = (void *)st;
-    return 0;
-}
 
 namespace {
 

@@ -142,30 +142,10 @@ if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 _side = {}          # device -> [stream, list of tensors the pending launches still read]
 
-# Scheduling priority per helper stream, RDFC_STREAM_PRIO="wgrad:1,branch:0,net:0" (-1 high, 0 normal, 1 low; round 6).  The
-# weight-gradient stream has no consumer before the optimizer step: on a LOW stream its split-K GEMMs take the workgroup slots the
-# streams of the step's dependency chain leave free instead of competing with them on equal terms.
-_PRIO = {}
-for _kv in os.environ.get('RDFC_STREAM_PRIO', '').split(','):
-    if ':' in _kv:
-        _PRIO[_kv.split(':')[0].strip()] = int(_kv.split(':')[1])
-
-
-def _new_stream(device, role):
-    level = _PRIO.get(role, 0)
-    if level == 0:
-        return torch.cuda.Stream(device=device)
-    import ctypes
-    h = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        hip._chk(hip.lib().rdfc_stream_create(level, ctypes.byref(h)), 'rdfc_stream_create')
-    return torch.cuda.ExternalStream(h.value, device=device)
-
-
 def _side_stream(device):
     s = _side.get(device)
     if s is None:
-        s = _side[device] = [_new_stream(device, 'wgrad'), []]
+        s = _side[device] = [torch.cuda.Stream(device=device), []]
     return s
 
 
@@ -176,7 +156,7 @@ def branch_stream(device):
     """second compute stream for an independent branch of a network (RDFGenerator's depth branch)"""
     s = _branch.get(device)
     if s is None:
-        s = _branch[device] = _new_stream(device, 'branch')
+        s = _branch[device] = torch.cuda.Stream(device=device)
     return s
 
 
@@ -187,7 +167,7 @@ def net_stream(device):
     """third compute stream: the half of the train step that does not depend on the other (RDFCGAN: the B->A chain)"""
     s = _net.get(device)
     if s is None:
-        s = _net[device] = _new_stream(device, 'net')
+        s = _net[device] = torch.cuda.Stream(device=device)
     return s
 
 

@@ -106,6 +106,11 @@ CONV_CASES = [
     (4, 130, 141, 3, 64, 3, 1, 1),
     # round 5: the 128 -> 32 head convs' weight gradient on the ring kernel's 64-channel tile (upper half beyond Cout: range-checked zeros)
     (4, 48, 64, 128, 32, 3, 1, 1),
+    # round 6: the narrow-map kernels (conv_narrow.hip): NLSPN's conv_offset_aff (8 -> 24: forward, input gradient 24 -> 8, weight gradient)
+    # and the input gradient of gd_dec0 (128 -> 8, gathered map of 8 channels -> 128); odd sizes, partial tiles
+    (4, 66, 130, 8, 24, 3, 1, 1),
+    (2, 35, 71, 128, 8, 3, 1, 1),
+    (2, 21, 50, 24, 16, 3, 1, 1),
 ]
 
 
@@ -151,6 +156,66 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     dw = h.conv_wgrad(dwd, x_pm, gy_pm)
     gw = h.unpack_wgrad(dw, Co, Ci, k, k)
     assert rel_err(gw, wr.grad) < tol(dtype), 'wgrad'
+
+
+NARROW_CASES = [
+    # N, H, W, Ci, Co: what each direction must run on (conv_narrow.hip); None = another kernel's shape
+    (4, 66, 130, 8, 24, 'narrow3x3_kernel<8, 2', 'narrow3x3_kernel<24, 1', 'false>'),       # conv_offset_aff (nlspn_model.py:29-33)
+    (4, 66, 130, 128, 8, None, 'narrow3x3_kernel<8, 8', 'true>'),                            # gd_dec0 (rdf_generator.py:95-102): input and weight gradient
+    (3, 41, 97, 128, 8, None, 'narrow3x3_kernel<8, 8', None),
+    (2, 33, 70, 8, 8, 'narrow3x3_kernel<8, 1', 'narrow3x3_kernel<8, 1', None),
+    (8, 70, 64, 8, 32, 'narrow3x3_kernel<8, 2', None, 'false>'),
+    (9, 59, 64, 32, 8, None, 'narrow3x3_kernel<8, 2', 'true>'),
+    (2, 33, 70, 8, 64, 'narrow3x3_kernel<8, 4', None, None),
+    (2, 33, 70, 24, 32, 'narrow3x3_kernel<24, 2', None, None),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES[1:], ids=DT_IDS[1:])
+@pytest.mark.parametrize('case', NARROW_CASES, ids=lambda c: 'x'.join(map(str, c[:5])))
+def test_narrow_map_convs(case, dtype):
+    """conv_narrow.hip (round 6): 3x3 / stride-1 / pad-1 layers around 8- and 24-channel maps -- forward with bias into a 2-byte and into an
+    f32 result (a channel slice of a wider map as input), input gradient, weight gradient (accumulating into a non-zero buffer, and bit
+    for bit the same on a second run: its partial sums are added in a fixed order) -- against F.conv2d in fp32 on identically rounded
+    operands, and each direction on the kernel it was written for (rdfc_last_kernel)."""
+    h = hip()
+    N, H, W, Ci, Co, k_fwd, k_dgrad, k_wgrad = case
+    last = lambda: h.lib().rdfc_last_kernel().decode()
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=(Ci * 9) ** -0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    xr = x.to(dtype).float().requires_grad_(True)
+    wr = w.to(dtype).float().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, b, 1, 1)
+    gy = rnd(*y_ref.shape, seed=4)
+    y_ref.backward(gy.to(dtype).float())
+    x_pm = to_pm(x, dtype, ld_extra=8)
+    wf, wb = h.pack_weight(w.to(DEV), dtype)
+    for out_f32 in (False, True):
+        y_pm = torch.empty(N, H, W, Co, dtype=torch.float32 if out_f32 else dtype, device=DEV)
+        d = h.conv_desc(x_pm.shape, Co, 3, 1, 1, ldx=h.ld(x_pm), ldy=Co, dtype=h.dt(x_pm), act='none', out_f32=out_f32)
+        h.conv_forward(d, x_pm, wf, b.to(DEV), y_pm)
+        if k_fwd is not None:
+            assert k_fwd in last(), last()
+        assert rel_err(from_pm(y_pm), y_ref.detach()) < tol(dtype), f'forward (f32 result: {out_f32})'
+    gy_pm = to_pm(gy, dtype)
+    dx_pm = torch.empty(N, H, W, Ci, dtype=dtype, device=DEV)
+    dd = h.conv_desc(x_pm.shape, Co, 3, 1, 1, ldx=Ci, ldy=Co, dtype=h.dt(x_pm))
+    h.conv_dgrad(dd, gy_pm, wb, None, dx_pm)
+    if k_dgrad is not None:
+        assert k_dgrad in last(), last()
+    assert rel_err(from_pm(dx_pm), xr.grad) < tol(dtype), 'dgrad'
+    dwd = h.conv_desc(x_pm.shape, Co, 3, 1, 1, ldx=h.ld(x_pm), ldy=Co, dtype=h.dt(x_pm))
+    base = torch.full((Co, 9, Ci), 0.5, device=DEV)
+    runs = []
+    for _ in range(2):
+        buf = base.clone()
+        h.conv_wgrad(dwd, x_pm, gy_pm, into=buf)
+        runs.append(buf)
+    if k_wgrad is not None:
+        assert 'narrow_wgrad_kernel' in last() and last().endswith(k_wgrad), last()
+        assert torch.equal(runs[0], runs[1]), 'the narrow weight gradient must repeat bit for bit'
+    assert rel_err(h.unpack_wgrad(runs[0] - 0.5, Co, Ci, 3, 3), wr.grad) < tol(dtype), 'wgrad'
 
 
 DILATED_CASES = [
