@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/rdfc_hip.h"
@@ -202,6 +203,72 @@ template <typename A> __device__ __forceinline__ void rs_flush(const unsigned ch
         *reinterpret_cast<u32x4 *>(y + off + chunk * 8) = *reinterpret_cast<const u32x4 *>(Ot + px * RS_ROW + chunk * 16);
     }
     __builtin_amdgcn_wave_barrier();         // (the tile may be refilled by the same wave)
+}
+
+// ---- the same with ADDENDS (round 6) -------------------------------------------------------------------------------------------------
+// rdfc_conv2d_dgrad_add / _add2 add one or two maps to the input gradient in the epilogue (residual junctions of the BasicBlocks, skip
+// connections behind the stride-2 stages, chained fan-outs).  Until round 6 a lane fetched its 4 channels of the addend -- 8 bytes --
+// on the way INTO the staging tile: the same 32-byte-per-pixel access pattern the whole-row stores were built to get rid of, on the read
+// side.  tools/addend_bench.py, alone, f16: 64 <- 64 @ 16 x 228 x 304 110 us plain, 170 with one addend (142 MB: 28 us at 5 TB/s);
+// the transposed stride-2 kernel 64 <- 128 77 / 138 / 190 us with none / one / two.  Now the tile is staged in F32 (32 pixels at a
+// time: 32 x 272 B fit the same 9 KB per wave) and the flush -- where a lane owns 8 consecutive channels of a pixel and eight lanes a
+// whole 128-byte row -- loads the addends as 16-byte pieces, adds them in f32 in the old order (bias, activation, addend, second
+// addend, ONE rounding) and stores: same bits as before.
+constexpr int RSF_ROW = 272;                 // bytes per pixel row of the f32 tile: 64 channels x 4 + 16 (bank spread)
+constexpr int RSF_PX = 32;                   // pixels per pass
+static_assert(RSF_PX * RSF_ROW <= RS_TILE, "the f32 tile of a pass lives in the wave's share of the staging LDS");
+__device__ __forceinline__ void rsf_put(unsigned char *Ot, int px, int ch, const float (&v)[4]) {
+    *reinterpret_cast<f32x4 *>(Ot + px * RSF_ROW + ch * 4) = f32x4{v[0], v[1], v[2], v[3]};
+}
+// The addend pieces of a pass are FETCHED a pass ahead (rsf_fetch into registers: the first pass's while the workgroup waits at the
+// barrier in front of the epilogue, the next one's while the current pass is flushed) -- with the loads issued inside the flush, between
+// the staging tile's write and the store, every pass paid a memory round trip (64 <- 64 @ 16 x 228 x 304: 170 -> 158 us only).
+struct RsfAdd {
+    bf16x8 a[RSF_PX / 8];                    // a lane's four 16-byte pieces of one addend and pass
+};
+// add: element 0 of the addend + the wave's first channel; nch as in rs_flush; pix(px) -> PIXEL index of tile pixel px (0 .. 31) in the
+// maps, < 0: no such pixel; ld: pixel stride (a multiple of 8: every piece is 16-byte aligned)
+template <typename A> __device__ __forceinline__ void rsf_fetch(RsfAdd &r, int lane, const bf16_t *add, int ld, int nch, A &&pix) {
+    const int chunk = lane & 7;
+#pragma unroll
+    for (int k = 0; k < RSF_PX / 8; ++k) {
+        const long po = pix(8 * k + (lane >> 3));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.a[k][i] = (bf16_t)0.0f;
+        if (po >= 0 && chunk * 8 < nch) r.a[k] = *reinterpret_cast<const bf16x8 *>(add + po * ld + chunk * 8);
+    }
+}
+// y: element 0 of the result + the wave's first channel; r1 (and r2, may be null): the fetched pieces of this pass
+template <int DT, typename A>
+__device__ __forceinline__ void rsf_flush(const unsigned char *Ot, int lane, bf16_t *y, int ld_out, const RsfAdd &r1, const RsfAdd *r2, int nch, A &&pix) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int chunk = lane & 7;
+#pragma unroll
+    for (int k = 0; k < RSF_PX / 8; ++k) {
+        const int px = 8 * k + (lane >> 3);
+        const long po = pix(px);
+        if (po < 0 || chunk * 8 >= nch) continue;
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(Ot + px * RSF_ROW + chunk * 32), hi = *reinterpret_cast<const f32x4 *>(Ot + px * RSF_ROW + chunk * 32 + 16);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += f32of<DT>(r1.a[k][r]);
+        if (r2 != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += f32of<DT>(r2->a[k][r]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = cvt16<DT>(v[r]);
+        *reinterpret_cast<bf16x8 *>(y + po * ld_out + chunk * 8) = o;
+    }
+    __builtin_amdgcn_wave_barrier();         // (the tile may be refilled by the same wave)
+}
+// whether the addends of a launch qualify for it (else: the 8-byte pieces on the way in, as before)
+static inline bool rsf_ok(const void *addend, int ld_add, const void *addend2 = nullptr, int ld_add2 = 0) {
+    static const bool on = !(getenv("RDFC_RSF") != nullptr && atoi(getenv("RDFC_RSF")) == 0);      // RDFC_RSF=0: A/B against the 8-byte pieces
+    return on && addend != nullptr && ld_add % 8 == 0 && (reinterpret_cast<size_t>(addend) & 15) == 0 &&
+           (addend2 == nullptr || (ld_add2 % 8 == 0 && (reinterpret_cast<size_t>(addend2) & 15) == 0));
 }
 
 // ---- wave / block reductions ---------------------------------------------------------

@@ -513,6 +513,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(GParams p, const b
         }
     };
     // ---- whole-row stores (common.h: rs_put / rs_flush); an f32 result keeps the direct path ---------------------------------------------
+    if (p.row_store == 2) {
+        // the launches with an addend (rdfc_conv2d_dgrad_add): f32 staging, 32 pixels (two tile rows) per pass, the addend fetched in whole
+        // 128-byte rows a pass ahead and added by the flush (common.h: rsf_put / rsf_fetch / rsf_flush) -- same arithmetic, same order,
+        // same bits as the path below
+        const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
+        const int cow = co0 + wr * 64;
+        const bf16_t *addw = reinterpret_cast<const bf16_t *>(p.addend) + cow;
+        auto ppix = [&](int j0, int px) -> long {                  // pixel index of pixel px (0 .. 31) of the pass that starts at tile row j0
+            const int j = j0 + (px >> 4), c = px & 15;             // (px >> 4: compile-time after unrolling)
+            if (oyr[j] < 0 || x0 + c >= p.W) return -1;
+            return ((long)on[j] * p.H + oyr[j]) * p.W + x0 + c;
+        };
+        RsfAdd cur, nxt;
+        rsf_fetch(cur, lane, addw, p.ld_add, p.Cout - cow, [&](int px) { return ppix(0, px); });
+        __syncthreads();                                           // every wave is done with the operand tiles
+        unsigned char *Ot = smem + wave * RS_TILE;
+#pragma unroll
+        for (int j0 = 0; j0 < JR; j0 += 2) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = acc[i][j0 + jj][r] + bv[i][r];
+                        v[r] = u > 0.f ? u : u * ns;
+                    }
+                    rsf_put(Ot, 16 * jj + (lane & 15), 16 * i + q4, v);
+                }
+            if (j0 + 2 < JR) rsf_fetch(nxt, lane, addw, p.ld_add, p.Cout - cow, [&](int px) { return ppix(j0 + 2 < JR ? j0 + 2 : j0, px); });
+            rsf_flush<DT>(Ot, lane, reinterpret_cast<bf16_t *>(yout) + cow, p.ld_out, cur, nullptr, p.Cout - cow, [&](int px) { return ppix(j0, px); });
+            cur = nxt;
+        }
+        return;
+    }
     if (p.row_store) {
         const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
         __syncthreads();                                           // every wave is done with the operand tiles
@@ -750,6 +786,7 @@ int rdfc_try_conv3x3_glds(const rdfc_conv_desc *d, int transposed, const void *i
     p.row_store = !d->out_f32 && Cout % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
+    if (p.row_store && rsf_ok(addend, ld_add)) p.row_store = 2;         // the addend in whole rows, from the flush (common.h)
     p.tiles_x = cdiv(p.W, TC);                                 // 128 co x (2 JR x 16) px or 64 co x (16 x 16) px per workgroup
     if (stats != nullptr) {
         if (G < 1 || p.N % G != 0 || transposed || reflect) return 0;

@@ -252,6 +252,37 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(IGParams p, const bf1
         }
     }
     // ---- whole-row stores (common.h: rs_put / rs_flush); an addend is added here, in f32, from its 8-byte pieces -----------------------
+    if (p.row_store == 2) {
+        // launches with an addend (rdfc_conv2d_dgrad_add): f32 staging, 32 of the wave's 64 pixels per pass, the addend fetched in whole
+        // 128-byte rows a pass ahead and added by the flush (common.h: rsf_put / rsf_fetch / rsf_flush); same bits as the path below
+        const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
+        const int cow = co0 + wr * 64;
+        const bf16_t *addw = reinterpret_cast<const bf16_t *>(p.addend) + cow;
+        auto ppix = [&](int j0, int px) -> long { return (long)pxo[wc * 64 + 16 * j0 + px]; };
+        RsfAdd cur, nxt;
+        rsf_fetch(cur, lane, addw, p.ld_add, p.Cout - cow, [&](int px) { return ppix(0, px); });
+        __syncthreads();
+        unsigned char *Ot = smem + wave * RS_TILE;
+#pragma unroll
+        for (int j0 = 0; j0 < 4; j0 += 2) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = acc[i][j0 + jj][r] + bv[i][r];
+                        v[r] = u > 0.f ? u : u * ns;
+                    }
+                    rsf_put(Ot, 16 * jj + (lane & 15), 16 * i + q4, v);
+                }
+            if (j0 == 0) rsf_fetch(nxt, lane, addw, p.ld_add, p.Cout - cow, [&](int px) { return ppix(2, px); });
+            rsf_flush<DT>(Ot, lane, reinterpret_cast<bf16_t *>(yout) + cow, p.ld_out, cur, nullptr, p.Cout - cow, [&](int px) { return ppix(j0, px); });
+            cur = nxt;
+        }
+        return;
+    }
     if (p.row_store) {
         const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
         __syncthreads();                                           // every wave is done with the operand tiles
@@ -394,6 +425,7 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
     // qdiv's range: one image's (parity class of) output pixels and the stride / tap arithmetic below 2^21; the batch's flat pixel index goes
     // through qdiv_wide (round 5 refused N * Hout * Wout >= 2^21 here -- batch 8 at 480 x 640 fell back to the register-staged kernel silently)
+    if (p.row_store && rsf_ok(addend, ld_add)) p.row_store = 2;        // the addend in whole rows, from the flush (common.h)
     if ((long)p.Hout * p.Wout >= (1L << 21) || (long)p.N * p.Hout * p.Wout >= 0x7fffff00L || d->KH * d->dh + d->ph > 1000 || d->KW * d->dw + d->pw > 1000 ||
         d->sh > 1000 || d->sw > 1000) return 0;
     p.r_sh = 1.f / (float)d->sh;

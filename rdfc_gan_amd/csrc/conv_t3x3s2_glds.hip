@@ -252,6 +252,50 @@ __global__ __launch_bounds__(NT, 2) void convt3x3s2_glds_kernel(TParams p, const
     };
     // ---- whole-row stores (common.h: rs_put / rs_flush): per result-row parity ry the wave's two column classes are 2 rows x 32
     //      CONSECUTIVE result pixels x 64 channels = one 64-pixel tile (tile pixel = 32 j + 2 col + rx) -----------------------------------
+    if (p.row_store == 2) {
+        // launches with addends (rdfc_conv2d_dgrad_add / _add2): f32 staging, one result row of the wave (32 consecutive pixels) per pass,
+        // the addends fetched in whole 128-byte rows a pass ahead and added by the flush (common.h: rsf_put / rsf_fetch / rsf_flush); same
+        // bits as the path below
+        const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
+        const bf16_t *add1 = reinterpret_cast<const bf16_t *>(p.addend) + co0;
+        const bf16_t *add2 = p.addend2 != nullptr ? reinterpret_cast<const bf16_t *>(p.addend2) + co0 : nullptr;
+        auto ppix = [&](int pass, int px) -> long {                // pass = 2 ry + j: result row 2 (y0 + JR wave + j) + ry, pixels 2 x0 ...
+            const int oy = 2 * (y0 + JR * wave + (pass & 1)) + (pass >> 1);
+            if (oy >= p.Hr || 2 * x0 + px >= p.Wr) return -1;
+            return ((long)n * p.Hr + oy) * p.Wr + 2 * x0 + px;
+        };
+        static_assert(JR == 2, "pass = 2 ry + j");
+        RsfAdd c1, c2, n1, n2;
+        rsf_fetch(c1, lane, add1, p.ld_add, p.Cout - co0, [&](int px) { return ppix(0, px); });
+        if (add2 != nullptr) rsf_fetch(c2, lane, add2, p.ld_add2, p.Cout - co0, [&](int px) { return ppix(0, px); });
+        __syncthreads();
+        unsigned char *Ot = smem + wave * RS_TILE;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int ry = pass >> 1, j = pass & 1;
+#pragma unroll
+            for (int rx = 0; rx < 2; ++rx)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = acc[2 * ry + rx][i][j][r] + bv[i][r];
+                        v[r] = u > 0.f ? u : u * ns;
+                    }
+                    rsf_put(Ot, 2 * (lane & 15) + rx, 16 * i + q4, v);
+                }
+            if (pass < 3) {
+                rsf_fetch(n1, lane, add1, p.ld_add, p.Cout - co0, [&](int px) { return ppix(pass < 3 ? pass + 1 : pass, px); });
+                if (add2 != nullptr) rsf_fetch(n2, lane, add2, p.ld_add2, p.Cout - co0, [&](int px) { return ppix(pass < 3 ? pass + 1 : pass, px); });
+            }
+            rsf_flush<DT>(Ot, lane, reinterpret_cast<bf16_t *>(yout) + co0, p.ld_out, c1, add2 != nullptr ? &c2 : nullptr, p.Cout - co0,
+                          [&](int px) { return ppix(pass, px); });
+            c1 = n1;
+            c2 = n2;
+        }
+        return;
+    }
     if (p.row_store) {
         const float ns = p.act == RDFC_ACT_NONE ? 1.f : (p.act == RDFC_ACT_RELU ? 0.f : p.slope);
         __syncthreads();                                           // every wave is done with the operand tiles
@@ -359,6 +403,7 @@ int rdfc_try_convt3x3s2_glds(const rdfc_conv_desc *d, const void *src, const voi
                   (addend == nullptr || (ld_add % 4 == 0 && (reinterpret_cast<size_t>(addend) & 7) == 0)) &&
                   (addend2 == nullptr || (ld_add2 % 4 == 0 && (reinterpret_cast<size_t>(addend2) & 7) == 0)) &&
                   d->act != RDFC_ACT_TANH && d->act != RDFC_ACT_SIGMOID;
+    if (p.row_store && rsf_ok(addend, ld_add, addend2, ld_add2)) p.row_store = 2;     // the addends in whole rows, from the flush (common.h)
     if (KS == 4) return d->dtype == RDFC_F16 ? launch<RDFC_F16, 4>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16, 4>(p, src, w_bwd, bias, res, zero, st);
     return d->dtype == RDFC_F16 ? launch<RDFC_F16, 3>(p, src, w_bwd, bias, res, zero, st) : launch<RDFC_BF16, 3>(p, src, w_bwd, bias, res, zero, st);
 }

@@ -206,3 +206,34 @@ def test_igemm_glds_takes_batches_beyond_2_21_pixels():
     ref = x.view(P, Ci)[idx.to(DEV)].float().cpu() @ w.view(Co, Ci).cpu().t()
     got = y.view(P, Co)[idx.to(DEV)].float().cpu()
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize('dtype', DT, ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', [LAYERS[0], LAYERS[1], LAYERS[5], LAYERS[6], LAYERS[8]], ids=[IDS[0], IDS[1], IDS[5], IDS[6], IDS[8]])
+def test_epilogue_addends_in_whole_rows_give_the_same_bits(case, dtype):
+    """round 6: rdfc_conv2d_dgrad_add / _add2 at the benchmark's launch sizes -- the addends fetched as 16-byte pieces by the epilogue's flush
+    from an f32 staging tile (common.h: rsf_flush; 16-byte aligned maps) against the 8-byte pieces on the way into the 16-bit tile (maps
+    that are only 8-byte aligned: channel slices starting at channel 4), which is the path every earlier round's parity tests ran on.  The
+    arithmetic and its order are the same: bit-equal.  And both equal the plain input gradient + the maps within one rounding."""
+    hip, d, x, w, wf, wb, gy, oshape = _layer(case, dtype, seed=2)
+    N, H, W, Ci, Co, k, s, p = case
+    g = torch.Generator(device=DEV).manual_seed(9)
+    wide = [torch.randn(N, H, W, Ci + 8, device=DEV, generator=g).to(dtype) for _ in range(2)]
+    al = [t[..., 8:] for t in wide]                       # 16-byte aligned slices
+    odd = []
+    for t in al:
+        o = torch.zeros(N, H, W, Ci + 8, dtype=dtype, device=DEV)[..., 4:4 + Ci]
+        o.copy_(t)
+        odd.append(o)
+    assert al[0].data_ptr() % 16 == 0 and odd[0].data_ptr() % 16 == 8
+    plain = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x))
+    one_a = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x), addend=al[0])
+    one_o = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x), addend=odd[0])
+    assert torch.equal(one_a, one_o)
+    ref = plain.float() + al[0].float()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert float((one_a.float() - ref).abs().max()) <= 2 * eps * float(ref.abs().max())
+    if s == 2:                                            # the transposed stride-2 kernel takes two
+        two_a = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x), addend=al[0], addend2=al[1])
+        two_o = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x), addend=odd[0], addend2=odd[1])
+        assert torch.equal(two_a, two_o)

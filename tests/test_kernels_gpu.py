@@ -934,6 +934,15 @@ def test_dgrad_with_addend_and_reflect_adjoint_with_addend(case, dtype):
     fused = h.conv_dgrad(d, gy, wb, None, torch.empty(N, H, W, Ci, dtype=dtype, device=DEV), addend=add)
     ref = plain.float() + add.float()
     assert rel_err(fused.float(), ref) < {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+    if dtype != torch.float32:
+        # round 6: an addend whose pieces are 16-byte aligned is fetched in whole rows by the epilogue's flush from an f32 staging tile
+        # (common.h: rsf_flush); one that is only 8-byte aligned -- a slice starting at channel 4 -- keeps the 8-byte pieces on the way into
+        # the 16-bit tile.  Same arithmetic in the same order: the two must agree bit for bit
+        odd = torch.zeros(N, H, W, Ci + 8, dtype=dtype, device=DEV)[..., 4:4 + Ci]
+        odd.copy_(add)
+        assert odd.data_ptr() % 16 == 8
+        fused_odd = h.conv_dgrad(d, gy, wb, None, torch.empty(N, H, W, Ci, dtype=dtype, device=DEV), addend=odd)
+        assert torch.equal(fused_odd, fused)
     # two maps (rdfc_conv2d_dgrad_add2: both in the transposed stride-2 kernel's epilogue where it takes the launch -- RDFC_T3S2=3 in
     # tests/test_variants_gpu.py sends the small shapes there too --, else the one-addend path + a sum pass); the second one a channel slice
     add2 = to_pm(rnd(N, Ci + 8, H, W, seed=7), dtype)[..., 8:]

@@ -27,6 +27,8 @@ VARIANTS = [
     ('RDFC_GLDS_JR', '6', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
     ('RDFC_GLDS_JR', '8', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
     ('RDFC_GLDS_JR', '10', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
+    # round 6: epilogue addends as 8-byte pieces on the way into the staging tile (the path of rounds 4-5) instead of whole rows from the flush
+    ('RDFC_RSF', '0', 'addend and not f32'),
 ]
 
 
@@ -44,7 +46,10 @@ def _run_all():
     def one(variant):
         name, value, expr = variant[:3]
         test_files = variant[3:] if len(variant) > 3 else ('test_kernels_gpu.py',)
-        env = dict(os.environ, **{name: value})
+        # (each child computes its fp32 references on the host with torch's thread pool: three pools of cpu_count threads each oversubscribe
+        #  the cores several-fold and everything crawls -- a third of the cores per child)
+        nthr = str(max(4, (os.cpu_count() or 12) // 3))
+        env = dict(os.environ, OMP_NUM_THREADS=nthr, MKL_NUM_THREADS=nthr, **{name: value})
         try:
             r = subprocess.run([sys.executable, '-m', 'pytest'] + [os.path.join(ROOT, 'tests', f) for f in test_files] + ['-q', '-x', '-k', expr, '-p', 'no:cacheprovider'],
                                cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
