@@ -407,6 +407,9 @@ int rdfc_try_igemm_glds(const rdfc_conv_desc *d, int transposed, const void *in,
     // kernel (1x1 192->384, 6 steps: 83 vs 69 us); with three slots and three workgroups per CU this kernel wins from 6 steps up
     // (1x1 192->384 67 -> 63 us forward, 67 -> 57 input gradient; 1x1 384->768 57 -> 49 / 56 -> 47; 1x1 768->1536 60 -> 46;
     // 3x3/s2 64->128 54 -> 46); 3-step reductions (1x1 96->192) stay where they were.
+    // (round 6 re-measured the short reductions with this kernel's round-5 set-up: 1x1 / stride 2 64 -> 128 @ 16 x 228 x 304 32.9 -> 27.2 us, its
+    //  input gradient 79.3 -> 59.5, 1x1 96 -> 192 59.1 -> 52.3 alone -- and nothing in the step: 265.4 / 264.0 / 262.6 against 263.8 / 263.2 / 262.0
+    //  pairs/s with min_steps = 2, three interleaved pairs; the threshold stays)
     constexpr int min_steps = 6;
     if (d->KH * d->KW * (Cin / BK) < min_steps) return 0;
     const bf16_t *zero = zero_page();

@@ -1,9 +1,15 @@
 #!/bin/bash
 # usage (GPU box, repo root): bash tools/final_round.sh r03   -> every artefact of a round under gpurun_out/<tag>_*
-tag=${1:-r05}
+tag=${1:-r06}
 mkdir -p gpurun_out
 bash tools/pmc_bench.sh $tag                                                # HBM-side bytes per kernel (separate --pmc passes)
 cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json       # (this box's copy: the bench line below cites counters of THIS build)
+# round 6: the same three passes for the extra legs of the default bench line (bench.py pmc_table: suffix per workload), so that
+# as_worded_bf16 / configs.#3 / configs.#5 carry roofline.traffic and mfma_busy too
+PMC_SUFFIX=_bf16 bash tools/pmc_bench.sh $tag --dtype bf16
+PMC_SUFFIX=_nlspn bash tools/pmc_bench.sh $tag --nlspn
+PMC_SUFFIX=_480x640 bash tools/pmc_bench.sh $tag --height 480 --width 640 --batch 4
+for sfx in _bf16 _nlspn _480x640; do cp gpurun_out/${tag}_pmc_traffic$sfx.json profiles/${tag}_pmc_traffic$sfx.json; done
 bash tools/profile_round.sh $tag                                            # default bench (with CPU baseline) + the same command under rocprofv3
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-as-worded --rccl-self-test > gpurun_out/${tag}_rccl_one_rank_bench.json 2> gpurun_out/${tag}_rccl.err
 bash tools/timeline.sh --no-as-worded > gpurun_out/${tag}_timeline.txt 2>&1
