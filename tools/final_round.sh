@@ -27,6 +27,13 @@ python bench.py --steps 5 --warmup 2 --no-cpu-baseline --dtype f32 > gpurun_out/
 # every conv shape alone (one stream)
 RDFC_BRANCH_STREAMS=0 RDFC_NET_STREAMS=0 RDFC_WGRAD_STREAM=0 RDFC_D_UNDER_G=0 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-as-worded --event-every 1 --by-shape gpurun_out/${tag}_by_shape_one_stream.txt > gpurun_out/${tag}_bench_one_stream.json 2>/dev/null
 JRS=4,6,8,10 python tools/conv_tall_bench.py 3 10 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_conv_tall_ab.txt     # the 3x3 kernel at every forced tile height against the plan's choice
+# round 6: the narrow-map launches and the epilogue addends alone, the NLSPN chains alone, host slack, 1 000-step soaks in f16 and in the f32 parity mode
+bash tools/narrow_bench.sh 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_narrow_bench.txt
+python tools/addend_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_addend_bench.txt
+python tools/nlspn_bench.py 16 228 304 18 1.5 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_nlspn_chains.txt
+python tools/host_slack.py 20 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_host_slack.txt
+SOAK_EVERY=100 python tools/soak.py 1000 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_soak_f16.txt
+SOAK_DTYPE=f32 SOAK_EVERY=100 python tools/soak.py 1000 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_soak_f32.txt
 for f in ${tag}_bench ${tag}_bench_under_rocprof ${tag}_rccl_one_rank_bench ${tag}_nlspn_bench ${tag}_bf16_bench ${tag}_f16_480x640_bench ${tag}_f32_bench ${tag}_bench_one_stream; do
 python3 - gpurun_out/$f.json <<'PY'
 import json,sys

@@ -20,5 +20,5 @@ for i in range(n):
     if i % 20 == 19 and (i + 1) % int(os.environ.get('SOAK_EVERY', 100 if n > 400 else 20)) == 0:
         torch.cuda.synchronize()
         print(f'step {i+1}: allocated {torch.cuda.memory_allocated()/2**30:.2f} GiB, reserved {torch.cuda.memory_reserved()/2**30:.2f} GiB, '
-              f'peak {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, loss_G {ls["loss_G"]:.3f} (A2B_L1_true {ls["loss_A2B_L1_true"]:.3f}, cycle_A {ls["loss_cycle_A"]:.3f}, cycle_B {ls["loss_cycle_B"]:.3f}, D_A {ls["loss_D_A"]:.4f}, D_B {ls["loss_D_B"]:.4f})'
+              f'peak {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, loss_G {ls["loss_G"]:.3f} (' + ', '.join(f'{k[5:]} {ls[k]:.4f}' for k in ('loss_G_A2B', 'loss_G_B2A', 'loss_cycle_A', 'loss_cycle_B', 'loss_A2B_L1', 'loss_D_A', 'loss_D_B') if k in ls) + ')'
               + (f', loss scale {m.scaler.scale():.0f}, skipped {m.scaler.skipped()}' if m.scaler is not None else ''))
