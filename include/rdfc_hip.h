@@ -152,6 +152,16 @@ int rdfc_conv2d_dgrad_add2(const rdfc_conv_desc *d, const void *dy, const void *
                            const void *addend2, int ld_add2, void *dx, void *stream);
 /* dw_packed f32 [Co][KH*KW][Ci] += sum_pixels dy (x) x   (caller zeroes dw_packed first). */
 int rdfc_conv2d_wgrad(const rdfc_conv_desc *d, const void *x, const void *dy, float *dw_packed, void *stream);
+/* Weight AND bias gradient of a conv block WITHOUT a normalisation layer with the backward of its activation folded in (round 6): the
+ * stems -- conv_bn_relu(..., bn=False) on the 3- / 1-channel inputs at full resolution (rdf_generator.py:60-66, common.py:29-44), where
+ * autograd runs ReLU's backward (a pass over dz and y that writes dy), the bias gradient (a pass over dy) and the weight gradient (another
+ * one).  dz: the cotangent BEHIND the activation (pixel stride d->ldy), y_act: the block's activated output (pixel stride ld_y);
+ * dy = dz * act'(y_act) is formed while dz is staged, rounded once like rdfc_act_bwd's result; d->act / d->slope name the activation
+ * (RDFC_ACT_RELU | RDFC_ACT_LRELU).  dw_packed [Co][KH*KW][Ci] and dbias [Co] (may be NULL) are ACCUMULATED into, like rdfc_conv2d_wgrad.
+ * Covered: thin inputs (Ci <= 4), stride 1, 2-byte dtypes -- ask rdfc_conv2d_wgrad_act_supported first (1 = covered). */
+int rdfc_conv2d_wgrad_act_supported(const rdfc_conv_desc *d);
+int rdfc_conv2d_wgrad_act(const rdfc_conv_desc *d, const void *x, const void *dz, const void *y_act, int ld_y, float *dw_packed,
+                          float *dbias, void *stream);
 
 /* ------------------------------------------------------------------------------
  * Layout / data movement.

@@ -289,6 +289,38 @@ def _geometry(spec, x, weight):
     return Cout, Ho, Wo
 
 
+def _stem_backward(ctx, spec, x, weight, dz, yout, d_alias):
+    """the backward of a conv + bias + ReLU / LeakyReLU block that needs NO input gradient and whose parameters' .grad buffers take
+    accumulation (FlatAdam's): one launch for weight and bias gradient with the activation's backward folded in.  -> True if it ran"""
+    if (ctx.needs_input_grad[0] or d_alias is not None or spec.reflect or spec.transposed or spec.wscale != 1.0 or not x.is_cuda
+            or spec.act not in ('relu', 'lrelu') or not ctx.needs_input_grad[1]):
+        return False
+    g, bg = weight.grad, (ctx.bias.grad if ctx.has_bias else None)
+    if not (g is not None and g.dtype == torch.float32 and hip.is_ohwi(g) and not g.requires_grad):
+        return False
+    if ctx.has_bias and not (ctx.needs_input_grad[2] and _accumulable(bg)):
+        return False
+    if yout.dtype != x.dtype or dz.data_ptr() % 16 or yout.data_ptr() % 16 or hip.ld(yout) % 8:
+        return False
+    Cout = weight.shape[0]
+    d = hip.conv_desc(x.shape, Cout, spec.k, spec.stride, spec.pad, spec.dil, ldx=hip.ld(x), ldy=hip.ld(dz), dtype=hip.dt(x), act=spec.act,
+                      slope=spec.slope)
+    if not hip.conv_wgrad_act_supported(d):
+        return False
+    if _WGRAD_STREAM and _multi_stream:
+        stream, keep = _side_stream(x.device)
+        stream.wait_stream(torch.cuda.current_stream(x.device))
+        if hip.PROFILE is None:
+            hip.conv_wgrad_act(d, x, dz, yout, g, bg, stream=stream.cuda_stream)
+        else:
+            with torch.cuda.stream(stream):                                 # (per-kernel events record on the current stream)
+                hip.conv_wgrad_act(d, x, dz, yout, g, bg)
+        keep.append((x, dz, yout))          # their memory must not be recycled before the join
+    else:
+        hip.conv_wgrad_act(d, x, dz, yout, g, bg)
+    return True
+
+
 class _ConvBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, res, prelu, spec, training, run_mean, run_var, cat_with=None, chain=None):
@@ -403,6 +435,10 @@ class _ConvBlock(torch.autograd.Function):
             if spec.act != 'none':
                 if dz.dtype != x.dtype:
                     dz = dz.to(x.dtype)
+                if _stem_backward(ctx, spec, x, weight, dz, yout, d_alias):
+                    # the stems (no input gradient, thin input): ReLU's backward, the bias gradient and the weight gradient in ONE pass over
+                    # dz and y (rdfc_conv2d_wgrad_act) instead of three passes and a dy map in between
+                    return None, None, None, g_gamma, g_beta, g_res, g_prelu, None, None, None, None, g_cat, None
                 dy = hip.act_bwd(dz, yout, spec.act, spec.slope)
             else:
                 dy = dz if dz.dtype == x.dtype else dz.to(x.dtype)

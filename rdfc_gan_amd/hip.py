@@ -399,6 +399,20 @@ def conv_wgrad(d, x, dy, into=None, stream=None, reflect=False):
     return dw
 
 
+def conv_wgrad_act_supported(d):
+    """whether conv_wgrad_act covers the layer (thin input, stride 1, ReLU / LeakyReLU in d.act)"""
+    return bool(lib().rdfc_conv2d_wgrad_act_supported(C.byref(d)))
+
+
+def conv_wgrad_act(d, x, dz, y_act, into, bias_into=None, stream=None):
+    """weight (and bias) gradient of a conv block without normalisation, its activation's backward folded in: dz is the cotangent behind
+    the activation named by d.act / d.slope, y_act the block's activated output; accumulates into `into` [Co][KH*KW][Ci] (and bias_into)"""
+    with _Timed('wgrad_kernel (conv weight grad)', d):
+        _chk(lib().rdfc_conv2d_wgrad_act(C.byref(d), _p(x), _p(dz), _p(y_act), ld(y_act), _p(into), _p(bias_into),
+                                         _st() if stream is None else stream), 'rdfc_conv2d_wgrad_act')
+    return into
+
+
 def wgrad_ring_reserve(stream, nbytes=0):
     """give `stream` (a torch.cuda.Stream) the deterministic weight-gradient kernels' scratch slab before it is captured into a graph"""
     _chk(lib().rdfc_wgrad_ring_reserve(stream.cuda_stream, C.c_size_t(nbytes)), 'rdfc_wgrad_ring_reserve')

@@ -218,6 +218,49 @@ def test_narrow_map_convs(case, dtype):
     assert rel_err(h.unpack_wgrad(runs[0] - 0.5, Co, Ci, 3, 3), wr.grad) < tol(dtype), 'wgrad'
 
 
+@pytest.mark.parametrize('dtype', DTYPES[1:], ids=DT_IDS[1:])
+@pytest.mark.parametrize('case', [(4, 130, 140, 3, 64, 3, 'relu'), (4, 130, 141, 1, 16, 3, 'lrelu'), (3, 131, 150, 3, 48, 3, 'relu'), (4, 134, 146, 1, 64, 7, 'lrelu')],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_stem_backward_in_one_pass(case, dtype):
+    """rdfc_conv2d_wgrad_act (round 6): weight and bias gradient of conv + bias + ReLU / LeakyReLU with the activation's backward folded into
+    the staging of the cotangent -- against the three passes it replaces (rdfc_act_bwd, rdfc_channel_sum, rdfc_conv2d_wgrad: same 16-bit dy,
+    so only the order of the f32 adds differs) and against autograd in fp32 on identically rounded operands; the cotangent is a channel
+    slice of a wider map, both gradients ACCUMULATE into non-zero buffers."""
+    h = hip()
+    N, H, W, Ci, Co, k, act = case
+    pad = k // 2
+    slope = 0.2 if act == 'lrelu' else 0.0
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    xr, wr, br = x.to(dtype).float(), w.to(dtype).float().requires_grad_(True), b.clone().requires_grad_(True)
+    x_pm = to_pm(x, dtype)
+    wf, _ = h.pack_weight(w.to(DEV), dtype)
+    y = torch.empty(N, H, W, Co, dtype=dtype, device=DEV)
+    d = h.conv_desc(x_pm.shape, Co, k, 1, pad, ldx=h.ld(x_pm), ldy=Co, dtype=h.dt(x_pm), act=act, slope=slope)
+    h.conv_forward(d, x_pm, wf, b.to(DEV), y)
+    gz = rnd(N, Co, H, W, seed=4)
+    dz = to_pm(gz, dtype, ld_extra=8)
+    dd = h.conv_desc(x_pm.shape, Co, k, 1, pad, ldx=h.ld(x_pm), ldy=h.ld(dz), dtype=h.dt(x_pm), act=act, slope=slope)
+    assert h.conv_wgrad_act_supported(dd)
+    dw = torch.full((Co, k * k, Ci), 0.25, device=DEV)
+    db = torch.full((Co,), -0.5, device=DEV)
+    h.conv_wgrad_act(dd, x_pm, dz, y, dw, db)
+    assert 'wgrad_thin_kernel' in h.lib().rdfc_last_kernel().decode() and 'true' in h.lib().rdfc_last_kernel().decode()
+    # the three passes it replaces
+    dy = h.act_bwd(dz, y, act, slope)
+    dw3 = h.conv_wgrad(h.conv_desc(x_pm.shape, Co, k, 1, pad, ldx=h.ld(x_pm), ldy=Co, dtype=h.dt(x_pm)), x_pm, dy)
+    db3 = h.channel_sum(dy)
+    assert rel_err(dw - 0.25, dw3) < 2e-5 and rel_err(db + 0.5, db3) < 2e-5
+    # autograd: the mask comes from the STORED (rounded) output, as in the kernels
+    pre = F.conv2d(xr, wr, br, 1, pad)
+    mask = from_pm(y) > 0
+    g_pre = gz.to(dtype).float() * torch.where(mask, torch.ones(()), torch.full((), slope))
+    pre.backward(g_pre.to(dtype).float())
+    assert rel_err(h.unpack_wgrad(dw - 0.25, Co, Ci, k, k), wr.grad) < tol(dtype)
+    assert rel_err(db + 0.5, br.grad) < tol(dtype)
+
+
 DILATED_CASES = [
     # N, H, W, Ci, Co, k, s, p, dil   (label net: dilated ResNet-50 stages, backbone_resnet50.py:126-235)
     (2, 15, 19, 64, 64, 3, 1, 2, 2),
