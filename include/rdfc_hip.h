@@ -50,6 +50,10 @@ void rdfc_tune_glds_rows(int rows_per_wave);
  * older kernels by measurement; the initial value comes from RDFC_WGRAD_RING, read once.  Process-wide, not thread-safe.  No upstream
  * counterpart. */
 void rdfc_tune_wgrad_ring(int mode);
+/* Measurement / test aid: 1 (default; RDFC_WGRAD_KG) = the three kernel rows of a 64-channel tile of the ring weight gradient run as ONE
+ * 768-thread workgroup in lockstep (one fabric read of dY and X instead of up to three), 0 = one row per 256-thread workgroup as in
+ * rounds 3-5.  Same bits either way.  No upstream counterpart. */
+void rdfc_tune_wgrad_kg(int on);
 int rdfc_version(void);
 /* sha256 (first 16 hex digits) of the kernel sources this library was built from (rdfc_gan_amd/build.py: source_hash()): measurement
  * artefacts under profiles/ carry it, and bench.py refuses counters taken from another build.  No upstream counterpart. */

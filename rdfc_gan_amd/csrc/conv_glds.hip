@@ -644,8 +644,7 @@ int launch(const GParams &p, const void *x, const void *w, const float *bias, vo
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * (p.vstride ? 1 : p.N), cdiv(p.Cout, TCO));
-    if (JR == 4) rdfc_note_kernel("conv3x3_glds_kernel<%d, %d>", TCO, DT);         // the symbol as rocprofv3 prints it (a default template argument is not printed)
-    else rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d>", TCO, DT, JR);
+    rdfc_note_kernel("conv3x3_glds_kernel<%d, %d, %d>", TCO, DT, JR);            // the symbol as rocprofv3 prints it (every template argument, a default one too: round 6 -- the JR = 4 launches used to be noted without it and missed their counters in profiles/*_pmc_traffic.json)
     hipLaunchKernelGGL((conv3x3_glds_kernel<TCO, DT, JR>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)w, bias, y, zero, stats);
     return 1;
 }

@@ -100,8 +100,14 @@ __device__ inline bf16x8 tr_pair2(const unsigned char *a0, const unsigned char *
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int TCO, int DT, int S = 1, int K = 3, bool REFL = false>
-__global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring2_kernel(RParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
+// KG (round 6): kernel rows per workgroup.  KG = 1: a 256-thread workgroup owns ONE kernel row ky of its (co, ci) tile (blockIdx.y counts
+// (tile, ky)).  KG = K: a workgroup is K such four-wave groups side by side -- group g = ky, its own slots and rings in its own third of the
+// LDS, the same code -- that share NOTHING BUT THE BARRIER: the K groups walk the slice in lockstep, so the dY block they all stage and the
+// X' rows they stage one row apart are fetched from the fabric once and found in the L2 / L1 by the other two.  As separate workgroups
+// the three drifted apart: 472 MB fetched per launch on the 64-channel full-resolution layers for 260 MB of operands
+// (profiles/r05_pmc_traffic.json), in the phase of the step where the convolutions and normalisation passes of the same maps want the same HBM.
+template <int TCO, int DT, int S = 1, int K = 3, bool REFL = false, int KG = 1>
+__global__ __launch_bounds__(NT * KG, KG > 1 ? 1 : (TCO == 128 ? 2 : 3)) void wgrad_ring2_kernel(RParams p, const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                                            float *__restrict__ slab) {
     constexpr int TCI = 64, NPL = S;
     constexpr bool PIPE = S == 1;
@@ -118,10 +124,14 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring2_kernel(RPa
     constexpr int MT = WTCO / 16, NTF = WTCI / 16;
     constexpr int NSH = S == 1 ? K : K / 2 + 1;                 // distinct shifts within a plane: 3 | 4 (stride 1), 2 | 3 (stride 2)
     static_assert(XR >= LOOK + 2 && U % RY == 0, "ring sizes");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    static_assert(KG == 1 || KG == K, "one kernel row per workgroup, or all of them");
+    constexpr int SMEM_G = RY * YB + NPL * XRING;                // LDS of one four-wave group
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_all[];
+    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    unsigned char *smem = smem_all + grp * SMEM_G;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem_all + (unsigned)(grp * SMEM_G);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x & (NT - 1), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.y, slice = blockIdx.x;
     if (p.xcd_group) {
         const int k = blockIdx.x >> 3;
@@ -129,8 +139,11 @@ __global__ __launch_bounds__(NT, TCO == 128 ? 2 : 3) void wgrad_ring2_kernel(RPa
         slice = (k / p.tiles) * 8 + (blockIdx.x & 7);
     }
     if (slice >= p.nslices) return;
-    const int ky = tile % K;
-    tile /= K;
+    int ky = grp;
+    if (KG == 1) {
+        ky = tile % K;
+        tile /= K;
+    }
     const int ci0 = (tile % p.tiles_ci) * TCI, co0 = (tile / p.tiles_ci) * TCO;
     const int seg0 = slice * p.steps_per_slice;
     int nseg = p.total_steps - seg0;
@@ -411,23 +424,34 @@ float *slab_for(hipStream_t st, size_t bytes, bool reserve_only = false) {
     return (float *)e->ptr;
 }
 
+// RDFC_WGRAD_KG=0: one kernel row per 256-thread workgroup everywhere (rounds 3-5; A/B); rdfc_tune_wgrad_kg switches inside a process
+// (measurement / test aid like rdfc_tune_wgrad_ring: process-wide, not thread-safe)
+static bool g_ring_kg = !(getenv("RDFC_WGRAD_KG") != nullptr && atoi(getenv("RDFC_WGRAD_KG")) == 0);
+extern "C" void rdfc_tune_wgrad_kg(int on) { g_ring_kg = on != 0; }
+
 template <int TCO, int DT, int S, int K>
 int launch(RParams p, const void *x, const void *dy, float *dw, hipStream_t st) {
     constexpr int XR = S == 1 ? 8 : 4;
     constexpr int SMEM = 4 * (SEG * TCO * 2) + S * XR * (SEG * 64 * 2);
+    // the 64-co tile of the 3x3 / stride-1 layers (48 KB, three workgroups per CU): the three kernel rows of a tile as ONE 768-thread
+    // workgroup in lockstep (the kernel's KG) -- same LDS per CU, same waves per SIMD, dY and X' fetched from the fabric once
+    constexpr bool KG_OK = TCO == 64 && S == 1 && K == 3;
+    const bool kg = KG_OK && g_ring_kg && !p.reflect;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)wgrad_ring2_kernel<TCO, DT, S, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
         if constexpr (S == 1 && K == 3)
             if (hipFuncSetAttribute((const void *)wgrad_ring2_kernel<TCO, DT, S, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 0;
+        if constexpr (KG_OK)
+            if (hipFuncSetAttribute((const void *)wgrad_ring2_kernel<TCO, DT, S, K, false, K>, hipFuncAttributeMaxDynamicSharedMemorySize, K * SMEM) != hipSuccess) return 0;
         attr_set = true;
     }
     p.tiles_ci = cdiv(p.Ci, 64);
-    const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * K;
-    // one round of the chip's workgroup slots (2 per CU with the 128-co tile, 3 with the 64-co one) within a slab budget: every
-    // workgroup writes its tile once (plain stores) and the reduction reads it once
+    const int tiles = cdiv(p.Co, TCO) * p.tiles_ci * (kg ? 1 : K);
+    // one round of the chip's workgroup slots (2 per CU with the 128-co tile, 3 with the 64-co one, 1 with three kernel rows per
+    // workgroup) within a slab budget: every workgroup writes its tile once (plain stores) and the reduction reads it once
     constexpr double cap_mb = 64.0;
-    const int slots = TCO == 64 ? 768 : 512;
+    const int slots = kg ? 256 : (TCO == 64 ? 768 : 512);
     int slices = slots / tiles;
     const size_t dw_bytes = (size_t)4 * p.Co * p.Ci * K * K;
     const int cap = (int)(cap_mb * 1.0e6 / (double)dw_bytes);
@@ -442,7 +466,16 @@ int launch(RParams p, const void *x, const void *dy, float *dw, hipStream_t st) 
     if (slab == nullptr) return 0;
     p.xcd_group = tiles <= 4 && slices >= 8;
     const dim3 grid = p.xcd_group ? dim3(cdiv(slices, 8) * 8 * tiles, 1) : dim3(slices, tiles);
-    rdfc_note_kernel("wgrad_ring2_kernel<%d, %d, %d, %d, %s>", TCO, DT, S, K, p.reflect ? "true" : "false");
+    // (the symbol as rocprofv3 prints it: every template argument, defaults included)
+    rdfc_note_kernel("wgrad_ring2_kernel<%d, %d, %d, %d, %s, %d>", TCO, DT, S, K, p.reflect ? "true" : "false", kg ? K : 1);
+    if constexpr (KG_OK) {
+        if (kg) {
+            hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, false, K>), grid, dim3(NT * K), K * SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
+            const size_t n4 = dw_bytes / 16;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float *)slab, dw, n4, slices);
+            return 1;
+        }
+    }
     if constexpr (S == 1 && K == 3) {
         if (p.reflect) hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, true>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);
         else hipLaunchKernelGGL((wgrad_ring2_kernel<TCO, DT, S, K, false>), grid, dim3(NT), SMEM, st, p, (const bf16_t *)x, (const bf16_t *)dy, slab);

@@ -237,3 +237,24 @@ def test_epilogue_addends_in_whole_rows_give_the_same_bits(case, dtype):
         two_a = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x), addend=al[0], addend2=al[1])
         two_o = hip.conv_dgrad(d, gy, wb, None, torch.empty_like(x), addend=odd[0], addend2=odd[1])
         assert torch.equal(two_a, two_o)
+
+
+@pytest.mark.parametrize('dtype', DT, ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', [LAYERS[0], LAYERS[1], LAYERS[4], LAYERS[10]], ids=[IDS[0], IDS[1], IDS[4], IDS[10]])
+def test_three_kernel_rows_per_workgroup_give_the_same_bits(case, dtype):
+    """round 6: the ring weight gradient's 64-co tile runs the three kernel rows of a tile as one 768-thread workgroup (three four-wave
+    groups in lockstep, conv_wgrad_ring.hip: KG) instead of three 256-thread workgroups: same slices, same walk, same order of the f32
+    adds -- bit-equal to the rounds 3-5 launch on the 64-channel full-resolution layers, the 128 -> 128 and the 128 -> 32 ones."""
+    hip, d, x, w, wf, wb, gy, oshape = _layer(case, dtype, seed=4)
+    lib = hip.lib()
+    try:
+        lib.rdfc_tune_wgrad_kg(1)
+        a = hip.conv_wgrad(d, x, gy)
+        ka = lib.rdfc_last_kernel().decode()
+        lib.rdfc_tune_wgrad_kg(0)
+        b = hip.conv_wgrad(d, x, gy)
+        kb = lib.rdfc_last_kernel().decode()
+    finally:
+        lib.rdfc_tune_wgrad_kg(1)
+    assert ka.endswith(', 3>') and kb.endswith(', 1>') and 'wgrad_ring2_kernel<64' in ka, (ka, kb)
+    assert torch.equal(a, b)
