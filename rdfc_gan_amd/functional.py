@@ -289,10 +289,13 @@ def _geometry(spec, x, weight):
     return Cout, Ho, Wo
 
 
+_STEM_FOLD = os.environ.get('RDFC_STEM_FOLD', '1') != '0'       # RDFC_STEM_FOLD=0: act_bwd + bias sum + weight gradient as three passes (A/B)
+
+
 def _stem_backward(ctx, spec, x, weight, dz, yout, d_alias):
     """the backward of a conv + bias + ReLU / LeakyReLU block that needs NO input gradient and whose parameters' .grad buffers take
     accumulation (FlatAdam's): one launch for weight and bias gradient with the activation's backward folded in.  -> True if it ran"""
-    if (ctx.needs_input_grad[0] or d_alias is not None or spec.reflect or spec.transposed or spec.wscale != 1.0 or not x.is_cuda
+    if (not _STEM_FOLD or ctx.needs_input_grad[0] or d_alias is not None or spec.reflect or spec.transposed or spec.wscale != 1.0 or not x.is_cuda
             or spec.act not in ('relu', 'lrelu') or not ctx.needs_input_grad[1]):
         return False
     g, bg = weight.grad, (ctx.bias.grad if ctx.has_bias else None)
