@@ -394,18 +394,31 @@ def broadcast_module_state(modules, src=0):
 
 
 def resync_replicas(modules, optimizers, src=0):
-    """Make every rank a copy of rank `src` again: parameters and buffers (broadcast_module_state), Adam moments, step counts and the
-    device-side loss-scaler state of every optimizer.  For diagnostics that let replicas drift on purpose (bench.py's
-    collectives-off leg runs optimizer steps on local gradients); training never needs it."""
+    """Make every rank a copy of rank `src` again: parameters (the optimizers' flat buffers: the parameters are views of them), module
+    buffers (packed into one tensor per dtype: a few hundred BatchNorm statistics one broadcast each cost a gloo job a minute), Adam
+    moments, step counts and the device-side loss-scaler state of every optimizer.  For diagnostics that let replicas drift on purpose
+    (bench.py's collectives-off leg runs optimizer steps on local gradients); training never needs it."""
     if not dp_active():
         return
-    broadcast_module_state(modules, src)
     seen = set()
     for o in optimizers:
-        for t in (o.exp_avg, o.exp_avg_sq, o._ostate, o._hyper, getattr(o.scaler, 'state', None)):
+        for t in (o.flat, o.exp_avg, o.exp_avg_sq, o._ostate, o._hyper, getattr(o.scaler, 'state', None)):
             if t is not None and id(t) not in seen:
                 seen.add(id(t))
                 dist.broadcast(t, src)
         steps = torch.tensor([o.steps], dtype=torch.int64, device=o.flat.device)
         dist.broadcast(steps, src)
         o.steps = int(steps)
+    covered = {p.data_ptr() for o in optimizers for p in o._params}
+    rest = [t for m in modules for t in list(m.parameters()) + list(m.buffers()) if t.data_ptr() not in covered and t.numel() > 0]
+    by_dtype = {}
+    for t in rest:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dt_, ts in by_dtype.items():
+        packed = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(packed, src)
+        off = 0
+        for t in ts:
+            t.data.copy_(packed[off:off + t.numel()].view_as(t))
+            off += t.numel()
+    Fh.invalidate_packed_weights()

@@ -40,7 +40,7 @@ _RESULTS = {}
 
 
 def _run_all():
-    """every variant's child pytest, THREE at a time (round 6: one after the other they were 216 s of a 720 s suite -- each is mostly process
+    """every variant's child pytest, FOUR at a time (round 6: one after the other they were 216 s of a 720 s suite -- each is mostly process
     start-up, host-side references and small launches; the children share the GPU like any two processes do).  Started by the first of
     the parametrised tests below, which then only look up their own child's outcome."""
     if _RESULTS:
@@ -51,8 +51,8 @@ def _run_all():
         name, value, expr = variant[:3]
         test_files = variant[3:] if len(variant) > 3 else ('test_kernels_gpu.py',)
         # (each child computes its fp32 references on the host with torch's thread pool: three pools of cpu_count threads each oversubscribe
-        #  the cores several-fold and everything crawls -- a third of the cores per child)
-        nthr = str(max(4, (os.cpu_count() or 12) // 3))
+        #  the cores several-fold and everything crawls -- a quarter of the cores per child)
+        nthr = str(max(4, (os.cpu_count() or 16) // 4))
         env = dict(os.environ, OMP_NUM_THREADS=nthr, MKL_NUM_THREADS=nthr, **{name: value})
         try:
             r = subprocess.run([sys.executable, '-m', 'pytest'] + [os.path.join(ROOT, 'tests', f) for f in test_files] + ['-q', '-x', '-k', expr, '-p', 'no:cacheprovider'],
@@ -60,7 +60,7 @@ def _run_all():
             return r.returncode, (r.stdout + r.stderr)[-2500:]
         except subprocess.TimeoutExpired as e:
             return -1, f'timed out: {e}'
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         for variant, res in zip(VARIANTS, ex.map(one, VARIANTS)):
             _RESULTS[variant[:2]] = res
 
