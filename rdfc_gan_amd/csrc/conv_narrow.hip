@@ -26,6 +26,8 @@
 // the partials in a fixed order (bit-reproducible, no float atomics).
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int NT = 256, TH = 8, TW = 64, PH = TH + 2, PW = TW + 2;
@@ -333,7 +335,9 @@ struct NWScratch {
 };
 NWScratch g_nw[64];
 int g_nnw = 0;
+std::mutex g_nw_mu;                                                // (the autograd engine's thread and the caller's may both launch weight gradients)
 float *nw_scratch(hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_nw_mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     for (int i = 0; i < g_nnw; ++i)
