@@ -240,6 +240,17 @@ int rdfc_norm_bwd_apply_acc(const void *dz, const void *x, const float *mean, co
                             const float *beta, const void *res, const float *sums, void *dx, void *dres,
                             int G, int P, int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype,
                             int act, float slope, const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream);
+/* Round 6: the apply pass that ALSO sums the input gradient it stores -- the gradient of a conv bias in FRONT of the norm layer
+ * (ResnetGenerator's convs, resnet_generator.py:60-100; analytically zero, in practice the rounding noise that Adam turns into lr-sized
+ * steps, upstream's too): dbias_acc[c] += sum over groups and pixels of dx as stored; fixed-order two-stage sum (one partial row per
+ * workgroup in dxsum_scratch [rdfc_norm_dxsum_scratch_floats(G, P, C, dtype)], then rdfc_channel_sum's finalize launch): bitwise
+ * reproducible, and one pass over dx less than rdfc_channel_sum_acc behind rdfc_norm_bwd_apply.  dbias_acc NULL: rdfc_norm_bwd_apply_acc. */
+int rdfc_norm_dxsum_scratch_floats(int G, int P, int C, int dtype);
+int rdfc_norm_bwd_apply_dxsum(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                              const float *beta, const void *res, const float *sums, void *dx, void *dres,
+                              int G, int P, int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype,
+                              int act, float slope, const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc,
+                              float *dxsum_scratch, float *dbias_acc, void *stream);
 /* One layer's launches behind one call (the same kernels, in the same order, on the same stream as the three-call sequences above:
  * reduction launch -> fixed-order f64 finalize launch -> apply pass; bitwise reproducible).  scratch: f32
  * [rdfc_norm_scratch_floats(G, rdfc_norm_nchunk(P, C, dtype), K, C)], K = 2 (forward) / 3 (backward): the partial rows + the f64
@@ -269,6 +280,12 @@ int rdfc_norm_backward(const void *dz, const void *x, const float *mean, const f
                        const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P, int C,
                        int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope, const float *prelu,
                        int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream);
+/* rdfc_norm_backward + the bias gradient of rdfc_norm_bwd_apply_dxsum */
+int rdfc_norm_backward_dxsum(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                       const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P, int C,
+                       int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope, const float *prelu,
+                       int frozen_stats, float *dbeta_acc, float *dgamma_acc,
+                             float *dxsum_scratch, float *dbias_acc, void *stream);
 
 /* W-AdaIN (model_utils.py:72-90): out = gb[:, 0:C] * IN(x) + gb[:, C:2C], gb = per-pixel style affine. */
 int rdfc_adain_apply(const void *x, const float *mean, const float *rstd, const void *gb, void *out,

@@ -486,15 +486,23 @@ __global__ __launch_bounds__(FNT2) void sum_finalize_kernel(int G, int C, int K,
     }
 }
 
-template <typename T>
+template <typename T, bool DXS = false>        // DXS: also the partial rows of sum(stored dx) -- its own instantiation: the block reduction's 8 KB of LDS stay out of the plain one
 __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const T *__restrict__ dz, const T *__restrict__ x,
                                                        const T *__restrict__ res, const float *__restrict__ sums,
                                                        T *__restrict__ dx, T *__restrict__ dres, int lddz, int ldx, int ldr,
                                                        int lddx, int lddr, int frozen, float *__restrict__ dbeta_acc,
-                                                       float *__restrict__ dgamma_acc) {
+                                                       float *__restrict__ dgamma_acc, float *__restrict__ dxsum) {
     constexpr int VEC = Elem<T>::VEC;
     Ctx<T> cx(m);
-    if (!cx.active) return;
+    // dxsum (round 6): per-workgroup partial rows [g][chunk][C] of the sum over pixels of the STORED input gradient -- the gradient of a
+    // conv bias in front of the norm layer (ResnetGenerator's convs, resnet_generator.py:60-100: analytically zero, in practice the
+    // rounding noise that Adam turns into lr-sized steps, upstream's too); it used to be one more pass over dx (rdfc_channel_sum).
+    // With it every thread stays to the end (block_reduce_store has a workgroup barrier)
+    if (!cx.active && !DXS) return;
+    float sb[1][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) sb[0][v] = 0.f;
+    if (cx.active) {
     // d beta / d gamma of an affine norm straight into their .grad: ONE thread per channel adds the groups' sums (BatchNorm over
     // stacked batches has one set per group) in group order and issues one add -- reproducible whatever the launch order of the
     // workgroups; the add is atomic because a parameter's two uses per step may run their backward on different streams
@@ -544,10 +552,16 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(Map m, ApplyArgs a, const
             o.set(v, sc[v] * (du - m1[v] - xh * m2[v]));
             orr.set(v, du);
         }
+        if constexpr (DXS) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) sb[0][v] += o.get(v);     // (the rounded value that is stored)
+        }
         o.ST(dx + (gb + p) * lddx + cx.c0);
         if (dres) orr.ST(dres + (gb + p) * lddr + cx.c0);
     };
         ROW_LOOP(cx, body);
+    }
+    if constexpr (DXS) block_reduce_store<T, 1>(cx, m, sb, dxsum);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -862,18 +876,58 @@ extern "C" int rdfc_norm_bwd_finalize(const float *partial, float *sums, int G, 
     return rdfc_norm_bwd_finalize_acc(partial, sums, G, P, C, dtype, nullptr, nullptr, stream);
 }
 
+// floats of scratch the dx-sum variants need: the apply pass's partial rows [G][chunks][C] + the finalized sums [C]
+extern "C" int rdfc_norm_dxsum_scratch_floats(int G, int P, int C, int dtype) {
+    if (!rdfc_dtype_ok(dtype) || G < 1 || P < 1 || C < 1) return 0;
+    const Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
+    return G * cdiv(P, m.chunk) * C + C;
+}
+// the apply pass; dxsum_scratch (rdfc_norm_dxsum_scratch_floats) + dbias_acc: also dbias_acc[c] += sum over groups and pixels of the stored dx
+// (a fixed-order two-stage sum: partial rows per workgroup, then the finalize launch of rdfc_channel_sum -- bit-reproducible)
+static int bwd_apply_launch(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                            const void *res, const float *sums, void *dx, void *dres, int G, int P, int C, int lddz, int ldx, int ldr,
+                            int lddx, int lddr, int dtype, int act, float slope, const float *prelu, int frozen_stats, float *dbeta_acc,
+                            float *dgamma_acc, float *dxsum_scratch, float *dbias_acc, void *stream) {
+    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
+    ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
+    float *part = dbias_acc != nullptr ? dxsum_scratch : nullptr;
+    if (part == nullptr) {
+        DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
+                                           (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
+                                           lddx, lddr, frozen_stats, dbeta_acc, dgamma_acc, nullptr));
+    } else {
+        DISPATCH(dtype, hipLaunchKernelGGL((bwd_apply_kernel<T, true>), grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
+                                           (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
+                                           lddx, lddr, frozen_stats, dbeta_acc, dgamma_acc, part));
+        const int rows = G * cdiv(P, m.chunk);
+        RDFC_FC_DISPATCH(pick_fc(rows), hipLaunchKernelGGL(sum_finalize_kernel<FC>, dim3(cdiv(C, FC), 1), dim3(FNT2), 0, (hipStream_t)stream, 1, C, 1, rows,
+                                                          part, part + (size_t)rows * C, dbias_acc, nullptr));
+    }
+    return 0;
+}
+
 extern "C" int rdfc_norm_bwd_apply_acc(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
                                        const float *beta, const void *res, const float *sums, void *dx, void *dres, int G, int P,
                                        int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
                                        const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream) {
     if (int e = check_map("rdfc_norm_bwd_apply", G, P, C, dtype, {lddz, ldx, lddx})) return e;
     RDFC_REQUIRE(dbeta_acc != nullptr || dgamma_acc == nullptr, "rdfc_norm_bwd_apply_acc: d gamma accumulates together with d beta");
-    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
-    ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
-    DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                       (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
-                                       lddx, lddr, frozen_stats, dbeta_acc, dgamma_acc));
+    bwd_apply_launch(dz, x, mean, rstd, gamma, beta, res, sums, dx, dres, G, P, C, lddz, ldx, ldr, lddx, lddr, dtype, act, slope, prelu, frozen_stats,
+                     dbeta_acc, dgamma_acc, nullptr, nullptr, stream);
     RDFC_LAUNCH_CHECK("rdfc_norm_bwd_apply");
+    return 0;
+}
+extern "C" int rdfc_norm_bwd_apply_dxsum(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                                         const float *beta, const void *res, const float *sums, void *dx, void *dres, int G, int P,
+                                         int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
+                                         const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, float *dxsum_scratch,
+                                         float *dbias_acc, void *stream) {
+    if (int e = check_map("rdfc_norm_bwd_apply_dxsum", G, P, C, dtype, {lddz, ldx, lddx})) return e;
+    RDFC_REQUIRE(dbeta_acc != nullptr || dgamma_acc == nullptr, "rdfc_norm_bwd_apply_dxsum: d gamma accumulates together with d beta");
+    RDFC_REQUIRE(dbias_acc == nullptr || dxsum_scratch != nullptr, "rdfc_norm_bwd_apply_dxsum: the bias accumulator needs the scratch rows");
+    bwd_apply_launch(dz, x, mean, rstd, gamma, beta, res, sums, dx, dres, G, P, C, lddz, ldx, ldr, lddx, lddr, dtype, act, slope, prelu, frozen_stats,
+                     dbeta_acc, dgamma_acc, dxsum_scratch, dbias_acc, stream);
+    RDFC_LAUNCH_CHECK("rdfc_norm_bwd_apply_dxsum");
     return 0;
 }
 
@@ -922,26 +976,43 @@ extern "C" int rdfc_norm_forward_seq(const void *x, float *scratch, float *mean,
                                         run_var, group_momentum ? group_momentum : zeros, act, slope, prelu, stream);
 }
 
-extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
-                                  const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P,
-                                  int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
-                                  const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream) {
-    if (int e = check_map("rdfc_norm_backward", G, P, C, dtype, {lddz, ldx, lddx})) return e;
-    RDFC_REQUIRE(dbeta_acc != nullptr || dgamma_acc == nullptr, "rdfc_norm_backward: d gamma accumulates together with d beta");
+static int norm_backward_impl(const char *who, const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                              const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P,
+                              int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
+                              const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, float *dxsum_scratch,
+                              float *dbias_acc, void *stream) {
+    if (int e = check_map(who, G, P, C, dtype, {lddz, ldx, lddx})) return e;
+    RDFC_REQUIRE(dbeta_acc != nullptr || dgamma_acc == nullptr, "%s: d gamma accumulates together with d beta", who);
+    RDFC_REQUIRE(dbias_acc == nullptr || dxsum_scratch != nullptr, "%s: the bias accumulator needs the scratch rows", who);
     ApplyArgs a{mean, rstd, gamma, beta, prelu, act, slope};
     {   // pass 1: the three sums (partial rows, then the fixed-order finalize launch)
         Map m = make_map(G, P, C, rdfc_vec(dtype));
         launch_bwd_reduce(dtype, m, a, dz, x, res, scratch, lddz, ldx, ldr, stream);
-        RDFC_LAUNCH_CHECK("rdfc_norm_backward (sums)");
+        RDFC_LAUNCH_CHECK(who);
         if (int e = rdfc_norm_bwd_finalize_acc(scratch, sums, G, P, C, dtype, nullptr, nullptr, stream)) return e;
     }
     // (the affine gradients are accumulated by the apply pass, which reads the sums anyway: the groups in group order)
-    Map m = make_map_stream(G, P, C, rdfc_vec(dtype));
-    DISPATCH(dtype, hipLaunchKernelGGL(bwd_apply_kernel<T>, grid_for(m, Elem<T>::VEC), dim3(NT), 0, (hipStream_t)stream, m, a,
-                                       (const T *)dz, (const T *)x, (const T *)res, sums, (T *)dx, (T *)dres, lddz, ldx, ldr,
-                                       lddx, lddr, frozen_stats, dbeta_acc, dgamma_acc));
-    RDFC_LAUNCH_CHECK("rdfc_norm_backward");
+    bwd_apply_launch(dz, x, mean, rstd, gamma, beta, res, sums, dx, dres, G, P, C, lddz, ldx, ldr, lddx, lddr, dtype, act, slope, prelu, frozen_stats,
+                     dbeta_acc, dgamma_acc, dxsum_scratch, dbias_acc, stream);
+    RDFC_LAUNCH_CHECK(who);
     return 0;
+}
+
+extern "C" int rdfc_norm_backward(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                                  const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P,
+                                  int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
+                                  const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, void *stream) {
+    return norm_backward_impl("rdfc_norm_backward", dz, x, mean, rstd, gamma, beta, res, scratch, sums, dx, dres, G, P, C, lddz, ldx, ldr, lddx, lddr,
+                              dtype, act, slope, prelu, frozen_stats, dbeta_acc, dgamma_acc, nullptr, nullptr, stream);
+}
+// the same + the gradient of a conv bias in front of the norm layer: dbias_acc[c] += sum of the stored dx (see bwd_apply_kernel: dxsum)
+extern "C" int rdfc_norm_backward_dxsum(const void *dz, const void *x, const float *mean, const float *rstd, const float *gamma,
+                                        const float *beta, const void *res, float *scratch, float *sums, void *dx, void *dres, int G, int P,
+                                        int C, int lddz, int ldx, int ldr, int lddx, int lddr, int dtype, int act, float slope,
+                                        const float *prelu, int frozen_stats, float *dbeta_acc, float *dgamma_acc, float *dxsum_scratch,
+                                        float *dbias_acc, void *stream) {
+    return norm_backward_impl("rdfc_norm_backward_dxsum", dz, x, mean, rstd, gamma, beta, res, scratch, sums, dx, dres, G, P, C, lddz, ldx, ldr, lddx,
+                              lddr, dtype, act, slope, prelu, frozen_stats, dbeta_acc, dgamma_acc, dxsum_scratch, dbias_acc, stream);
 }
 
 extern "C" int rdfc_adain_apply(const void *x, const float *mean, const float *rstd, const void *gb, void *out, int N, int P,

@@ -289,6 +289,7 @@ def _geometry(spec, x, weight):
     return Cout, Ho, Wo
 
 
+_BIAS_IN_APPLY = os.environ.get('RDFC_BIAS_IN_APPLY', '1') != '0'   # RDFC_BIAS_IN_APPLY=0: the bias gradient behind a norm layer by its own pass (A/B)
 _STEM_FOLD = os.environ.get('RDFC_STEM_FOLD', '1') != '0'       # RDFC_STEM_FOLD=0: act_bwd + bias sum + weight gradient as three passes (A/B)
 
 
@@ -422,9 +423,14 @@ class _ConvBlock(torch.autograd.Function):
             # affine gradients straight into persistent .grad buffers (FlatAdam's) when there is one statistics group
             direct = (gamma is not None and beta is not None and ctx.needs_input_grad[3]
                       and ctx.needs_input_grad[4] and _accumulable(gamma.grad) and _accumulable(beta.grad))
+            # a conv bias in front of the norm layer (ResnetGenerator): its gradient = the sum of dy over the pixels, taken by the apply pass
+            # while it stores dy (rdfc_norm_backward_dxsum) instead of by one more pass over dy
+            bias_in_apply = (_BIAS_IN_APPLY and ctx.has_bias and ctx.needs_input_grad[2] and _accumulable(ctx.bias.grad) and y.is_cuda
+                             and y.dtype != torch.float64)
             dy, g_res, sums = hip.norm_backward(dz, y, mean, rstd, gamma, beta, res, spec.act, spec.slope, prelu,
                               frozen=frozen, want_dres=res is not None and ctx.needs_input_grad[5],
-                              acc_beta=beta.grad if direct else None, acc_gamma=gamma.grad if direct else None)
+                              acc_beta=beta.grad if direct else None, acc_gamma=gamma.grad if direct else None,
+                              acc_bias=ctx.bias.grad if bias_in_apply else None)
             if gamma is not None and not direct:
                 g_gamma, g_beta = (sums[0, 1], sums[0, 0]) if sums.shape[0] == 1 else (sums[:, 1].sum(0), sums[:, 0].sum(0))
             if prelu is not None:
@@ -445,7 +451,7 @@ class _ConvBlock(torch.autograd.Function):
                 dy = hip.act_bwd(dz, yout, spec.act, spec.slope)
             else:
                 dy = dz if dz.dtype == x.dtype else dz.to(x.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not (has_norm and bias_in_apply):
             bg = ctx.bias.grad
             if _accumulable(bg) and not dy.dtype == torch.float64:
                 hip.channel_sum(dy, acc=bg)         # straight into the persistent .grad (FlatAdam's)

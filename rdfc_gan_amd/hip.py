@@ -583,9 +583,11 @@ def norm_apply(x, mean, rstd, gamma, beta, res, z, act='none', slope=0.0, prelu=
 
 
 def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, prelu=None, frozen=False,
-                  want_dres=False, acc_beta=None, acc_gamma=None):
+                  want_dres=False, acc_beta=None, acc_gamma=None, acc_bias=None):
     """-> dx, dres (or None), sums[G,3,C] (sum du, sum du*xhat, sum dz*min(u,0)).
     acc_beta / acc_gamma: f32[C] buffers that additionally receive += the sums over all groups of sums[g,0] / sums[g,1].
+    acc_bias: f32[C] buffer that receives += the sum over pixels of dx as stored (the gradient of a conv bias in front of the norm
+    layer: round 6, rdfc_norm_backward_dxsum -- one pass over dx less than channel_sum(dx, acc=...)).
     One call: reduce + finalize + apply (rdfc_norm_backward)."""
     N, H, W, Cc = x.shape
     G = mean.shape[0]
@@ -596,6 +598,9 @@ def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, pr
     base = buf.data_ptr()
     dx = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device)
     dres = torch.empty(N, H, W, Cc, dtype=x.dtype, device=x.device) if want_dres else None
+    dxs = None
+    if acc_bias is not None:
+        dxs = torch.empty(lib().rdfc_norm_dxsum_scratch_floats(G, P, Cc, d), dtype=torch.float32, device=x.device)
     if PROFILE_HBM is not None:
         mb, nr = x.numel() * x.element_size(), 2 + (res is not None)
         ps = base + 4 * npart
@@ -604,9 +609,14 @@ def norm_backward(dz, x, mean, rstd, gamma, beta, res, act='none', slope=0.0, pr
                                             ld(res) if res is not None else 0, d, ACT[act], _f(slope), _p(prelu), _st()), 'rdfc_norm_bwd_reduce')
         _chk(lib().rdfc_norm_bwd_finalize(base, ps, G, P, Cc, d, _st()), 'rdfc_norm_bwd_finalize')
         with _TimedHBM('bwd_apply_kernel', mb * (nr + 1 + bool(want_dres))):
-            _chk(lib().rdfc_norm_bwd_apply_acc(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ps, _p(dx), _p(dres), G, P, Cc,
-                                               ld(dz), ld(x), ld(res) if res is not None else 0, Cc, Cc, d, ACT[act], _f(slope), _p(prelu),
-                                               int(frozen), _p(acc_beta), _p(acc_gamma), _st()), 'rdfc_norm_bwd_apply_acc')
+            _chk(lib().rdfc_norm_bwd_apply_dxsum(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), ps, _p(dx), _p(dres), G, P, Cc,
+                                                 ld(dz), ld(x), ld(res) if res is not None else 0, Cc, Cc, d, ACT[act], _f(slope), _p(prelu),
+                                                 int(frozen), _p(acc_beta), _p(acc_gamma), _p(dxs), _p(acc_bias), _st()), 'rdfc_norm_bwd_apply_dxsum')
+        return dx, dres, buf[npart:].view(G, 3, Cc)
+    if acc_bias is not None:
+        _chk(lib().rdfc_norm_backward_dxsum(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), base, base + 4 * npart, _p(dx),
+                                            _p(dres), G, P, Cc, ld(dz), ld(x), ld(res) if res is not None else 0, Cc, Cc, d, ACT[act], _f(slope),
+                                            _p(prelu), int(frozen), _p(acc_beta), _p(acc_gamma), _p(dxs), _p(acc_bias), _st()), 'rdfc_norm_backward_dxsum')
         return dx, dres, buf[npart:].view(G, 3, Cc)
     _chk(lib().rdfc_norm_backward(_p(dz), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(res), base, base + 4 * npart, _p(dx),
                                   _p(dres), G, P, Cc, ld(dz), ld(x), ld(res) if res is not None else 0, Cc, Cc, d, ACT[act], _f(slope),

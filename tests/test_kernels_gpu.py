@@ -430,6 +430,35 @@ def test_conv_fused_statistics(case, monkeypatch):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize('shape,G', [((4, 57, 76, 256), 4), ((2, 60, 76, 64), 1), ((16, 19, 23, 128), 16), ((3, 31, 33, 40), 3)],
+                         ids=['in256', 'bn64', 'in128x16', 'in40'])
+def test_bias_gradient_from_the_norm_backward_apply_pass(shape, G, dtype):
+    """round 6 (rdfc_norm_backward_dxsum): the gradient of a conv bias in front of a norm layer = sum of dx over the pixels, taken by the
+    apply pass while it stores dx.  Must be the sum of the STORED values (what rdfc_channel_sum_acc over dx returns, up to the order of the
+    f32 adds of ~1e5 rounding errors: compared against the sum of |dx|), accumulate into its buffer, leave dx / the sums untouched and
+    repeat bit for bit (fixed-order two-stage sum)."""
+    h = hip()
+    N, H, W, C = shape
+    x = to_pm(rnd(N, C, H, W, seed=1), dtype)
+    dz = to_pm(rnd(N, C, H, W, seed=2), dtype, ld_extra=8)
+    P = N * H * W // G
+    mean, rstd = h.norm_stats(x, G, 1e-5)
+    gamma = (rnd(C, seed=3).to(DEV) * 0.1 + 1.0) if G == 1 else None
+    beta = (rnd(C, seed=4).to(DEV) * 0.1) if G == 1 else None
+    dx0, _, sums0 = h.norm_backward(dz, x, mean, rstd, gamma, beta, None, 'relu', 0.0, None)
+    ref = h.channel_sum(dx0)
+    runs = []
+    for _ in range(2):
+        acc = torch.full((C,), 3.0, device=DEV)
+        dx1, _, sums1 = h.norm_backward(dz, x, mean, rstd, gamma, beta, None, 'relu', 0.0, None, acc_bias=acc)
+        assert torch.equal(dx1, dx0) and torch.equal(sums1, sums0)
+        runs.append(acc)
+    assert torch.equal(runs[0], runs[1])
+    scale = float(dx0.float().abs().sum(dim=(0, 1, 2)).max())
+    assert float((runs[0] - 3.0 - ref).abs().max()) <= 2e-6 * scale + 1e-6, (float((runs[0] - 3.0 - ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_adain(dtype):
     h = hip()
     N, H, W, C = 2, 7, 9, 192

@@ -29,6 +29,8 @@ VARIANTS = [
     ('RDFC_GLDS_JR', '10', JRK, 'test_kernels_gpu.py', 'test_fullsize_gpu.py'),
     # round 6: epilogue addends as 8-byte pieces on the way into the staging tile (the path of rounds 4-5) instead of whole rows from the flush
     ('RDFC_RSF', '0', 'addend and not f32'),
+    # round 6: the bias gradient behind a norm layer by its own pass over dy (rdfc_channel_sum_acc) instead of the apply pass's sums
+    ('RDFC_BIAS_IN_APPLY', '0', 'test_g_b2a or test_train_step_against_upstream_trace', 'test_modules_gpu.py'),
     # round 6: the stems' backward as three passes (rdfc_act_bwd, bias sum, weight gradient) instead of rdfc_conv2d_wgrad_act
     ('RDFC_STEM_FOLD', '0', 'test_train_step_against_upstream_trace or test_g_a2b', 'test_modules_gpu.py'),
     # round 6: one kernel row per 256-thread workgroup in the ring weight gradient's 64-co tile (rounds 3-5) instead of three rows in lockstep
