@@ -35,5 +35,6 @@ def test_stale_counters_are_refused_and_fresh_ones_fill_the_block():
     roof = dict(traffic=None, avg_launch_us=120.0)
     m = bench.pmc_for_kernel(roof, top, '', meta['csrc_sha16'])
     assert m is not None and roof['traffic'] > 5e7 and 0.05 < roof['mfma_busy']['frac_of_simd_cycles'] < 1.0
-    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r06_bench.json')).read().strip().splitlines()[-1])
+    tag = os.path.basename(fname).split('_')[0]                       # the bench line of the same round's artefacts
+    line = json.loads(open(os.path.join(ROOT, 'profiles', f'{tag}_bench.json')).read().strip().splitlines()[-1])
     assert line['roofline']['traffic'] == roof['traffic'] and abs(line['fabric_gb_per_step'] - m['fabric_gb_per_step']) < 1e-6
